@@ -1,0 +1,627 @@
+"""Operators of the hipla protocol: BaseMatrix (subclassable from user code),
+SparseMatrix (CSR in HBM), block / scaled / product / sum / transpose / identity
+wrappers, and the two native preconditioners of the hot path (point / block Jacobi).
+
+Reference call sites this mirrors: operator algebra
+``M*v, -M*v, s*M, M.T, M@N, M+N, IdentityMatrix()-M, -IdentityMatrix(n),
+M.CreateTranspose(), .height/.width, Create{Col,Row,}Vector, BlockMatrix([[..]])``
+(bramble_pasciak_cg.py:24-36,50-62,77-85,102,125-127,135;
+solvers/bramblepasciak_new.py:88,122,160,198; run.py:45-46) and the hooks the
+runtime calls back on user subclasses: ``Mult, MultAdd, MultTrans, MultTransAdd,
+Height, Width, Create*Vector`` (bramble_pasciak_cg.py:16-36,45-62;
+templates/NavierStokesSIMPLE_iterative.py:272-288,375-389).
+"""
+
+import numpy as np
+
+from .engine import get_engine
+from .vector import BaseVector, BlockVector, Expr, Term, Vector, _DataProxy, _is_scalar, as_expr
+
+
+class BaseMatrix:
+    """Abstract linear operator.  Subclass and override ``Mult`` or ``MultAdd``
+    (and ``Height``/``Width``); everything else has defaults."""
+
+    def __init__(self):
+        pass
+
+    # ---- shape -----------------------------------------------------------
+    def Height(self):
+        raise NotImplementedError("%s must implement Height()" % type(self).__name__)
+
+    def Width(self):
+        raise NotImplementedError("%s must implement Width()" % type(self).__name__)
+
+    @property
+    def height(self):
+        return self.Height()
+
+    @property
+    def width(self):
+        return self.Width()
+
+    def Shape(self):
+        return (self.height, self.width)
+
+    # ---- application hooks -----------------------------------------------
+    def _overrides(self, name):
+        return getattr(type(self), name) is not getattr(BaseMatrix, name)
+
+    def Mult(self, x, y):
+        if not self._overrides("MultAdd"):
+            raise NotImplementedError("%s implements neither Mult nor MultAdd" % type(self).__name__)
+        y[:] = 0.0
+        self.MultAdd(1.0, x, y)
+
+    def MultAdd(self, s, x, y):
+        if not self._overrides("Mult"):
+            raise NotImplementedError("%s implements neither Mult nor MultAdd" % type(self).__name__)
+        tmp = y.CreateVector()
+        self.Mult(x, tmp)
+        y._accumulate(as_expr(tmp) * s)
+
+    def MultTrans(self, x, y):
+        if not self._overrides("MultTransAdd"):
+            raise NotImplementedError("%s implements neither MultTrans nor MultTransAdd" % type(self).__name__)
+        y[:] = 0.0
+        self.MultTransAdd(1.0, x, y)
+
+    def MultTransAdd(self, s, x, y):
+        if not self._overrides("MultTrans"):
+            raise NotImplementedError("%s implements neither MultTrans nor MultTransAdd" % type(self).__name__)
+        tmp = y.CreateVector()
+        self.MultTrans(x, tmp)
+        y._accumulate(as_expr(tmp) * s)
+
+    # ---- vector factories --------------------------------------------------
+    def CreateColVector(self):
+        return Vector(self.height)
+
+    def CreateRowVector(self):
+        return Vector(self.width)
+
+    def CreateVector(self):
+        return self.CreateColVector()
+
+    # ---- algebra -------------------------------------------------------------
+    def __mul__(self, other):
+        if isinstance(other, _DataProxy):
+            other = other.owner
+        if isinstance(other, BaseVector):
+            return Expr([Term(1.0, self, other)])
+        if isinstance(other, Expr):
+            if len(other.terms) == 1 and other.terms[0].mat is None:
+                t = other.terms[0]
+                return Expr([Term(t.scale, self, t.vec)])
+            return Expr([Term(1.0, self, other.materialize())])
+        if _is_scalar(other):
+            return ScaledMatrix(float(other), self)
+        return NotImplemented
+
+    def __rmul__(self, other):
+        if _is_scalar(other):
+            return ScaledMatrix(float(other), self)
+        return NotImplemented
+
+    def __neg__(self):
+        return ScaledMatrix(-1.0, self)
+
+    def __matmul__(self, other):
+        if isinstance(other, BaseMatrix):
+            return ProductMatrix(self, other)
+        return NotImplemented
+
+    def __add__(self, other):
+        if isinstance(other, BaseMatrix):
+            return SumMatrix(self, other, 1.0)
+        return NotImplemented
+
+    def __sub__(self, other):
+        if isinstance(other, BaseMatrix):
+            return SumMatrix(self, other, -1.0)
+        return NotImplemented
+
+    @property
+    def T(self):
+        return TransposeMatrix(self)
+
+    def CreateTranspose(self):
+        return TransposeMatrix(self)
+
+
+def _col_like(mat, fallback):
+    """Column vector for an intermediate result of `mat`; user subclasses may
+    return a plain vector where a block one is needed (reference quirk,
+    bramble_pasciak_cg.py:58-59) -- then follow the layout of `fallback`."""
+    try:
+        v = mat.CreateColVector()
+    except NotImplementedError:
+        return fallback.CreateVector()
+    return v
+
+
+class ScaledMatrix(BaseMatrix):
+    def __init__(self, scale, mat):
+        super().__init__()
+        if isinstance(mat, ScaledMatrix):
+            scale, mat = scale * mat.scale, mat.mat
+        self.scale = float(scale)
+        self.mat = mat
+
+    def Height(self):
+        return self.mat.height
+
+    def Width(self):
+        return self.mat.width
+
+    def Mult(self, x, y):
+        self.mat.Mult(x, y)
+        if self.scale != 1.0:
+            y *= self.scale
+
+    def MultAdd(self, s, x, y):
+        self.mat.MultAdd(s * self.scale, x, y)
+
+    def MultTrans(self, x, y):
+        self.mat.MultTrans(x, y)
+        if self.scale != 1.0:
+            y *= self.scale
+
+    def MultTransAdd(self, s, x, y):
+        self.mat.MultTransAdd(s * self.scale, x, y)
+
+    def CreateColVector(self):
+        return self.mat.CreateColVector()
+
+    def CreateRowVector(self):
+        return self.mat.CreateRowVector()
+
+
+class TransposeMatrix(BaseMatrix):
+    def __init__(self, mat):
+        super().__init__()
+        self.mat = mat
+
+    def Height(self):
+        return self.mat.width
+
+    def Width(self):
+        return self.mat.height
+
+    def Mult(self, x, y):
+        self.mat.MultTrans(x, y)
+
+    def MultAdd(self, s, x, y):
+        self.mat.MultTransAdd(s, x, y)
+
+    def MultTrans(self, x, y):
+        self.mat.Mult(x, y)
+
+    def MultTransAdd(self, s, x, y):
+        self.mat.MultAdd(s, x, y)
+
+    def CreateColVector(self):
+        return self.mat.CreateRowVector()
+
+    def CreateRowVector(self):
+        return self.mat.CreateColVector()
+
+    @property
+    def T(self):
+        return self.mat
+
+
+class ProductMatrix(BaseMatrix):
+    """``a @ b``: y = a (b x) through one intermediate vector."""
+
+    def __init__(self, a, b):
+        super().__init__()
+        self.a, self.b = a, b
+        self._tmp = None
+
+    def Height(self):
+        return self.a.height
+
+    def Width(self):
+        return self.b.width
+
+    def _mid(self, x):
+        if self._tmp is None:
+            self._tmp = _col_like(self.b, x)
+        return self._tmp
+
+    def Mult(self, x, y):
+        t = self._mid(x)
+        self.b.Mult(x, t)
+        self.a.Mult(t, y)
+
+    def MultAdd(self, s, x, y):
+        t = self._mid(x)
+        self.b.Mult(x, t)
+        self.a.MultAdd(s, t, y)
+
+    def MultTrans(self, x, y):
+        t = self.a.CreateRowVector()
+        self.a.MultTrans(x, t)
+        self.b.MultTrans(t, y)
+
+    def MultTransAdd(self, s, x, y):
+        t = self.a.CreateRowVector()
+        self.a.MultTrans(x, t)
+        self.b.MultTransAdd(s, t, y)
+
+    def CreateColVector(self):
+        return self.a.CreateColVector()
+
+    def CreateRowVector(self):
+        return self.b.CreateRowVector()
+
+
+class SumMatrix(BaseMatrix):
+    """``a + sb * b``"""
+
+    def __init__(self, a, b, sb):
+        super().__init__()
+        self.a, self.b, self.sb = a, b, float(sb)
+
+    def _shape_of(self, which):
+        for m in (self.a, self.b):
+            v = getattr(m, which)
+            if v is not None:
+                return v
+        return None
+
+    def Height(self):
+        return self._shape_of("height")
+
+    def Width(self):
+        return self._shape_of("width")
+
+    def Mult(self, x, y):
+        self.a.Mult(x, y)
+        self.b.MultAdd(self.sb, x, y)
+
+    def MultAdd(self, s, x, y):
+        self.a.MultAdd(s, x, y)
+        self.b.MultAdd(s * self.sb, x, y)
+
+    def MultTrans(self, x, y):
+        self.a.MultTrans(x, y)
+        self.b.MultTransAdd(self.sb, x, y)
+
+    def MultTransAdd(self, s, x, y):
+        self.a.MultTransAdd(s, x, y)
+        self.b.MultTransAdd(s * self.sb, x, y)
+
+    def CreateColVector(self):
+        return (self.a if self.a.height is not None else self.b).CreateColVector()
+
+    def CreateRowVector(self):
+        return (self.a if self.a.width is not None else self.b).CreateRowVector()
+
+
+class IdentityMatrix(BaseMatrix):
+    """``IdentityMatrix(n)``; ``IdentityMatrix()`` is size-agnostic
+    (solvers/bramblepasciak_new.py:88)."""
+
+    def __init__(self, n=None):
+        super().__init__()
+        self.n = None if n is None else int(n)
+
+    def Height(self):
+        return self.n
+
+    def Width(self):
+        return self.n
+
+    def Mult(self, x, y):
+        y._assign(as_expr(x))
+
+    def MultAdd(self, s, x, y):
+        y._accumulate(as_expr(x) * s)
+
+    MultTrans = Mult
+    MultTransAdd = MultAdd
+
+    @property
+    def T(self):
+        return self
+
+
+class BlockMatrix(BaseMatrix):
+    """2-D list of operators; ``None`` is a zero block (bramble_pasciak_cg.py:77-85,
+    run.py:45-46).  ``y_i = sum_j M_ij x_j`` evaluated block-row by block-row."""
+
+    def __init__(self, rows):
+        super().__init__()
+        self.rows = [list(r) for r in rows]
+        self.nrows = len(self.rows)
+        self.ncols = len(self.rows[0])
+        if any(len(r) != self.ncols for r in self.rows):
+            raise ValueError("ragged BlockMatrix")
+
+    def __getitem__(self, ij):
+        i, j = ij
+        return self.rows[i][j]
+
+    def _row_op(self, i):
+        for m in self.rows[i]:
+            if m is not None and m.height is not None:
+                return m
+        raise ValueError("block row %d has no sized operator" % i)
+
+    def _col_op(self, j):
+        for r in self.rows:
+            if r[j] is not None and r[j].width is not None:
+                return r[j]
+        raise ValueError("block column %d has no sized operator" % j)
+
+    def Height(self):
+        return sum(self._row_op(i).height for i in range(self.nrows))
+
+    def Width(self):
+        return sum(self._col_op(j).width for j in range(self.ncols))
+
+    def CreateColVector(self):
+        return BlockVector([Vector(self._row_op(i).height) for i in range(self.nrows)])
+
+    def CreateRowVector(self):
+        return BlockVector([Vector(self._col_op(j).width) for j in range(self.ncols)])
+
+    def Mult(self, x, y):
+        y[:] = 0.0
+        self.MultAdd(1.0, x, y)
+
+    def MultAdd(self, s, x, y):
+        for i, row in enumerate(self.rows):
+            for j, m in enumerate(row):
+                if m is not None:
+                    m.MultAdd(s, x[j], y[i])
+
+    def MultTrans(self, x, y):
+        y[:] = 0.0
+        self.MultTransAdd(1.0, x, y)
+
+    def MultTransAdd(self, s, x, y):
+        for i, row in enumerate(self.rows):
+            for j, m in enumerate(row):
+                if m is not None:
+                    m.MultTransAdd(s, x[i], y[j])
+
+
+class SparseMatrix(BaseMatrix):
+    """fp64 CSR matrix resident in engine memory (int32 indices).
+
+    ``SparseMatrix.from_scipy(csr)`` / ``SparseMatrix(m, n, rowptr, col, val)``
+    upload host CSR arrays; SpMV runs in the engine (``csr_spmv_f64``).  The
+    explicit transpose is built once and cached (reference:
+    solvers/bramblepasciak_new.py:198 ``matB.CreateTranspose()``)."""
+
+    def __init__(self, m, n, rowptr, col, val, engine=None, host=None):
+        super().__init__()
+        self.engine = engine if engine is not None else get_engine()
+        self.m, self.n = int(m), int(n)
+        rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
+        col = np.ascontiguousarray(col, dtype=np.int32)
+        val = np.ascontiguousarray(val, dtype=np.float64)
+        if rowptr.shape != (self.m + 1,) or col.shape != val.shape or int(rowptr[-1]) != col.size:
+            raise ValueError("inconsistent CSR arrays")
+        if col.size and (col.min() < 0 or col.max() >= self.n):
+            raise ValueError("CSR column index out of range")
+        self.nnz = int(col.size)
+        self.handle = self.engine.csr_create(self.m, self.n, rowptr, col, val)
+        self._transpose = None
+        self._host = (rowptr, col, val)
+
+    @classmethod
+    def from_scipy(cls, csr, engine=None):
+        csr = csr.tocsr()
+        csr.sort_indices()
+        return cls(csr.shape[0], csr.shape[1], csr.indptr, csr.indices, csr.data, engine=engine)
+
+    def to_scipy(self):
+        import scipy.sparse as sp
+        rowptr, col, val = self._host
+        return sp.csr_matrix((val, col, rowptr), shape=(self.m, self.n))
+
+    def host_csr(self):
+        return self._host
+
+    def Height(self):
+        return self.m
+
+    def Width(self):
+        return self.n
+
+    def Mult(self, x, y):
+        self.engine.csr_spmv(self.handle, 1.0, x.buf, 0.0, y.buf)
+
+    def MultAdd(self, s, x, y):
+        self.engine.csr_spmv(self.handle, float(s), x.buf, 1.0, y.buf)
+
+    def MultTrans(self, x, y):
+        self.CreateTranspose().Mult(x, y)
+
+    def MultTransAdd(self, s, x, y):
+        self.CreateTranspose().MultAdd(s, x, y)
+
+    def CreateTranspose(self):
+        if self._transpose is None:
+            import scipy.sparse as sp
+            rowptr, col, val = self._host
+            t = sp.csr_matrix((val, col, rowptr), shape=(self.m, self.n)).transpose().tocsr()
+            t.sort_indices()
+            tm = SparseMatrix(self.n, self.m, t.indptr, t.indices, t.data, engine=self.engine)
+            tm._transpose = self
+            self._transpose = tm
+        return self._transpose
+
+    @property
+    def T(self):
+        return self.CreateTranspose()
+
+    def diagonal(self):
+        rowptr, col, val = self._host
+        d = np.zeros(min(self.m, self.n))
+        rows = np.repeat(np.arange(self.m, dtype=np.int64), np.diff(rowptr))
+        on = rows == col
+        d[rows[on]] = val[on]
+        return d
+
+    # ---- smoothers (templates/NavierStokesSIMPLE_iterative.py:253,373) -------
+    def CreateSmoother(self, freedofs=None):
+        return JacobiPreconditioner(self, freedofs=freedofs)
+
+    def CreateBlockSmoother(self, blocks):
+        return BlockJacobi(self, blocks)
+
+
+class DiagonalMatrix(BaseMatrix):
+    """``y = diag(d) x`` with ``d`` resident in engine memory (``diag_scale_f64``)."""
+
+    def __init__(self, d, engine=None):
+        super().__init__()
+        self.engine = engine if engine is not None else get_engine()
+        d = np.ascontiguousarray(d, dtype=np.float64)
+        self.n = d.size
+        self.d_host = d
+        self.d = self.engine.from_host(d)
+
+    def Height(self):
+        return self.n
+
+    def Width(self):
+        return self.n
+
+    def Mult(self, x, y):
+        self.engine.diag_apply(self.d, 1.0, x.buf, 0.0, y.buf)
+
+    def MultAdd(self, s, x, y):
+        self.engine.diag_apply(self.d, float(s), x.buf, 1.0, y.buf)
+
+    MultTrans = Mult
+    MultTransAdd = MultAdd
+
+    @property
+    def T(self):
+        return self
+
+
+class JacobiPreconditioner(DiagonalMatrix):
+    """Point Jacobi ``y_i = x_i / A_ii`` on the free dofs -- what
+    ``Preconditioner(mass, 'local')`` is for the pressure mass matrix (reference
+    call sites: templates/NavierStokesSIMPLE_iterative.py:197-200, run.py:62,
+    stokes_hcurldiv.py:50-53)."""
+
+    def __init__(self, mat, freedofs=None):
+        diag = mat.diagonal()
+        if np.any(diag == 0.0):
+            if freedofs is None:
+                raise ZeroDivisionError("zero diagonal entry in Jacobi preconditioner")
+        inv = np.zeros_like(diag)
+        mask = np.ones(diag.size, dtype=bool) if freedofs is None else np.asarray(freedofs, dtype=bool)
+        inv[mask] = 1.0 / diag[mask]
+        super().__init__(inv, engine=mat.engine)
+        self.mat = mat
+
+
+class BlockJacobi(BaseMatrix):
+    """Additive block-Jacobi ``J = sum_b E_b A_bb^{-1} E_b^T`` over disjoint dof
+    blocks -- the smoother ``a.mat.CreateBlockSmoother(blocks)`` used as an operator
+    (templates/NavierStokesSIMPLE_iterative.py:360-373,383).  Dense ``bs x bs``
+    inverses are computed once in the engine and stored block-interleaved in HBM;
+    apply is ``block_jacobi_apply_f64``.  Dofs in no block map to zero.
+
+    The multiplicative sweeps ``Smooth``/``SmoothBack`` (GS=True, :376-381) are
+    scope row N1 of SURVEY.md section 8f and not implemented."""
+
+    def __init__(self, mat, blocks):
+        super().__init__()
+        self.engine = mat.engine
+        self.mat = mat
+        self.n = mat.height
+        if isinstance(blocks, np.ndarray) and blocks.ndim == 2:
+            # prebuilt table (bs, nblocks), -1 = padding (staggered_grid.facet_blocks)
+            idx = np.ascontiguousarray(blocks, dtype=np.int32)
+            self.bs, self.nblocks = idx.shape
+        else:
+            blocks = [np.asarray(b, dtype=np.int64).ravel() for b in blocks]
+            blocks = [b for b in blocks if b.size]
+            self.nblocks = len(blocks)
+            self.bs = max(b.size for b in blocks) if blocks else 0
+            idx = -np.ones((self.bs, self.nblocks), dtype=np.int32)
+            for k, b in enumerate(blocks):
+                idx[: b.size, k] = b
+        if self.nblocks == 0:
+            raise ValueError("BlockJacobi needs at least one non-empty block")
+        if self.bs > 16:
+            raise ValueError("block size %d > 16 not supported by block_jacobi_apply_f64" % self.bs)
+        flat = idx[idx >= 0]
+        if flat.size and (flat.max() >= self.n or np.unique(flat).size != flat.size):
+            raise ValueError("BlockJacobi blocks must be disjoint and in range")
+        self.idx_host = idx
+        self.handle = self.engine.bjac_create(mat.handle, idx)
+
+    def Height(self):
+        return self.n
+
+    def Width(self):
+        return self.n
+
+    def Mult(self, x, y):
+        self.engine.bjac_apply(self.handle, 1.0, x.buf, 0.0, y.buf)
+
+    def MultAdd(self, s, x, y):
+        self.engine.bjac_apply(self.handle, float(s), x.buf, 1.0, y.buf)
+
+    MultTrans = Mult          # A_bb symmetric on this path
+    MultTransAdd = MultAdd
+
+    @property
+    def T(self):
+        return self
+
+    def Smooth(self, y, x):
+        raise NotImplementedError("multiplicative block Gauss-Seidel sweep: SURVEY.md section 8f row N1")
+
+    SmoothBack = Smooth
+
+
+class Projector(BaseMatrix):
+    """``Projector(mask, range)``: keeps entries where ``mask == range``."""
+
+    def __init__(self, mask, range=True, engine=None):
+        super().__init__()
+        m = np.asarray(mask, dtype=bool)
+        self._diag = DiagonalMatrix((m == bool(range)).astype(np.float64), engine=engine)
+
+    def Height(self):
+        return self._diag.n
+
+    def Width(self):
+        return self._diag.n
+
+    def Mult(self, x, y):
+        self._diag.Mult(x, y)
+
+    def MultAdd(self, s, x, y):
+        self._diag.MultAdd(s, x, y)
+
+    MultTrans = Mult
+    MultTransAdd = MultAdd
+
+
+def Preconditioner(form, kind, blocks=None, **_):
+    """``Preconditioner(blf, 'local')`` -> point Jacobi; ``'blockjacobi'`` -> additive
+    block Jacobi over `blocks`.  'bddc' / 'h1amg' belong to NGSolve's FE stack and are
+    out of scope."""
+    mat = form.mat if hasattr(form, "mat") else form
+    if kind == "local":
+        if blocks is not None:
+            return BlockJacobi(mat, blocks)
+        return JacobiPreconditioner(mat)
+    if kind in ("blockjacobi", "block_jacobi"):
+        if blocks is None:
+            raise ValueError("blockjacobi needs blocks=")
+        return BlockJacobi(mat, blocks)
+    raise NotImplementedError("preconditioner %r is outside the hot-path scope (SURVEY.md section 8f)" % (kind,))

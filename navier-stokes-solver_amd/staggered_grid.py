@@ -1,0 +1,223 @@
+"""Deterministic synthetic assembler: MAC (staggered-grid) Stokes systems.
+
+Netgen meshing / NGSolve FE assembly are outside the hot-path scope (SURVEY.md
+section 2, rows "FE-space factories", "MCS Stokes script"); what the Krylov path
+needs from them is the triple the drivers hand over --
+``(a.mat, b.mat, mass) + (f.vec, g.vec)`` (stokes_hcurldiv.py:75-77,
+run.py:105-106,166-167, templates/NavierStokesSIMPLE_iterative.py:397).  This module
+produces that triple for the unit square / cube with no-slip walls (SURVEY.md
+section 8d): ``A`` = nu * vector Laplacian (5-/7-point, Dirichlet in the normal and
+ghost-cell reflection in the tangential directions), ``B`` = discrete divergence,
+``M_p`` = lumped pressure mass.  Rows are scaled by the cell volume h^d (the
+integrated, FE-like form): A ~ nu h^(d-2), B ~ +-h^(d-1), M_p = h^d.
+
+Unknown ordering is *slab-major*: the slowest grid axis (y in 2-D, z in 3-D) is the
+outermost loop, inside a slab the velocity components follow each other, x is the
+fastest index.  A contiguous row range is therefore a spatial slab, which is what
+the row partition across GPUs cuts.
+
+Sizes: n_u = d n^(d-1) (n-1), n_p = n^d  (n=136, d=3: 7 490 880 + 2 515 456).
+Assembly runs on the host with numpy/scipy (set-up, not the solve path).
+"""
+
+from dataclasses import dataclass, field
+
+import numpy as np
+import scipy.sparse as sp
+
+
+def _component_ids(dim, n):
+    """Global velocity ids per component, arrays indexed [slab, ..., x]."""
+    m = n - 1
+    if dim == 2:
+        per_slab = m + n
+        S = np.arange(n, dtype=np.int64) * per_slab
+        gu = S[:, None] + np.arange(m, dtype=np.int64)[None, :]                       # (n, n-1)
+        gv = S[: n - 1, None] + m + np.arange(n, dtype=np.int64)[None, :]             # (n-1, n)
+        n_u = int(n * m + m * n)
+        return [gu, gv], S, n_u
+    if dim == 3:
+        nu_, nv_, nw_ = n * m, m * n, n * n
+        per_slab = nu_ + nv_ + nw_
+        S = np.arange(n, dtype=np.int64) * per_slab
+        j_m = np.arange(n, dtype=np.int64)
+        gu = S[:, None, None] + (j_m[None, :, None] * m + np.arange(m, dtype=np.int64)[None, None, :])
+        gv = S[:, None, None] + nu_ + (np.arange(m, dtype=np.int64)[None, :, None] * n + j_m[None, None, :])
+        gw = S[: n - 1, None, None] + nu_ + nv_ + (j_m[None, :, None] * n + j_m[None, None, :])
+        n_u = int(3 * n * n * m)
+        return [gu, gv, gw], S, n_u
+    raise ValueError("dim must be 2 or 3")
+
+
+def _axis_of_component(dim, c):
+    """Array axis (in [slab, ..., x] order) along which component c is face-centred."""
+    return dim - 1 - c       # c=0 (x-normal) -> last axis
+
+
+def _shift_slices(ndim, axis):
+    lo = [slice(None)] * ndim
+    hi = [slice(None)] * ndim
+    lo[axis] = slice(0, -1)
+    hi[axis] = slice(1, None)
+    return tuple(lo), tuple(hi)
+
+
+@dataclass
+class StokesSystem:
+    dim: int
+    n: int
+    nu: float
+    h: float
+    A: sp.csr_matrix
+    B: sp.csr_matrix
+    mass: np.ndarray
+    velocity_slab_offsets: np.ndarray      # length n+1, row offsets of the slabs in A
+    pressure_slab_offsets: np.ndarray      # length n+1, row offsets of the slabs in B
+    component_ids: list = field(repr=False, default_factory=list)
+    block_size: int = 1
+
+    @property
+    def n_u(self):
+        return self.A.shape[0]
+
+    @property
+    def n_p(self):
+        return self.B.shape[0]
+
+    @property
+    def ndof(self):
+        return self.n_u + self.n_p
+
+    def rhs(self, seed=0):
+        """f ~ N(0,1) from default_rng(seed), g = 0."""
+        rng = np.random.default_rng(seed)
+        return rng.standard_normal(self.n_u), np.zeros(self.n_p)
+
+    def saddle_matrix(self):
+        return sp.bmat([[self.A, self.B.T], [self.B, None]], format="csr")
+
+    def facet_blocks(self):
+        """One block per grid cell: its 'plus' faces (u_{i+1/2}, v_{j+1/2}[, w_{k+1/2}]) --
+        the facet-like block-Jacobi variant (bs = dim) of SURVEY.md section 8a row A7.
+        Returns an int32 array (bs, nblocks), -1 = padding; blocks are disjoint and
+        cover every velocity dof.  For an inflated system the block holds all
+        `block_size` copies of each face dof."""
+        dim, n = self.dim, self.n
+        cells = -np.ones((dim,) + (n,) * dim, dtype=np.int64)
+        for c, g in enumerate(self.component_ids):
+            ax = _axis_of_component(dim, c)
+            sl = [slice(None)] * dim
+            sl[ax] = slice(0, n - 1)
+            cells[(c,) + tuple(sl)] = g
+        idx = cells.reshape(dim, -1)
+        keep = (idx >= 0).any(axis=0)
+        idx = idx[:, keep]
+        if self.block_size > 1:
+            b = self.block_size
+            rep = np.where(idx[:, None, :] >= 0, idx[:, None, :] * b + np.arange(b)[None, :, None], -1)
+            idx = rep.reshape(dim * b, -1)
+        return np.ascontiguousarray(idx, dtype=np.int32)
+
+    def line_blocks(self, bs=3):
+        """Blocks of `bs` consecutive dofs of one velocity component along x (the
+        fastest axis): genuinely coupled tridiagonal A_bb, contiguous in memory.
+        Returns int32 (bs * block_size, nblocks), -1 = padding (ragged line ends)."""
+        cols = []
+        for g in self.component_ids:
+            L = g.shape[-1]
+            pad = (-L) % bs
+            gp = np.concatenate([g, -np.ones(g.shape[:-1] + (pad,), dtype=np.int64)], axis=-1)
+            cols.append(gp.reshape(-1, bs).T)
+        idx = np.concatenate(cols, axis=1)
+        if self.block_size > 1:
+            b = self.block_size
+            rep = np.where(idx[:, None, :] >= 0, idx[:, None, :] * b + np.arange(b)[None, :, None], -1)
+            idx = rep.reshape(bs * b, -1)
+        return np.ascontiguousarray(idx, dtype=np.int32)
+
+    def partition(self, nranks):
+        """Slab-aligned row ranges for `nranks` GPUs: (velocity offsets, pressure offsets)."""
+        cuts = np.round(np.arange(nranks + 1) * self.n / nranks).astype(np.int64)
+        return self.velocity_slab_offsets[cuts].copy(), self.pressure_slab_offsets[cuts].copy()
+
+    def inflate(self, bs, seed=1):
+        """'HDG-like' stress variant: Kronecker-inflate A with a seeded SPD bs x bs
+        block (about 7*bs non-zeros per row, cf. the reference's ~84 at order 2 in 3-D)
+        and B with a seeded 1 x bs row."""
+        rng = np.random.default_rng(seed)
+        q = rng.standard_normal((bs, bs))
+        s_blk = np.eye(bs) + 0.25 * (q @ q.T) / bs
+        r_blk = (1.0 + 0.5 * rng.random((1, bs))) / bs
+        A = sp.kron(self.A, sp.csr_matrix(s_blk), format="csr")
+        B = sp.kron(self.B, sp.csr_matrix(r_blk), format="csr")
+        A.sort_indices()
+        B.sort_indices()
+        return StokesSystem(self.dim, self.n, self.nu, self.h, A, B, self.mass.copy(),
+                            self.velocity_slab_offsets * bs, self.pressure_slab_offsets.copy(),
+                            self.component_ids, block_size=self.block_size * bs)
+
+
+def mac_stokes(dim, n, nu=0.01):
+    """Assemble the MAC Stokes system on the unit square (dim=2) / cube (dim=3)."""
+    if n < 2:
+        raise ValueError("need n >= 2")
+    h = 1.0 / n
+    comps, S, n_u = _component_ids(dim, n)
+    n_p = n ** dim
+    ca = nu * h ** (dim - 2)
+    cb = h ** (dim - 1)
+
+    rows, cols, vals = [], [], []
+    for c, g in enumerate(comps):
+        normal_ax = _axis_of_component(dim, c)
+        diag = np.full(g.shape, 2.0 * dim)
+        for ax in range(dim):
+            lo, hi = _shift_slices(dim, ax)
+            rows += [g[lo].ravel(), g[hi].ravel()]
+            cols += [g[hi].ravel(), g[lo].ravel()]
+            off = np.full(g[lo].size, -ca)
+            vals += [off, off]
+            if ax != normal_ax:      # tangential wall: ghost reflection u_ghost = -u
+                first = [slice(None)] * dim
+                last = [slice(None)] * dim
+                first[ax] = 0
+                last[ax] = -1
+                diag[tuple(first)] += 1.0
+                diag[tuple(last)] += 1.0
+        rows.append(g.ravel())
+        cols.append(g.ravel())
+        vals.append(ca * diag.ravel())
+    A = sp.coo_matrix((np.concatenate(vals), (np.concatenate(rows).astype(np.int32),
+                                               np.concatenate(cols).astype(np.int32))),
+                      shape=(n_u, n_u)).tocsr()
+    A.sort_indices()
+
+    pid = np.arange(n_p, dtype=np.int64).reshape((n,) * dim)
+    rows, cols, vals = [], [], []
+    for c, g in enumerate(comps):
+        ax = _axis_of_component(dim, c)
+        lo, hi = _shift_slices(dim, ax)
+        rows += [pid[lo].ravel(), pid[hi].ravel()]          # face m: + for cell m, - for cell m+1
+        cols += [g.ravel(), g.ravel()]
+        vals += [np.full(g.size, cb), np.full(g.size, -cb)]
+    B = sp.coo_matrix((np.concatenate(vals), (np.concatenate(rows).astype(np.int32),
+                                               np.concatenate(cols).astype(np.int32))),
+                      shape=(n_p, n_u)).tocsr()
+    B.sort_indices()
+
+    vel_off = np.concatenate([S, [n_u]]).astype(np.int64)
+    prs_off = (np.arange(n + 1, dtype=np.int64) * n ** (dim - 1))
+    return StokesSystem(dim, n, float(nu), h, A, B, np.full(n_p, h ** dim), vel_off, prs_off, comps)
+
+
+def diffusion_2d(n=64, dt=1e-3):
+    """cfg1 plumbing matrix: 5-point ``M + dt*K`` on an n x n interior grid with
+    homogeneous Dirichlet walls (4 096 rows, 20 224 nnz at n=64;
+    stands in for the heat.py operator, heat.py:58-61)."""
+    h = 1.0 / (n + 1)
+    t = sp.diags([-1.0, 2.0, -1.0], [-1, 0, 1], shape=(n, n))
+    k = (sp.kron(sp.identity(n), t) + sp.kron(t, sp.identity(n))) / (h * h)
+    m = sp.identity(n * n) + dt * k
+    m = m.tocsr()
+    m.sort_indices()
+    return m

@@ -1,0 +1,129 @@
+"""TEST INFRASTRUCTURE -- numpy/scipy checker engine for the hipla protocol.
+
+Only ``tests/``, ``tests/golden/make_golden.py``, ``__graft_entry__.smoke()`` and
+``bench.py``'s ``cpu_baseline`` leg may import this module.  It implements the
+engine interface of ``hipla/engine.py`` with host arithmetic so that (a) the
+reference's *unmodified* solver files can be run over the protocol layer to produce
+golden vectors, (b) the host logic is testable without a GPU and (c) the gloo
+multi-process tests have a CPU compute leg.  The product never selects it.
+"""
+
+import numpy as np
+import scipy.sparse as sp
+
+
+class _Csr:
+    def __init__(self, mat):
+        self.mat = mat
+
+
+class _Bjac:
+    def __init__(self, idx, inv):
+        self.idx = idx      # (bs, nblocks) int32, -1 = padding
+        self.inv = inv      # (nblocks, bs, bs)
+
+
+class NumpyEngine:
+    name = "numpy-oracle"
+
+    # ---- buffers -----------------------------------------------------------
+    def zeros(self, n):
+        return np.zeros(int(n), dtype=np.float64)
+
+    def length(self, buf):
+        return int(buf.shape[0])
+
+    def from_host(self, arr):
+        return np.array(arr, dtype=np.float64, copy=True)
+
+    def upload(self, arr, buf):
+        buf[:] = arr
+
+    def to_host(self, buf):
+        return np.array(buf, copy=True)
+
+    def view(self, buf, a, b):
+        return buf[a:b]
+
+    def same_buffer(self, a, b):
+        return a is b or (a.shape == b.shape and a.__array_interface__["data"][0] == b.__array_interface__["data"][0])
+
+    def overlaps(self, a, b):
+        return np.shares_memory(a, b)
+
+    def synchronize(self):
+        pass
+
+    # ---- BLAS-1 --------------------------------------------------------------
+    def fill(self, buf, c):
+        buf[:] = c
+
+    def copy(self, src, dst):
+        dst[:] = src
+
+    def scal(self, buf, a):
+        buf *= a
+
+    def lincomb(self, dst, terms):
+        s0, b0 = terms[0]
+        acc = b0 * s0 if s0 != 1.0 else b0.copy()
+        for s, b in terms[1:]:
+            acc += s * b
+        dst[:] = acc
+
+    def dot(self, x, y):
+        return float(np.dot(x, y))
+
+    def dot_multi(self, pairs):
+        total = 0.0
+        for x, y in pairs:
+            total += float(np.dot(x, y))
+        return total
+
+    # ---- operators -------------------------------------------------------------
+    def csr_create(self, m, n, rowptr, col, val):
+        return _Csr(sp.csr_matrix((val, col, rowptr), shape=(m, n)))
+
+    def csr_spmv(self, h, alpha, x, beta, y):
+        ax = h.mat @ x
+        if beta == 0.0:
+            y[:] = alpha * ax if alpha != 1.0 else ax
+        else:
+            if beta != 1.0:
+                y *= beta
+            y += alpha * ax if alpha != 1.0 else ax
+
+    def diag_apply(self, d, alpha, x, beta, y):
+        dx = d * x
+        if beta == 0.0:
+            y[:] = alpha * dx
+        else:
+            if beta != 1.0:
+                y *= beta
+            y += alpha * dx
+
+    def bjac_create(self, csr_handle, idx):
+        bs, nb = idx.shape
+        a = csr_handle.mat.tocsr()
+        a.sort_indices()
+        blocks = np.zeros((nb, bs, bs))
+        safe = np.where(idx >= 0, idx, 0)
+        for r in range(bs):
+            for c in range(bs):
+                both = (idx[r] >= 0) & (idx[c] >= 0)
+                vals = np.asarray(a[safe[r], safe[c]]).ravel()
+                blocks[:, r, c] = np.where(both, vals, 1.0 if r == c else 0.0)
+        inv = np.linalg.inv(blocks)
+        return _Bjac(idx.copy(), inv)
+
+    def bjac_apply(self, h, alpha, x, beta, y):
+        idx, inv = h.idx, h.inv
+        safe = np.where(idx >= 0, idx, 0)
+        xb = np.where(idx >= 0, x[safe], 0.0)          # (bs, nb)
+        yb = np.einsum("krc,ck->rk", inv, xb)          # (bs, nb)
+        if beta == 0.0:
+            y[:] = 0.0
+        elif beta != 1.0:
+            y *= beta
+        live = idx >= 0
+        y[idx[live]] += alpha * yb[live]

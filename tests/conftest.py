@@ -1,0 +1,41 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "navier-stokes-solver_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture
+def numpy_engine():
+    """CPU checker engine from oracle/ installed into the protocol layer for the
+    duration of one test (host-logic tests only; the product never does this)."""
+    import hipla
+    from oracle.numpy_engine import NumpyEngine
+    prev = hipla.set_engine(NumpyEngine())
+    yield hipla.get_engine()
+    hipla.set_engine(prev)
+
+
+@pytest.fixture
+def hip_engine():
+    """The product engine (ctypes -> libnsskrylov.so -> gfx950 kernels)."""
+    import hipla
+    prev = hipla.set_engine(None)
+    eng = hipla.get_engine()
+    yield eng
+    hipla.set_engine(prev)
+
+
+def golden_path(name):
+    return os.path.join(GOLDEN, name + ".npz")

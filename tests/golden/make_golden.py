@@ -1,0 +1,301 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ (run in the BUILD CONTAINER only).
+
+How: the reference's *unmodified* solver files are loaded from /root/reference
+(minres.py, bramble_pasciak_cg.py, solvers/bramblepasciak_new.py,
+orthonormalization.py) with ``ngsolve`` resolved to tests/ngsolve_standin (the
+product's protocol layer ``hipla`` + the numpy checker engine of oracle/).  NGSolve
+itself is not installable here, so these goldens pin the
+reference's control flow, operation order, recurrences, stopping rules and return
+values over numpy/scipy arithmetic; against real NGSolve output parity is unpinned.
+
+Nothing of the reference is written to the repo: only inputs (generator parameters,
+seed) and outputs (k, histories, iteration counts, norms, solution samples).
+
+    python tests/golden/make_golden.py          # rewrites tests/golden/*.npz
+"""
+
+import contextlib
+import importlib.util
+import io
+import os
+import re
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "navier-stokes-solver_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests", "ngsolve_standin"))
+
+import hipla                                   # noqa: E402
+from oracle.numpy_engine import NumpyEngine    # noqa: E402
+from oracle import krylov_ref as kr            # noqa: E402
+from staggered_grid import mac_stokes, diffusion_2d   # noqa: E402
+
+
+def load_reference(name, rel):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, rel))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+class Form:
+    """BilinearForm-like operand (solvers/bramblepasciak_new.py:105-109)."""
+
+    def __init__(self, mat):
+        self.mat = mat
+        self.condense = False
+
+
+def build_case(dim, n, nu, pre):
+    sysm = mac_stokes(dim, n, nu)
+    A = hipla.SparseMatrix.from_scipy(sysm.A)
+    B = hipla.SparseMatrix.from_scipy(sysm.B)
+    if pre == "jacobi":
+        preA = hipla.JacobiPreconditioner(A)
+    elif pre == "bjac":
+        preA = hipla.BlockJacobi(A, sysm.line_blocks(3))
+    else:
+        raise ValueError(pre)
+    preS = hipla.DiagonalMatrix(1.0 / sysm.mass)
+    return sysm, A, B, preA, preS
+
+
+def oracle_pre(sysm, pre):
+    pa = kr.jacobi(sysm.A) if pre == "jacobi" else kr.block_jacobi(sysm.A, sysm.line_blocks(3))
+    return pa, kr.diag_inverse(sysm.mass)
+
+
+def stable_window(h1, h2, rtol=1e-10):
+    m = min(len(h1), len(h2))
+    rel = np.abs(h1[:m] - h2[:m]) / np.maximum(np.abs(h1[:m]), 1e-300)
+    bad = np.nonzero(rel > rtol)[0]
+    return int(bad[0]) if bad.size else m
+
+
+class _ReversedDot:
+    """Perturb only the summation order of every inner product."""
+
+    def __enter__(self):
+        self._dot = np.dot
+        real = np.dot
+        np.dot = lambda a, b: real(a[::-1], b[::-1])
+        return self
+
+    def __exit__(self, *exc):
+        np.dot = self._dot
+        return False
+
+
+def samples(x, count=16):
+    idx = np.linspace(0, x.size - 1, count).astype(np.int64)
+    return idx, x[idx]
+
+
+def main():
+    hipla.set_engine(NumpyEngine())
+    ref_minres = load_reference("ref_minres", "minres.py")
+    ref_v1 = load_reference("ref_bpcg_v1", "bramble_pasciak_cg.py")
+    ref_v2 = load_reference("ref_bpcg_v2", "solvers/bramblepasciak_new.py")
+    ref_orth = load_reference("ref_orth", "orthonormalization.py")
+
+    captured = {}
+
+    def spy(orig):
+        def wrapper(*a, **kw):
+            lams = orig(*a, **kw)
+            captured["lams"] = np.array(lams)
+            return lams
+        return wrapper
+
+    ref_v1.EigenValues_Preconditioner = spy(ref_v1.EigenValues_Preconditioner)
+    ref_v2.EigenValues_Preconditioner = spy(ref_v2.EigenValues_Preconditioner)
+
+    cases = [(2, 12, "jacobi"), (2, 24, "jacobi"), (2, 24, "bjac"), (2, 48, "bjac"),
+             (3, 6, "jacobi"), (3, 10, "bjac")]
+    nu, seed = 0.01, 0
+    written = []
+
+    def save(name, **kw):
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **kw)
+        written.append((name, os.path.getsize(path)))
+
+    for dim, n, pre in cases:
+        sysm, A, B, preA, preS = build_case(dim, n, nu, pre)
+        f, g = sysm.rhs(seed)
+        Ks = sysm.saddle_matrix()
+        b = np.concatenate([f, g])
+        tag = "stokes%dd_n%d_%s" % (dim, n, pre)
+        common = dict(dim=dim, n=n, nu=nu, seed=seed, pre=pre, n_u=sysm.n_u, n_p=sysm.n_p)
+        pa, ps = oracle_pre(sysm, pre)
+
+        # ---- BPCG v1 (bramble_pasciak_cg.py:65) ----------------------------
+        tol1, max1 = 1e-10, 5000
+        out = io.StringIO()
+        with contextlib.redirect_stdout(out):
+            sol, errors = ref_v1.bramble_pasciak_cg(A, B, None, preA, preS,
+                                                   hipla.Vector.from_numpy(f), hipla.Vector.from_numpy(g),
+                                                   tolerance=tol1, max_steps=max1, print_rates=False)
+        lams = captured["lams"]
+        k = 1.0 / lams.min() + 1e-3
+        x = sol.numpy()
+        errors = np.array(errors)
+        o1 = kr.bpcg_v1(sysm.A, sysm.B, pa, ps, f, g, k, tolerance=tol1, max_steps=max1)
+        with _ReversedDot():
+            o2 = kr.bpcg_v1(sysm.A, sysm.B, pa, ps, f, g, k, tolerance=tol1, max_steps=max1)
+        W = stable_window(o1[2], o2[2])
+        si, sv = samples(x)
+        save(tag + "_bpcg1", solver="bpcg1", tol=tol1, maxsteps=max1, k=k, lam_min=lams.min(), lam_max=lams.max(),
+             errors=errors, iterations=len(errors) - 1, window=W, x_norm=np.linalg.norm(x),
+             residual=np.linalg.norm(b - Ks @ x), b_norm=np.linalg.norm(b), sample_idx=si, sample_val=sv,
+             warned="Warning" in out.getvalue(), **common)
+
+        # ---- BPCG v2 (solvers/bramblepasciak_new.py:24) ----------------------
+        tol2, max2 = 1e-10, 5000
+        solv = hipla.BlockVector([hipla.Vector(sysm.n_u), hipla.Vector(sysm.n_p)])
+        out = io.StringIO()
+        with contextlib.redirect_stdout(out):
+            ret = ref_v2.BramblePasciakCG(Form(A), Form(B), None, hipla.Vector.from_numpy(f),
+                                          hipla.Vector.from_numpy(g), preA, preS, solv,
+                                          tol=tol2, maxsteps=max2, printrates=True)
+        it, _t = ret
+        text = out.getvalue()
+        hist = np.array([float(m) for m in re.findall(r"it =\s+\d+\s+err =\s+(\S+)", text)])
+        err0 = float(re.search(r"err0 (\S+)", text).group(1))
+        lams = captured["lams"]
+        k2 = 1.0 / lams.min() + 1e-3
+        x = solv.numpy()
+        p1 = kr.bpcg_v2(sysm.A, sysm.B, pa, ps, f, g, k2, tol=tol2, maxsteps=max2)
+        with _ReversedDot():
+            p2 = kr.bpcg_v2(sysm.A, sysm.B, pa, ps, f, g, k2, tol=tol2, maxsteps=max2)
+        W = stable_window(p1[3], p2[3])
+        si, sv = samples(x)
+        save(tag + "_bpcg2", solver="bpcg2", tol=tol2, maxsteps=max2, k=k2, lam_min=lams.min(), lam_max=lams.max(),
+             history=hist, err0=err0, iterations=it, window=W, x_norm=np.linalg.norm(x),
+             residual=np.linalg.norm(b - Ks @ x), b_norm=np.linalg.norm(b), sample_idx=si, sample_val=sv,
+             warned="Warning" in text, **common)
+
+        # ---- MINRES (minres.py:12; operands as run.py:45-46) -------------------
+        tol3, max3 = 1e-10, 5000
+        K = hipla.BlockMatrix([[A, B.T], [B, None]])
+        C = hipla.BlockMatrix([[preA, None], [None, preS]])
+        rhs = hipla.BlockVector([hipla.Vector.from_numpy(f), hipla.Vector.from_numpy(g)])
+        out = io.StringIO()
+        with contextlib.redirect_stdout(out):
+            u, errs = ref_minres.MinRes(mat=K, pre=C, rhs=rhs, maxsteps=max3, tol=tol3, printrates=False)
+        x = u.numpy()
+        errs = np.array(errs)
+        q1 = kr.minres(sysm.A, sysm.B, pa, ps, f, g, maxsteps=max3, tol=tol3)
+        with _ReversedDot():
+            q2 = kr.minres(sysm.A, sysm.B, pa, ps, f, g, maxsteps=max3, tol=tol3)
+        W = stable_window(q1[2], q2[2])
+        si, sv = samples(x)
+        save(tag + "_minres", solver="minres", tol=tol3, maxsteps=max3, errors=errs, iterations=len(errs) - 1,
+             window=W, x_norm=np.linalg.norm(x), residual=np.linalg.norm(b - Ks @ x), b_norm=np.linalg.norm(b),
+             sample_idx=si, sample_val=sv, warned="Warning" in out.getvalue(), **common)
+
+    # ---- quirk cases (SURVEY.md 8c "Goldens to capture") ------------------------
+    dim, n, pre = 2, 12, "jacobi"
+    sysm, A, B, preA, preS = build_case(dim, n, nu, pre)
+    f, g = sysm.rhs(seed)
+    Ks = sysm.saddle_matrix()
+    common = dict(dim=dim, n=n, nu=nu, seed=seed, pre=pre, n_u=sysm.n_u, n_p=sysm.n_p)
+    rng = np.random.default_rng(7)
+    warm_u, warm_p = 0.1 * rng.standard_normal(sysm.n_u), 0.1 * rng.standard_normal(sysm.n_p)
+
+    # MINRES leaves through the absolute guard `ResNorm > tol` (:96) -> warning (:145-146)
+    fs = 1e-3 * f
+    rhs = hipla.BlockVector([hipla.Vector.from_numpy(fs), hipla.Vector.from_numpy(g)])
+    K = hipla.BlockMatrix([[A, B.T], [B, None]])
+    C = hipla.BlockMatrix([[preA, None], [None, preS]])
+    out = io.StringIO()
+    with contextlib.redirect_stdout(out):
+        u, errs = ref_minres.MinRes(mat=K, pre=C, rhs=rhs, maxsteps=2000, tol=1e-6, printrates=False)
+    save("quirk_minres_absolute_guard", solver="minres", rhs_scale=1e-3, tol=1e-6, maxsteps=2000,
+         errors=np.array(errs), iterations=len(errs) - 1, warned="Warning" in out.getvalue(),
+         x_norm=np.linalg.norm(u.numpy()), **common)
+
+    # MINRES warm start, initialize=False (:65-66)
+    sol = hipla.BlockVector([hipla.Vector.from_numpy(warm_u), hipla.Vector.from_numpy(warm_p)])
+    rhs = hipla.BlockVector([hipla.Vector.from_numpy(f), hipla.Vector.from_numpy(g)])
+    with contextlib.redirect_stdout(io.StringIO()):
+        u, errs = ref_minres.MinRes(mat=K, pre=C, rhs=rhs, sol=sol, initialize=False, maxsteps=2000,
+                                    tol=1e-8, printrates=False)
+    x = u.numpy()
+    save("quirk_minres_warm_start", solver="minres", tol=1e-8, maxsteps=2000, warm_seed=7, errors=np.array(errs),
+         iterations=len(errs) - 1, x_norm=np.linalg.norm(x), aliased=bool(u is sol),
+         residual=np.linalg.norm(np.concatenate([f, g]) - Ks @ x), **common)
+
+    # v2: zero right-hand side -> wdn == 0 -> returns the bare vector (:191-192)
+    solv = hipla.BlockVector([hipla.Vector(sysm.n_u), hipla.Vector(sysm.n_p)])
+    with contextlib.redirect_stdout(io.StringIO()):
+        ret = ref_v2.BramblePasciakCG(Form(A), Form(B), None, hipla.Vector(sysm.n_u), hipla.Vector(sysm.n_p),
+                                      preA, preS, solv, tol=1e-10, maxsteps=100)
+    save("quirk_bpcg2_zero_rhs", solver="bpcg2", returned_solution_object=bool(ret is solv),
+         x_norm=np.linalg.norm(solv.numpy()), **common)
+
+    # v2 warm start (initialize=False) and rel_err=False (absolute stop, :246)
+    for name, kw in [("quirk_bpcg2_warm_start", dict(initialize=False, rel_err=True)),
+                     ("quirk_bpcg2_abs_err", dict(initialize=True, rel_err=False))]:
+        solv = hipla.BlockVector([hipla.Vector.from_numpy(warm_u), hipla.Vector.from_numpy(warm_p)])
+        out = io.StringIO()
+        with contextlib.redirect_stdout(out):
+            it, _t = ref_v2.BramblePasciakCG(Form(A), Form(B), None, hipla.Vector.from_numpy(f),
+                                             hipla.Vector.from_numpy(g), preA, preS, solv, tol=1e-6,
+                                             maxsteps=2000, printrates=True, **kw)
+        text = out.getvalue()
+        hist = np.array([float(m) for m in re.findall(r"it =\s+\d+\s+err =\s+(\S+)", text)])
+        lams = captured["lams"]
+        x = solv.numpy()
+        save(name, solver="bpcg2", tol=1e-6, maxsteps=2000, warm_seed=7, k=1.0 / lams.min() + 1e-3,
+             history=hist, err0=float(re.search(r"err0 (\S+)", text).group(1)), iterations=it,
+             x_norm=np.linalg.norm(x), residual=np.linalg.norm(np.concatenate([f, g]) - Ks @ x),
+             initialize=kw["initialize"], rel_err=kw["rel_err"], **common)
+
+    # v1 warm start: `solution` given (:88-90), hits max_steps -> warning (:144-145)
+    sol = hipla.BlockVector([hipla.Vector.from_numpy(warm_u), hipla.Vector.from_numpy(warm_p)])
+    out = io.StringIO()
+    with contextlib.redirect_stdout(out):
+        s2, errors = ref_v1.bramble_pasciak_cg(A, B, None, preA, preS, hipla.Vector.from_numpy(f),
+                                               hipla.Vector.from_numpy(g), solution=sol, tolerance=1e-12,
+                                               max_steps=40, print_rates=False)
+    lams = captured["lams"]
+    save("quirk_bpcg1_warm_start_maxsteps", solver="bpcg1", tol=1e-12, maxsteps=40, warm_seed=7,
+         k=1.0 / lams.min() + 1e-3, errors=np.array(errors), iterations=len(errors), aliased=bool(s2 is sol),
+         warned="Warning" in out.getvalue(), x_norm=np.linalg.norm(s2.numpy()), **common)
+
+    # ---- cfg1 plumbing: SpMV + InnerProduct + AXPY via orthonormalization.py ----------
+    M = diffusion_2d(64)
+    Mh = hipla.SparseMatrix.from_scipy(M)
+    rng = np.random.default_rng(3)
+    x0 = rng.standard_normal(M.shape[0])
+    basis = [hipla.Vector.from_numpy(x0)]
+    for _ in range(4):
+        nxt = basis[-1].CreateVector()
+        nxt.data = Mh * basis[-1]
+        basis.append(nxt)
+    basis = ref_orth.orthonormalize(basis)
+    galerkin = np.zeros((5, 5))
+    res = basis[0].CreateVector()
+    for c in range(5):
+        res.data = Mh * basis[c]                        # heat.py:110
+        for r in range(5):
+            galerkin[r, c] = hipla.InnerProduct(basis[r], res)   # heat.py:112
+    gram = np.array([[hipla.InnerProduct(a, b_) for b_ in basis] for a in basis])
+    xs, hist = kr.cg(M, x0, tol=1e-10, maxsteps=500)
+    save("cfg1_heat_plumbing", n=64, seed=3, galerkin=galerkin, gram=gram, rows=M.shape[0], nnz=M.nnz,
+         cg_history=hist, cg_iterations=len(hist) - 1, cg_x_norm=np.linalg.norm(xs),
+         cg_residual=np.linalg.norm(x0 - M @ xs))
+
+    for name, size in written:
+        print("%-40s %6d B" % (name, size))
+
+
+if __name__ == "__main__":
+    main()

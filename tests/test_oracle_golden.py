@@ -1,0 +1,154 @@
+"""The CPU oracle (oracle/krylov_ref.py) against the golden vectors produced by the
+reference's own unmodified solver files (tests/golden/make_golden.py).
+
+Tolerance contract: (i) history relative difference <= 1e-8
+over the recorded stable window W; (ii) iteration count within +-max(2, 1 %);
+(iii) solution norm / true residual agree; quirk cases reproduce flags exactly."""
+
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, golden_path
+from oracle import krylov_ref as kr
+from staggered_grid import diffusion_2d, mac_stokes
+
+CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "stokes*.npz")))
+
+
+def _system(d):
+    sysm = mac_stokes(int(d["dim"]), int(d["n"]), float(d["nu"]))
+    f, g = sysm.rhs(int(d["seed"]))
+    pre = str(d["pre"])
+    pa = kr.jacobi(sysm.A) if pre == "jacobi" else kr.block_jacobi(sysm.A, sysm.line_blocks(3))
+    return sysm, f, g, pa, kr.diag_inverse(sysm.mass)
+
+
+def _close_history(h, ref, window, rtol=1e-8):
+    w = min(int(window), len(h), len(ref))
+    assert w > 10
+    rel = np.abs(h[:w] - ref[:w]) / np.abs(ref[:w])
+    assert rel.max() <= rtol, "history differs inside the stable window: %g" % rel.max()
+
+
+def _close_iterations(it, ref):
+    assert abs(int(it) - int(ref)) <= max(2, int(0.01 * int(ref)))
+
+
+def test_goldens_present():
+    assert len(CASES) == 18
+    for q in ("quirk_minres_absolute_guard", "quirk_minres_warm_start", "quirk_bpcg2_zero_rhs",
+              "quirk_bpcg2_warm_start", "quirk_bpcg2_abs_err", "quirk_bpcg1_warm_start_maxsteps",
+              "cfg1_heat_plumbing"):
+        assert os.path.exists(golden_path(q))
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_oracle_matches_reference_run(case):
+    d = np.load(golden_path(case))
+    sysm, f, g, pa, ps = _system(d)
+    Ks = sysm.saddle_matrix()
+    b = np.concatenate([f, g])
+    solver = str(d["solver"])
+    if solver == "bpcg1":
+        u, p, errors, conv = kr.bpcg_v1(sysm.A, sysm.B, pa, ps, f, g, float(d["k"]),
+                                        tolerance=float(d["tol"]), max_steps=int(d["maxsteps"]))
+        _close_history(errors, d["errors"], d["window"])
+        _close_iterations(len(errors) - 1, d["iterations"])
+        assert conv == (not bool(d["warned"]))
+    elif solver == "bpcg2":
+        it, u, p, hist, err0 = kr.bpcg_v2(sysm.A, sysm.B, pa, ps, f, g, float(d["k"]),
+                                          tol=float(d["tol"]), maxsteps=int(d["maxsteps"]))
+        assert abs(err0 - float(d["err0"])) <= 1e-10 * float(d["err0"])
+        _close_history(hist, d["history"], d["window"])
+        _close_iterations(it, d["iterations"])
+    else:
+        u, p, errors, warned = kr.minres(sysm.A, sysm.B, pa, ps, f, g,
+                                         maxsteps=int(d["maxsteps"]), tol=float(d["tol"]))
+        _close_history(errors, d["errors"], d["window"])
+        _close_iterations(len(errors) - 1, d["iterations"])
+        assert warned == bool(d["warned"])
+    x = np.concatenate([u, p])
+    assert abs(np.linalg.norm(x) - float(d["x_norm"])) <= 1e-6 * float(d["x_norm"])
+    res = np.linalg.norm(b - Ks @ x)
+    assert res <= 10 * max(float(d["residual"]), 1e-12 * float(d["b_norm"]))
+    np.testing.assert_allclose(x[d["sample_idx"]], d["sample_val"], rtol=0, atol=1e-6 * np.abs(x).max())
+
+
+def test_oracle_lanczos_scale_factor_matches_golden():
+    """k recorded in the goldens came from hipla/eigen.py; oracle/krylov_ref.lanczos_ritz is an
+    independent statement of the same recurrence (NGSolve's own is upstream: parity unpinned)."""
+    for case, tol in [("stokes2d_n12_jacobi_bpcg1", 1e-10), ("stokes2d_n12_jacobi_bpcg2", 1e-3),
+                      ("stokes3d_n10_bjac_bpcg2", 1e-3), ("stokes2d_n24_bjac_bpcg1", 1e-10)]:
+        d = np.load(golden_path(case))
+        sysm, f, g, pa, ps = _system(d)
+        ritz = kr.lanczos_ritz(sysm.A, pa, tol=tol)
+        assert abs(kr.scale_factor(ritz) - float(d["k"])) <= 1e-9 * float(d["k"])
+        assert abs(ritz.min() - float(d["lam_min"])) <= 1e-9 * float(d["lam_min"])
+    # Ritz values bracket the true spectrum of pre*A from inside
+    sysm = mac_stokes(2, 12)
+    dinv = 1.0 / sysm.A.diagonal()
+    true = np.linalg.eigvalsh((np.sqrt(dinv)[:, None] * sysm.A.toarray()) * np.sqrt(dinv)[None, :])
+    ritz = kr.lanczos_ritz(sysm.A, kr.jacobi(sysm.A), tol=1e-10)
+    assert ritz.min() >= true.min() * (1 - 1e-9) and ritz.max() <= true.max() * (1 + 1e-9)
+    assert abs(ritz.min() - true.min()) <= 1e-6 * true.min()
+
+
+def test_quirk_minres_absolute_guard():
+    d = np.load(golden_path("quirk_minres_absolute_guard"))
+    sysm, f, g, pa, ps = _system(d)
+    u, p, errors, warned = kr.minres(sysm.A, sysm.B, pa, ps, float(d["rhs_scale"]) * f, g,
+                                     maxsteps=int(d["maxsteps"]), tol=float(d["tol"]))
+    assert bool(d["warned"]) and warned          # converged absolutely, still warns (minres.py:96,145-146)
+    _close_iterations(len(errors) - 1, d["iterations"])
+    assert errors[-1] > float(d["tol"])          # relative criterion was NOT met
+
+
+def test_quirk_warm_starts_and_abs_err():
+    rng = np.random.default_rng(7)
+    d = np.load(golden_path("quirk_minres_warm_start"))
+    sysm, f, g, pa, ps = _system(d)
+    x0 = (0.1 * rng.standard_normal(sysm.n_u), 0.1 * rng.standard_normal(sysm.n_p))
+    u, p, errors, warned = kr.minres(sysm.A, sysm.B, pa, ps, f, g, x0=x0, maxsteps=int(d["maxsteps"]), tol=float(d["tol"]))
+    _close_iterations(len(errors) - 1, d["iterations"])
+    np.testing.assert_allclose(errors[:60], d["errors"][:60], rtol=1e-8)
+    assert bool(d["aliased"])
+
+    for name in ("quirk_bpcg2_warm_start", "quirk_bpcg2_abs_err"):
+        d = np.load(golden_path(name))
+        start = x0 if not bool(d["initialize"]) else None
+        it, u, p, hist, err0 = kr.bpcg_v2(sysm.A, sysm.B, pa, ps, f, g, float(d["k"]), x0=start,
+                                          tol=float(d["tol"]), maxsteps=int(d["maxsteps"]), rel_err=bool(d["rel_err"]))
+        _close_iterations(it, d["iterations"])
+        np.testing.assert_allclose(hist[:40], d["history"][:40], rtol=1e-8)
+        assert abs(err0 - float(d["err0"])) <= 1e-10 * err0
+
+    d = np.load(golden_path("quirk_bpcg1_warm_start_maxsteps"))
+    u, p, errors, conv = kr.bpcg_v1(sysm.A, sysm.B, pa, ps, f, g, float(d["k"]), x0=x0,
+                                    tolerance=float(d["tol"]), max_steps=int(d["maxsteps"]))
+    assert not conv and bool(d["warned"])
+    assert len(errors) == int(d["iterations"]) == int(d["maxsteps"])
+    np.testing.assert_allclose(errors, d["errors"], rtol=1e-8)
+
+
+def test_quirk_bpcg2_zero_rhs():
+    d = np.load(golden_path("quirk_bpcg2_zero_rhs"))
+    sysm, f, g, pa, ps = _system(d)
+    it, u, p, hist, err0 = kr.bpcg_v2(sysm.A, sysm.B, pa, ps, 0 * f, g, 10.0)
+    assert it == -1 and err0 == 0.0 and len(hist) == 0
+    assert bool(d["returned_solution_object"]) and float(d["x_norm"]) == 0.0
+
+
+def test_cfg1_heat_plumbing():
+    d = np.load(golden_path("cfg1_heat_plumbing"))
+    M = diffusion_2d(int(d["n"]))
+    assert M.shape[0] == int(d["rows"]) == 4096 and M.nnz == int(d["nnz"]) == 20224
+    np.testing.assert_allclose(d["gram"], np.eye(5), atol=1e-12)
+    x0 = np.random.default_rng(int(d["seed"])).standard_normal(M.shape[0])
+    x, hist = kr.cg(M, x0, tol=1e-10, maxsteps=500)
+    assert len(hist) - 1 == int(d["cg_iterations"])
+    np.testing.assert_allclose(hist, d["cg_history"], rtol=1e-9)
+    import scipy.sparse.linalg as spl
+    np.testing.assert_allclose(x, spl.spsolve(M.tocsc(), x0), rtol=0, atol=1e-9)
