@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Krylov iterations / second of the Bramble-Pasciak CG (v2) hot loop on
+the 3-D SIMPLE Stokes system (BASELINE.json configs[3]: MAC grid n=136, ~1e7 DoF, fp64),
+plus the HBM roofline of its dominant kernel and the CPU oracle timed beside it.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+A "step" is one BPCG iteration (reference loop body: solvers/bramblepasciak_new.py:200-249):
+3 CSR SpMVs (B^T, A, B), the block-Jacobi preconditioner apply, the lumped-mass apply, two
+global inner products and the fused vector updates.  Inputs are resident in HBM before the
+timed region.  For N > 1 (launched by torch.distributed.run, one rank per GPU) the same
+global system is row-partitioned into slabs: strong scaling, value = iterations/s of the
+whole job.  Rank 0 prints ONE JSON line.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "navier-stokes-solver_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--n", type=int, default=136, help="MAC grid cells per direction (136 -> 1.0e7 DoF)")
+    ap.add_argument("--dim", type=int, default=3)
+    ap.add_argument("--nu", type=float, default=0.01, help="1/Re")
+    ap.add_argument("--pre", default="bjac3", choices=["bjac3", "jacobi"])
+    ap.add_argument("--cpu-iters", type=int, default=-1, help="oracle iterations to time (-1: auto, 0: skip)")
+    ap.add_argument("--kernel-reps", type=int, default=30)
+    return ap.parse_args()
+
+
+class Form:
+    def __init__(self, mat):
+        self.mat, self.condense = mat, False
+
+
+def event_time_ms(torch, fn, reps):
+    """Average duration of `fn` (one kernel launch on the current stream) from HIP events."""
+    start = torch.cuda.Event(enable_timing=True)
+    stop = torch.cuda.Event(enable_timing=True)
+    fn()
+    torch.cuda.synchronize()
+    start.record()
+    for _ in range(reps):
+        fn()
+    stop.record()
+    stop.synchronize()
+    return start.elapsed_time(stop) / reps
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if args.gpus != world and rank == 0:
+        print("note: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+
+    import hipla
+    from solvers.bramblepasciak_new import BpcgSession
+    from staggered_grid import mac_stokes
+
+    eng = hipla.get_engine()
+    info = eng.device_info()
+    K, W = args.steps, args.warmup
+    total_its = W + K
+
+    t_asm = time.perf_counter()
+    sysm = mac_stokes(args.dim, args.n, args.nu)
+    f, g = sysm.rhs(0)
+    blocks = sysm.line_blocks(3) if args.pre == "bjac3" else None
+    t_asm = time.perf_counter() - t_asm
+
+    if world > 1:
+        from distributed import DistributedBpcg2
+        run = DistributedBpcg2(sysm, f, g, blocks, dist, eng)
+        run.start(tol=0.0, maxsteps=total_its)
+        run.iterate(0, W)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run.iterate(W, total_its)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        done, _, last = run.poll()
+        hist = run.history(total_its - 1)
+        ok = (not done) and last == total_its - 1 and bool(np.all(np.isfinite(hist)))
+        if rank == 0:
+            out = {
+                "metric": "Krylov iters/sec, 3D SIMPLE Stokes solve (BPCG)", "value": K / elapsed, "unit": "iters/s",
+                "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": 1e3 * elapsed / K,
+                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+                "data": "synthetic",
+                "config": {"workload": "templates/NavierStokesSIMPLE_test_3D.py restated: 3-D MAC Stokes n=%d, "
+                                       "%d DoF, BPCG v2, %s preA, row-partitioned over %d GPUs"
+                                       % (args.n, sysm.ndof, args.pre, world),
+                           "n_u": sysm.n_u, "n_p": sysm.n_p, "nnz_A": int(sysm.A.nnz), "nnz_B": int(sysm.B.nnz)},
+                "valid": ok, "halo_doubles_per_rank": run.halo_summary(),
+            }
+            print(json.dumps(out))
+        dist.destroy_process_group()
+        return
+
+    # ------------------------------- single GPU --------------------------------------------
+    A = hipla.SparseMatrix.from_scipy(sysm.A)
+    B = hipla.SparseMatrix.from_scipy(sysm.B)
+    preA = hipla.BlockJacobi(A, blocks) if blocks is not None else hipla.JacobiPreconditioner(A)
+    preM = hipla.DiagonalMatrix(1.0 / sysm.mass)
+    sol = hipla.BlockVector([hipla.Vector(sysm.n_u), hipla.Vector(sysm.n_p)])
+    t_setup = time.perf_counter()
+    ses = BpcgSession(Form(A), Form(B), None, hipla.Vector.from_numpy(f), hipla.Vector.from_numpy(g),
+                      preA, preM, sol=sol, initialize=True)
+    loop = ses.fused
+    if loop is None:
+        raise RuntimeError("fused BPCG loop unavailable for native operands")
+    ses.first_direction()
+    loop.start(ses.wdn, ses.err0, 0.0, True, total_its)      # tol = 0: never stops inside the run
+    torch.cuda.synchronize()
+    t_setup = time.perf_counter() - t_setup
+
+    loop.enqueue(0, W)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    loop.enqueue(W, total_its)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    done, _, last = loop.poll()
+    hist = loop.history(total_its - 1)
+    valid = (not done) and last == total_its - 1 and bool(np.all(np.isfinite(hist)))
+
+    # ---- roofline of the dominant kernel: fused A-SpMV (K2) ---------------------------------
+    a_info, b_info, bt_info = A.handle.info(), B.handle.info(), A.handle.info()
+    bt_info = ses.matBT.handle.info()
+    k2_bytes = a_info["algorithmic_bytes"] + 24 * sysm.n_u      # + read t0, s0; write t4 (fused epilogue)
+    reps = args.kernel_reps
+    it_probe = total_its - 1
+    k2_ms = event_time_ms(torch, lambda: loop.phase("K2", it_probe), reps)
+    k1_ms = event_time_ms(torch, lambda: loop.phase("K1", it_probe), reps)
+    k3_ms = event_time_ms(torch, lambda: loop.phase("K3", it_probe), reps)
+    k4_ms = event_time_ms(torch, lambda: loop.phase("K4", it_probe), reps)
+    xs, ys = eng.zeros(sysm.n_u), eng.zeros(sysm.n_u)
+    xs.fill_(1.0)
+    spmv_ms = event_time_ms(torch, lambda: eng.csr_spmv(A.handle, 1.0, xs, 0.0, ys), reps)
+    ntri = 1 << 26
+    ta, tb, tc = eng.zeros(ntri), eng.zeros(ntri), eng.zeros(ntri)
+    triad_ms = event_time_ms(torch, lambda: eng.stream_triad(0.5, ta, tb, tc), reps)
+    triad_gbs = 24.0 * ntri / (triad_ms * 1e-3) / 1e9
+    del ta, tb, tc
+    k2_gbs = k2_bytes / (k2_ms * 1e-3) / 1e9
+    spmv_gbs = a_info["algorithmic_bytes"] / (spmv_ms * 1e-3) / 1e9
+
+    # per-iteration algorithmic bytes (DESIGN.md section "bytes per iteration")
+    n_u, n_p = sysm.n_u, sysm.n_p
+    mat_bytes = sum(12 * i["nnz"] + 4 * (i["rows"] + 1) for i in (a_info, b_info, bt_info))
+    pre_bytes = preA.handle.algorithmic_bytes() - 16 * n_u if blocks is not None else 8 * n_u
+    vec_bytes = 8 * (26 * n_u + 15 * n_p)
+    iter_bytes = mat_bytes + pre_bytes + vec_bytes
+    iter_gbs = iter_bytes / (elapsed / K) / 1e9
+
+    # ---- CPU baseline: the oracle restatement on this box's host cores -------------------------
+    cpu = None
+    parity = None
+    if args.cpu_iters != 0:
+        from oracle import krylov_ref as kr
+        cpu_iters = args.cpu_iters if args.cpu_iters > 0 else max(3, min(40, int(2.0e9 / max(sysm.A.nnz, 1))))
+        pa = kr.block_jacobi(sysm.A, blocks) if blocks is not None else kr.jacobi(sysm.A)
+        timing = {}
+        it_c, _, _, hist_c, err0_c = kr.bpcg_v2(sysm.A, sysm.B, pa, kr.diag_inverse(sysm.mass), f, g, ses.k,
+                                                tol=0.0, maxsteps=cpu_iters, timing=timing)
+        cpu = {"value": cpu_iters / timing["loop_seconds"], "unit": "iters/s", "cores": 1, "kind": "port",
+               "host_cpus": os.cpu_count(),
+               "sample": "%d iterations of oracle/krylov_ref.bpcg_v2 (scipy CSR matvec + numpy, single thread "
+                         "for SpMV) on the identical matrices" % cpu_iters}
+        m = min(len(hist_c), len(hist))
+        parity = {"iterations_compared": m,
+                  "history_max_rel_diff": float(np.max(np.abs(hist[:m] - hist_c[:m]) / np.abs(hist_c[:m]))),
+                  "err0_rel_diff": abs(ses.err0 - err0_c) / err0_c}
+
+    out = {
+        "metric": "Krylov iters/sec, 3D SIMPLE Stokes solve (BPCG)", "value": K / elapsed, "unit": "iters/s",
+        "n_gpus": 1, "steps": K, "warmup": W, "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "templates/NavierStokesSIMPLE_test_3D.py restated: %d-D MAC Stokes n=%d, %d DoF, "
+                               "BPCG v2 (solvers/bramblepasciak_new.py), %s preA, lumped-mass preM, Re=%g"
+                               % (args.dim, args.n, sysm.ndof, args.pre, 1.0 / args.nu),
+                   "n_u": n_u, "n_p": n_p, "nnz_A": a_info["nnz"], "nnz_B": b_info["nnz"],
+                   "scale_factor_k": ses.k, "device": info["arch"], "cu_count": info["cu_count"]},
+        "roofline": {"bound": "hbm", "kernel": "csr_stream_kernel<1, EpiK2> (A SpMV + fused t4 / <s0,v0>)",
+                     "achieved": k2_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k2_gbs / HBM_PEAK_GBS,
+                     "traffic": None, "algorithmic_bytes_per_launch": k2_bytes, "avg_launch_ms": k2_ms,
+                     "frac_of_stream_triad": k2_gbs / triad_gbs},
+        "cpu_baseline": cpu,
+        "valid": valid,
+        "hbm_GBs": {"whole_iteration_algorithmic": iter_gbs, "stream_triad": triad_gbs, "spmv_A_plain": spmv_gbs,
+                    "spmv_A_fused_K2": k2_gbs},
+        "kernel_ms": {"K1_BT": k1_ms, "K2_A": k2_ms, "K3_B": k3_ms, "K4_update": k4_ms, "spmv_A_plain": spmv_ms,
+                      "triad_1.6GB": triad_ms},
+        "bytes_per_iteration": iter_bytes,
+        "parity": parity,
+        "setup_s": {"assemble_host": t_asm, "upload_lanczos_initial_residual": t_setup},
+    }
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,156 @@
+/* nss_krylov.h -- C ABI of libnsskrylov.so: the MI355X (gfx950) engine behind the
+ * Stokes / SIMPLE saddle-point Krylov path of matschiner/navier-stokes-solver.
+ *
+ * The reference has no FFI of its own: its hot path sits behind the Python-level
+ * NGSolve linear-algebra protocol.  Each entry point below
+ * names the reference operation(s) it replaces (file:line under /root/reference).
+ * The host side (navier-stokes-solver_amd/hipla, Python) binds these with ctypes;
+ * INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *  - every function returns int: 0 = ok, non-zero = error; nss_last_error() gives
+ *    the message of the last failure on the calling thread.  No C++ exception
+ *    crosses the boundary.
+ *  - `double*` / `int32_t*` vector arguments are DEVICE pointers owned by the caller
+ *    (the Python host allocates them as torch tensors so torch.distributed / RCCL can
+ *    exchange them); `h_`-prefixed arguments are HOST pointers, copied during the
+ *    call.  Matrix / preconditioner handles are owned by the library (hipMalloc).
+ *  - all arithmetic is fp64, indices int32.
+ *  - calls are asynchronous on `stream` (a hipStream_t passed as void*; NULL = the
+ *    legacy default stream) unless the name ends in `_host` or says otherwise.
+ *  - one process drives one GPU; handles are not thread-safe.
+ */
+#ifndef NSS_KRYLOV_H
+#define NSS_KRYLOV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NSS_API __attribute__((visibility("default")))
+#define NSS_ABI_VERSION 1
+
+typedef void* nss_stream_t;            /* hipStream_t */
+typedef struct nss_csr_s* nss_csr_t;   /* CSR matrix resident in HBM */
+typedef struct nss_bjac_s* nss_bjac_t; /* block-Jacobi inverse blocks resident in HBM */
+
+/* ---- library / device ---------------------------------------------------- */
+NSS_API int nss_abi_version(void);
+NSS_API const char* nss_last_error(void);
+/* name_cap bytes at `name` receive the gcnArchName; any out pointer may be NULL */
+NSS_API int nss_device_info(int32_t* cu_count, int64_t* hbm_bytes, int32_t* wavefront_size,
+                            char* name, int32_t name_cap);
+NSS_API int nss_stream_synchronize(nss_stream_t stream);
+
+/* ---- BLAS-1 (reference: every `x.data = ...`, `x *= s`, `v[:] = c` statement of
+ * minres.py:62-118, bramble_pasciak_cg.py:88-141, solvers/bramblepasciak_new.py:130-241) */
+NSS_API int nss_fill_f64(int64_t n, double value, double* x, nss_stream_t stream);
+NSS_API int nss_copy_f64(int64_t n, const double* x, double* y, nss_stream_t stream);
+NSS_API int nss_scal_f64(int64_t n, double a, double* x, nss_stream_t stream);
+/* y = sum_{i<nterms} h_coeff[i] * x_i, 1 <= nterms <= 4, evaluated left to right;
+ * y may alias any x_i (element-wise).  h_x is a HOST array of device pointers. */
+NSS_API int nss_lincomb_f64(int64_t n, int32_t nterms, const double* h_coeff,
+                            const double* const* h_x, double* y, nss_stream_t stream);
+/* InnerProduct (minres.py:71,98,103; bramble_pasciak_cg.py:105,130,137;
+ * bramblepasciak_new.py:185,222,235).  Deterministic two-stage reduction (fixed grid,
+ * fixed tree, no atomics).  npairs <= 4 pairs are summed pair 0 first (block vectors).
+ * `result_dev` (device, 1 double) is written asynchronously. */
+NSS_API int nss_dot_f64(int32_t npairs, const int64_t* h_n, const double* const* h_x,
+                        const double* const* h_y, double* result_dev, nss_stream_t stream);
+/* same, then waits and returns the value on the host */
+NSS_API int nss_dot_host_f64(int32_t npairs, const int64_t* h_n, const double* const* h_x,
+                             const double* const* h_y, double* h_result, nss_stream_t stream);
+/* z = x + a*y : STREAM-triad, the roofline denominator measured in the same run
+ *  */
+NSS_API int nss_stream_triad_f64(int64_t n, double a, const double* x, const double* y,
+                                 double* z, nss_stream_t stream);
+
+/* ---- CSR SpMV (reference: every `mat * vec` on blfA.mat / blfB.mat / B^T:
+ * bramblepasciak_new.py:130,133,160,163,166,202,206,210,213; bramble_pasciak_cg.py:46-47,
+ * 98-101,125,127; minres.py:66,97) ---------------------------------------------------- */
+NSS_API int nss_csr_create(int32_t nrows, int32_t ncols, int64_t nnz, const int32_t* h_rowptr,
+                           const int32_t* h_col, const double* h_val, nss_csr_t* out);
+NSS_API int nss_csr_destroy(nss_csr_t a);
+/* y = alpha * A x + beta * y   (beta == 0: y is not read).  x must not alias y. */
+NSS_API int nss_csr_spmv_f64(nss_csr_t a, double alpha, const double* x, double beta, double* y,
+                             nss_stream_t stream);
+/* shape, nnz, launch plan (row blocks, lanes per row) and algorithmic bytes of one
+ * SpMV: 12*nnz + 4*(rows+1) + 8*cols + 8*rows */
+NSS_API int nss_csr_info(nss_csr_t a, int32_t* nrows, int32_t* ncols, int64_t* nnz,
+                         int32_t* nblocks, int32_t* lanes_per_row, int64_t* algorithmic_bytes);
+NSS_API int nss_csr_diagonal(nss_csr_t a, double* diag_dev, nss_stream_t stream);
+
+/* ---- preconditioner applies -------------------------------------------------------------
+ * point Jacobi / lumped-mass inverse `Preconditioner(m,'local')`
+ * (templates/NavierStokesSIMPLE_iterative.py:197-200, run.py:62): y = alpha*d.*x + beta*y */
+NSS_API int nss_diag_apply_f64(int64_t n, const double* d, double alpha, const double* x,
+                               double beta, double* y, nss_stream_t stream);
+/* additive block Jacobi J = sum_b E_b A_bb^-1 E_b^T, the operator form of
+ * `a.mat.CreateBlockSmoother(blocks)` (templates/NavierStokesSIMPLE_iterative.py:360-373,383).
+ * h_idx: int32[bs][nblocks] (block-interleaved), -1 = padding; blocks must be disjoint.
+ * The bs x bs blocks are gathered from `a` and inverted on the device (Gauss-Jordan with
+ * partial pivoting), stored interleaved: inv[(r*bs+c)*nblocks + b].  1 <= bs <= 16. */
+NSS_API int nss_bjac_create(nss_csr_t a, int32_t bs, int32_t nblocks, const int32_t* h_idx,
+                            nss_bjac_t* out);
+NSS_API int nss_bjac_destroy(nss_bjac_t j);
+/* y[dofs] = alpha * J x + beta * y[dofs]; dofs in no block: y = beta*y (0 if beta == 0) */
+NSS_API int nss_bjac_apply_f64(nss_bjac_t j, double alpha, const double* x, double beta, double* y,
+                               nss_stream_t stream);
+NSS_API int nss_bjac_info(nss_bjac_t j, int32_t* bs, int32_t* nblocks, int64_t* n, int64_t* algorithmic_bytes);
+
+/* ---- fused Bramble-Pasciak CG, recurrence-optimised form ---------------------------------
+ * Replaces the loop body of solvers/bramblepasciak_new.py:200-249 (the solver the SIMPLE
+ * drivers call, templates/NavierStokesSIMPLE_iterative.py:397).  The host fills this struct
+ * with plain device pointers after the set-up phase (:124-189) and enqueues iterations;
+ * alpha / beta / wd / the stop test live in `scal` / `ctrl` on the device.
+ *
+ * Vector lengths: n_u for u0,d0,w0,s0,z0,q,t0,t2 ; t1 and t4 are SpMV operands of A and B and
+ * have A's / B's column count (n_u plus halo entries in a row-partitioned run); n_p for
+ * u1,d1,w1,t3 ; s1 is the operand of B^T (B^T's column count).
+ * scal: double[8] = { wd, as_s, wdn, alpha, beta, err0, tol, rel_err(0/1) };
+ * ctrl: int32[4]  = { done, it_final, last_it, - };  hist: double[maxsteps]. */
+typedef struct nss_bpcg2_s {
+  nss_csr_t A, B, BT;          /* A: n_u rows; B: n_p rows; BT: n_u rows (explicit transpose, :198) */
+  const double* pre_diag;      /* point-Jacobi preA (inverse diagonal, n_u)  -- or NULL          */
+  nss_bjac_t pre_bjac;         /* block-Jacobi preA                          -- or NULL          */
+  const double* minv;          /* preM = Preconditioner(mass,'local'): inverse mass diagonal, n_p */
+  double *u0, *u1, *d0, *d1, *w0, *w1, *s0, *s1, *z0, *q, *t0, *t1, *t2, *t3, *t4;
+  double* scal;
+  int32_t* ctrl;
+  double* hist;
+  double *partials_a, *partials_b, *partials_c; /* sizes: nss_bpcg2_workspace() */
+  double k;                    /* scale factor: preA = k * preA_unscaled (:118-122) */
+  int32_t n_u, n_p;
+} nss_bpcg2_t;
+
+enum {
+  NSS_BPCG2_K1 = 1,    /* t0 = (q recurrence) + B^T s1 [, t1 = k dinv t0]; block-Jacobi: t1 = k J t0 */
+  NSS_BPCG2_K2 = 2,    /* t2 = A t1, t4 = t1 - s0, partials <s0, t2 - t0>                             */
+  NSS_BPCG2_K3 = 3,    /* t3 = B t4, partials <s1, t3>                                                */
+  NSS_BPCG2_SUM1 = 4,  /* scal[as_s] = local sum of the K2/K3 partials                               */
+  NSS_BPCG2_ALPHA = 5, /* alpha = wd / as_s                                                           */
+  NSS_BPCG2_K4 = 6,    /* u += a s, d -= a v, w -= a C^-1 v, partials <w, d>                         */
+  NSS_BPCG2_SUM2 = 7,  /* scal[wdn] = local sum of the K4 partials                                   */
+  NSS_BPCG2_BETA = 8,  /* beta = wdn / wd, hist[it] = sqrt|wd|, stop test, wd <- wdn                */
+  NSS_BPCG2_K5 = 9     /* s1 = beta s1 + w1                                                           */
+};
+
+NSS_API int nss_bpcg2_workspace(const nss_bpcg2_t* s, int64_t* partials_a, int64_t* partials_b,
+                                int64_t* partials_c);
+/* one phase of iteration `it` (row-partitioned runs all-reduce scal[as_s] / scal[wdn] and exchange
+ * halos between phases) */
+NSS_API int nss_bpcg2_phase(const nss_bpcg2_t* s, int32_t which, int32_t it, nss_stream_t stream);
+/* enqueue iterations [it_begin, it_end) back to back (single GPU): no host synchronisation */
+NSS_API int nss_bpcg2_iterate(const nss_bpcg2_t* s, int32_t it_begin, int32_t it_end, nss_stream_t stream);
+/* wait for the stream and read ctrl: done flag, iteration at which the stop test fired, last
+ * iteration whose history entry was written */
+NSS_API int nss_bpcg2_poll(const nss_bpcg2_t* s, int32_t* done, int32_t* it_final, int32_t* last_it,
+                           nss_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NSS_KRYLOV_H */

@@ -1,0 +1,295 @@
+// Fused, device-resident iteration of the recurrence-optimised Bramble-Pasciak CG
+// (reference loop: solvers/bramblepasciak_new.py:200-249).
+//
+// One iteration = 3 CSR-stream SpMVs whose epilogues carry the vector recurrences and
+// the dot partials, one fused element-wise update, one small s-update and two
+// single-workgroup reductions that also advance the scalars (alpha, beta, stop test):
+//
+//   K1  rows of B^T :  [it>0] z0 -= a*t2 (:238, deferred), q = b*q + z0_old - a*t2 (:205),
+//                      s0 = b*s0 + w0 (:240-241, velocity part, deferred)
+//                      t0 = q + B^T s1 (:206-207);  Jacobi preA: t1 = k*dinv*t0 (:209)
+//   [J] block-Jacobi preA: t1 = k * J t0 (:209)
+//   K2  rows of A   :  t2 = A t1 (:210), t4 = t1 - s0 (:212), partial <s0, t2 - t0> (:218,222)
+//   K3  rows of B   :  t3 = B t4 (:213), partial <s1, t3> (:219,222)
+//   R1               :  as_s = sum partials, alpha = wd / as_s (:226)
+//   K4  element-wise:  u += a*s (:228), d -= a*v (:229), w0 -= a*t1, w1 -= a*minv*t3 (:232-233),
+//                      partial <w, d> (:235)
+//   R2               :  wdn, beta = wdn / wd (:236), hist[it] = sqrt|wd| (:243), stop test (:246)
+//   K5  element-wise:  s1 = b*s1 + w1 (:240-241, pressure part)
+//
+// alpha, beta, wd and the `done` flag live in device memory: nothing is copied to the host
+// inside the loop.  Once `done` is set every kernel returns immediately, so the state is
+// frozen exactly at the reference's `break` and the host may poll every m iterations.
+// R1/R2 are split into "local sum" and "scalar step" so that the row-partitioned
+// multi-GPU loop can all-reduce the local sums in between.
+#include "bpcg2.h"
+
+namespace nss {
+
+enum { S_WD = 0, S_AS = 1, S_WDN = 2, S_ALPHA = 3, S_BETA = 4, S_ERR0 = 5, S_TOL = 6, S_REL = 7 };
+enum { C_DONE = 0, C_IT_FINAL = 1, C_LAST_IT = 2 };
+
+struct EpiK1 {
+  const int32_t* __restrict__ ctrl;
+  const double* __restrict__ scal;
+  double* __restrict__ q;
+  double* __restrict__ z0;
+  const double* __restrict__ t2;
+  double* __restrict__ s0;
+  const double* __restrict__ w0;
+  double* __restrict__ t0;
+  double* __restrict__ t1;
+  const double* __restrict__ dinv;  // nullptr when preA is block-Jacobi
+  double k;
+  int first;
+  __device__ bool skip() const { return ctrl[C_DONE] != 0; }
+  __device__ void row(int r, double bts) const {
+    double qv = q[r];
+    if (!first) {
+      const double alpha = scal[S_ALPHA], beta = scal[S_BETA];
+      const double zo = z0[r], t2v = t2[r];
+      qv = fma(-alpha, t2v, fma(beta, qv, zo));
+      z0[r] = fma(-alpha, t2v, zo);
+      q[r] = qv;
+      s0[r] = fma(beta, s0[r], w0[r]);
+    }
+    const double t = qv + bts;
+    t0[r] = t;
+    if (dinv) t1[r] = k * (dinv[r] * t);
+  }
+  __device__ void finish(int, double*) const {}
+};
+
+struct EpiK2 {
+  const int32_t* __restrict__ ctrl;
+  const double* __restrict__ t0;
+  const double* __restrict__ t1;
+  const double* __restrict__ s0;
+  double* __restrict__ t2;
+  double* __restrict__ t4;
+  double* __restrict__ partials;
+  double acc = 0.0;
+  __device__ bool skip() const { return ctrl[C_DONE] != 0; }
+  __device__ void row(int r, double at1) {
+    const double sv = s0[r];
+    t2[r] = at1;
+    t4[r] = t1[r] - sv;
+    acc = fma(sv, at1 - t0[r], acc);
+  }
+  __device__ void finish(int b, double* lds) {
+    const double s = block_sum(acc, lds);
+    if (threadIdx.x == 0) partials[b] = s;
+  }
+};
+
+struct EpiK3 {
+  const int32_t* __restrict__ ctrl;
+  const double* __restrict__ s1;
+  double* __restrict__ t3;
+  double* __restrict__ partials;
+  double acc = 0.0;
+  __device__ bool skip() const { return ctrl[C_DONE] != 0; }
+  __device__ void row(int r, double bt4) {
+    t3[r] = bt4;
+    acc = fma(s1[r], bt4, acc);
+  }
+  __device__ void finish(int b, double* lds) {
+    const double s = block_sum(acc, lds);
+    if (threadIdx.x == 0) partials[b] = s;
+  }
+};
+
+// local sum of the partials of K2 and K3 (or of K4 when nb == 0) into scal[slot]
+__global__ __launch_bounds__(kBlock) void bpcg2_sum_kernel(const int32_t* __restrict__ ctrl, int na,
+                                                            const double* __restrict__ pa, int nb,
+                                                            const double* __restrict__ pb, double* __restrict__ scal,
+                                                            int slot) {
+  __shared__ double lds[kBlock / kWave];
+  if (ctrl[C_DONE] != 0) return;
+  double a = 0.0, b = 0.0;
+  for (int i = threadIdx.x; i < na; i += kBlock) a += pa[i];
+  for (int i = threadIdx.x; i < nb; i += kBlock) b += pb[i];
+  const double sa = block_sum(a, lds);
+  const double sb = block_sum(b, lds);
+  if (threadIdx.x == 0) scal[slot] = sa + sb;
+}
+
+// scalar steps (one lane): which = 1 -> alpha; which = 2 -> beta, history, stop test
+__global__ void bpcg2_scalar_kernel(int32_t* __restrict__ ctrl, double* __restrict__ scal, double* __restrict__ hist,
+                                    int which, int it) {
+  if (threadIdx.x != 0 || ctrl[C_DONE] != 0) return;
+  if (which == 1) {
+    scal[S_ALPHA] = scal[S_WD] / scal[S_AS];
+  } else {
+    const double wd = scal[S_WD], wdn = scal[S_WDN];
+    scal[S_BETA] = wdn / wd;
+    const double err = sqrt(fabs(wd));
+    hist[it] = err;
+    ctrl[C_LAST_IT] = it;
+    scal[S_WD] = wdn;
+    const double bound = scal[S_TOL] * (scal[S_REL] != 0.0 ? scal[S_ERR0] : 1.0);
+    if (err < bound) {
+      ctrl[C_IT_FINAL] = it;
+      ctrl[C_DONE] = 1;
+    }
+  }
+}
+
+struct K4Args {
+  const int32_t* ctrl;
+  const double* scal;
+  int32_t n_u, n_p;
+  double *u0, *d0, *w0, *u1, *d1, *w1;
+  const double *s0, *t0, *t1, *t2, *s1, *t3, *minv;
+  double* partials;
+};
+
+__global__ __launch_bounds__(kBlock) void bpcg2_k4_kernel(K4Args a) {
+  __shared__ double lds[kBlock / kWave];
+  if (a.ctrl[C_DONE] != 0) return;
+  const double alpha = a.scal[S_ALPHA];
+  const int stride = gridDim.x * kBlock;
+  double acc = 0.0;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < a.n_u; i += stride) {
+    const double sv = a.s0[i], t0v = a.t0[i], t1v = a.t1[i], t2v = a.t2[i];
+    a.u0[i] = fma(alpha, sv, a.u0[i]);
+    const double dn = fma(-alpha, t2v - t0v, a.d0[i]);
+    const double wn = fma(-alpha, t1v, a.w0[i]);
+    a.d0[i] = dn;
+    a.w0[i] = wn;
+    acc = fma(wn, dn, acc);
+  }
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < a.n_p; i += stride) {
+    const double sv = a.s1[i], t3v = a.t3[i];
+    a.u1[i] = fma(alpha, sv, a.u1[i]);
+    const double dn = fma(-alpha, t3v, a.d1[i]);
+    const double wn = fma(-alpha, a.minv[i] * t3v, a.w1[i]);
+    a.d1[i] = dn;
+    a.w1[i] = wn;
+    acc = fma(wn, dn, acc);
+  }
+  const double s = block_sum(acc, lds);
+  if (threadIdx.x == 0) a.partials[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(kBlock) void bpcg2_k5_kernel(const int32_t* __restrict__ ctrl,
+                                                           const double* __restrict__ scal, int32_t n_p,
+                                                           double* __restrict__ s1, const double* __restrict__ w1) {
+  if (ctrl[C_DONE] != 0) return;
+  const double beta = scal[S_BETA];
+  const int stride = gridDim.x * kBlock;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n_p; i += stride) s1[i] = fma(beta, s1[i], w1[i]);
+}
+
+static int k4_grid(const nss_bpcg2_t& s) { return stream_grid(int64_t(s.n_u) + s.n_p, kBlock * 4); }
+
+static void check_state(const nss_bpcg2_t* s) {
+  NSS_REQUIRE(s != nullptr, "bpcg2: NULL state");
+  NSS_REQUIRE(s->A && s->B && s->BT, "bpcg2: NULL matrix handle");
+  NSS_REQUIRE(s->A->m == s->n_u && s->BT->m == s->n_u && s->B->m == s->n_p, "bpcg2: matrix row counts do not match n_u/n_p");
+  NSS_REQUIRE((s->pre_diag != nullptr) != (s->pre_bjac != nullptr), "bpcg2: exactly one of pre_diag / pre_bjac");
+  NSS_REQUIRE(!s->pre_bjac || s->pre_bjac->n == s->n_u, "bpcg2: block-Jacobi size mismatch");
+  NSS_REQUIRE(s->minv && s->scal && s->ctrl && s->hist && s->partials_a && s->partials_b && s->partials_c,
+              "bpcg2: NULL work buffer");
+  NSS_REQUIRE(s->u0 && s->u1 && s->d0 && s->d1 && s->w0 && s->w1 && s->s0 && s->s1 && s->z0 && s->q && s->t0 &&
+                  s->t1 && s->t2 && s->t3 && s->t4,
+              "bpcg2: NULL vector");
+}
+
+static void phase(const nss_bpcg2_t& s, int which, int it, hipStream_t st) {
+  switch (which) {
+    case NSS_BPCG2_K1: {
+      EpiK1 e{s.ctrl, s.scal, s.q, s.z0, s.t2, s.s0, s.w0, s.t0, s.t1, s.pre_diag, s.k, it == 0 ? 1 : 0};
+      launch_csr_stream(*s.BT, s.s1, e, st);
+      if (s.pre_bjac) bjac_apply_guarded(*s.pre_bjac, s.k, s.t0, s.t1, s.ctrl, st);
+      break;
+    }
+    case NSS_BPCG2_K2: {
+      EpiK2 e{s.ctrl, s.t0, s.t1, s.s0, s.t2, s.t4, s.partials_a};
+      launch_csr_stream(*s.A, s.t1, e, st);
+      break;
+    }
+    case NSS_BPCG2_K3: {
+      EpiK3 e{s.ctrl, s.s1, s.t3, s.partials_b};
+      launch_csr_stream(*s.B, s.t4, e, st);
+      break;
+    }
+    case NSS_BPCG2_SUM1:
+      hipLaunchKernelGGL(bpcg2_sum_kernel, dim3(1), dim3(kBlock), 0, st, s.ctrl, s.A->nblk, s.partials_a, s.B->nblk,
+                         s.partials_b, s.scal, int(S_AS));
+      NSS_CHECK_LAUNCH();
+      break;
+    case NSS_BPCG2_ALPHA:
+      hipLaunchKernelGGL(bpcg2_scalar_kernel, dim3(1), dim3(kWave), 0, st, s.ctrl, s.scal, s.hist, 1, it);
+      NSS_CHECK_LAUNCH();
+      break;
+    case NSS_BPCG2_K4: {
+      K4Args a{s.ctrl, s.scal, s.n_u, s.n_p, s.u0, s.d0, s.w0, s.u1, s.d1, s.w1,
+               s.s0, s.t0, s.t1, s.t2, s.s1, s.t3, s.minv, s.partials_c};
+      hipLaunchKernelGGL(bpcg2_k4_kernel, dim3(k4_grid(s)), dim3(kBlock), 0, st, a);
+      NSS_CHECK_LAUNCH();
+      break;
+    }
+    case NSS_BPCG2_SUM2:
+      hipLaunchKernelGGL(bpcg2_sum_kernel, dim3(1), dim3(kBlock), 0, st, s.ctrl, k4_grid(s), s.partials_c, 0,
+                         s.partials_c, s.scal, int(S_WDN));
+      NSS_CHECK_LAUNCH();
+      break;
+    case NSS_BPCG2_BETA:
+      hipLaunchKernelGGL(bpcg2_scalar_kernel, dim3(1), dim3(kWave), 0, st, s.ctrl, s.scal, s.hist, 2, it);
+      NSS_CHECK_LAUNCH();
+      break;
+    case NSS_BPCG2_K5:
+      hipLaunchKernelGGL(bpcg2_k5_kernel, dim3(stream_grid(s.n_p, kBlock * 4)), dim3(kBlock), 0, st, s.ctrl, s.scal,
+                         s.n_p, s.s1, s.w1);
+      NSS_CHECK_LAUNCH();
+      break;
+    default:
+      throw Error("bpcg2: unknown phase");
+  }
+}
+
+}  // namespace nss
+
+using namespace nss;
+
+extern "C" {
+
+int nss_bpcg2_workspace(const nss_bpcg2_t* s, int64_t* partials_a, int64_t* partials_b, int64_t* partials_c) {
+  return guarded([&] {
+    NSS_REQUIRE(s && s->A && s->B, "bpcg2_workspace: NULL state / matrices");
+    if (partials_a) *partials_a = s->A->nblk;
+    if (partials_b) *partials_b = s->B->nblk;
+    if (partials_c) *partials_c = k4_grid(*s);
+  });
+}
+
+int nss_bpcg2_phase(const nss_bpcg2_t* s, int32_t which, int32_t it, nss_stream_t stream) {
+  return guarded([&] {
+    check_state(s);
+    phase(*s, which, it, as_stream(stream));
+  });
+}
+
+int nss_bpcg2_iterate(const nss_bpcg2_t* s, int32_t it_begin, int32_t it_end, nss_stream_t stream) {
+  return guarded([&] {
+    check_state(s);
+    hipStream_t st = as_stream(stream);
+    for (int it = it_begin; it < it_end; ++it)
+      for (int ph = NSS_BPCG2_K1; ph <= NSS_BPCG2_K5; ++ph) phase(*s, ph, it, st);
+  });
+}
+
+int nss_bpcg2_poll(const nss_bpcg2_t* s, int32_t* done, int32_t* it_final, int32_t* last_it, nss_stream_t stream) {
+  return guarded([&] {
+    NSS_REQUIRE(s && s->ctrl, "bpcg2_poll: NULL state");
+    int32_t h[4] = {0, 0, 0, 0};
+    NSS_HIP(hipMemcpyAsync(h, s->ctrl, sizeof(int32_t) * 3, hipMemcpyDeviceToHost, as_stream(stream)));
+    NSS_HIP(hipStreamSynchronize(as_stream(stream)));
+    if (done) *done = h[C_DONE];
+    if (it_final) *it_final = h[C_IT_FINAL];
+    if (last_it) *last_it = h[C_LAST_IT];
+  });
+}
+
+}  // extern "C"

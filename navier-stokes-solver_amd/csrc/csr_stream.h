@@ -1,0 +1,145 @@
+// CSR-stream SpMV kernel template for gfx950 (fp64 values, int32 indices).
+//
+// The Stokes blocks have short rows (7 / 6 / 2 non-zeros for A / B / B^T on the MAC
+// grid, ~25-84 for HDG-like operators), so a row-per-wave kernel would idle most of
+// its 64 lanes.  Instead a 256-thread workgroup owns a contiguous *row block* whose
+// non-zeros fit one LDS chunk:
+//   phase 1  every lane streams val[] / col[] with unit stride (fully coalesced HBM
+//            reads, 8 independent loads in flight per lane), gathers x[col] (served by
+//            L2 / Infinity Cache for banded operators) and stages the products in LDS;
+//   phase 2  each row is reduced from LDS by RG lanes (RG = 1, 4, 16 or 64 chosen from
+//            the mean row length) with a __shfl_xor butterfly, in a fixed order -- no
+//            atomics, bit-reproducible;
+//   epilogue a functor consumes (row, A x) -- plain alpha/beta update or the fused
+//            vector updates + dot partials of the Krylov loops -- so y is written once
+//            and the extra vectors are read while the row is still in registers.
+// Row blocks are precomputed on the host when the matrix is uploaded.  The
+// blockIdx -> row-block map is XCD-aware: workgroups b and b+8 share an XCD (round-robin
+// dispatch), so XCD i walks its own contiguous eighth of the rows and its private 4 MiB
+// L2 keeps one window of x instead of all eight L2s caching the same window.
+#pragma once
+
+#include "nss_common.h"
+
+namespace nss {
+
+constexpr int kChunk = 2048;            // products staged per workgroup: 16 KiB of LDS
+constexpr int kMaxRowsPerBlock = 2048;  // bound for blocks of empty / very short rows
+constexpr int kXcds = 8;
+
+struct CsrView {
+  const int32_t* __restrict__ rowblk;
+  const int32_t* __restrict__ rowptr;
+  const int32_t* __restrict__ col;
+  const double* __restrict__ val;
+  int32_t nblk;
+  int32_t per_xcd;  // ceil(nblk / 8)
+};
+
+}  // namespace nss
+
+struct nss_csr_s {
+  int32_t m = 0, n = 0;
+  int64_t nnz = 0;
+  int32_t* rowptr = nullptr;
+  int32_t* col = nullptr;
+  double* val = nullptr;
+  int32_t* rowblk = nullptr;
+  int32_t nblk = 0;
+  int32_t rg = 1;
+  nss::CsrView view() const {
+    return nss::CsrView{rowblk, rowptr, col, val, nblk, (nblk + nss::kXcds - 1) / nss::kXcds};
+  }
+  int grid() const { return ((nblk + nss::kXcds - 1) / nss::kXcds) * nss::kXcds; }
+};
+
+namespace nss {
+
+// Epi interface:
+//   __device__ void row(int r, double ax);          // called once per row by one lane
+//   __device__ void finish(int block, double* lds); // called by all threads at the end
+//   __device__ bool skip() const;                   // e.g. solver already converged
+template <int RG, class Epi>
+__global__ __launch_bounds__(kBlock) void csr_stream_kernel(CsrView a, const double* __restrict__ x, Epi epi) {
+  __shared__ double prod[kChunk];
+  __shared__ double red[kBlock / kWave];
+  if (epi.skip()) return;
+  const int b = (blockIdx.x & (kXcds - 1)) * a.per_xcd + (blockIdx.x >> 3);
+  if (b >= a.nblk) return;
+  const int tid = threadIdx.x;
+  const int r0 = a.rowblk[b];
+  const int r1 = a.rowblk[b + 1];
+  const int p0 = a.rowptr[r0];
+  const int cnt = a.rowptr[r1] - p0;
+
+  if (cnt <= kChunk) {
+    // ---- phase 1: coalesced stream of (col, val), gather x, stage products -----------
+    constexpr int kPer = kChunk / kBlock;
+    int32_t c[kPer];
+    double v[kPer];
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      const int i = tid + k * kBlock;
+      const bool live = i < cnt;
+      c[k] = live ? a.col[p0 + i] : 0;
+      v[k] = live ? a.val[p0 + i] : 0.0;
+    }
+    double xv[kPer];
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) xv[k] = (tid + k * kBlock < cnt) ? x[c[k]] : 0.0;
+#pragma unroll
+    for (int k = 0; k < kPer; ++k)
+      if (tid + k * kBlock < cnt) prod[tid + k * kBlock] = v[k] * xv[k];
+    __syncthreads();
+    // ---- phase 2: per-row reduction from LDS -------------------------------------------
+    constexpr int kRowsPerPass = kBlock / RG;
+    const int sub = tid % RG;
+    for (int r = r0 + tid / RG; r < r1; r += kRowsPerPass) {
+      const int s = a.rowptr[r] - p0;
+      const int e = a.rowptr[r + 1] - p0;
+      double sum = 0.0;
+      for (int j = s + sub; j < e; j += RG) sum += prod[j];
+      if (RG > 1) {
+#pragma unroll
+        for (int off = RG / 2; off > 0; off >>= 1) sum += __shfl_xor(sum, off, kWave);
+      }
+      if (sub == 0) epi.row(r, sum);
+    }
+  } else {
+    // ---- one row longer than the LDS chunk: the whole workgroup reduces it ------------
+    double acc = 0.0;
+    for (int i = tid; i < cnt; i += kBlock) acc = fma(a.val[p0 + i], x[a.col[p0 + i]], acc);
+    const double sum = block_sum(acc, red);
+    if (tid == 0) epi.row(r0, sum);
+  }
+  epi.finish(b, red);
+}
+
+template <class Epi>
+inline void launch_csr_stream(const nss_csr_s& A, const double* x, const Epi& epi, hipStream_t st) {
+  if (A.m == 0) return;
+  const CsrView v = A.view();
+  const dim3 grid(A.grid()), block(kBlock);
+  switch (A.rg) {
+    case 1: hipLaunchKernelGGL((csr_stream_kernel<1, Epi>), grid, block, 0, st, v, x, epi); break;
+    case 4: hipLaunchKernelGGL((csr_stream_kernel<4, Epi>), grid, block, 0, st, v, x, epi); break;
+    case 16: hipLaunchKernelGGL((csr_stream_kernel<16, Epi>), grid, block, 0, st, v, x, epi); break;
+    default: hipLaunchKernelGGL((csr_stream_kernel<64, Epi>), grid, block, 0, st, v, x, epi); break;
+  }
+  NSS_CHECK_LAUNCH();
+}
+
+// y = alpha * A x + beta * y
+struct EpiAxpby {
+  double alpha, beta;
+  double* __restrict__ y;
+  __device__ bool skip() const { return false; }
+  __device__ void row(int r, double ax) const {
+    double t = alpha * ax;
+    if (beta != 0.0) t = fma(beta, y[r], t);
+    y[r] = t;
+  }
+  __device__ void finish(int, double*) const {}
+};
+
+}  // namespace nss

@@ -1,0 +1,24 @@
+// Block-Jacobi handle shared by the preconditioner entry points and the fused loops.
+#pragma once
+
+#include "csr_stream.h"
+
+struct nss_bjac_s {
+  int32_t bs = 0, nblocks = 0;
+  int64_t n = 0;
+  int32_t* idx = nullptr;      // [bs][nblocks], -1 = padding
+  double* inv = nullptr;       // [bs*bs][nblocks]
+  int32_t* covered = nullptr;  // dofs that belong to no block (count: n_uncovered)
+  int32_t n_uncovered = 0;
+};
+
+namespace nss {
+
+constexpr int kMaxBs = 16;
+
+// y[dofs] = alpha * J x + beta * y[dofs]; returns immediately on the device when
+// `done` (device int, may be NULL) is non-zero.
+void bjac_apply(const nss_bjac_s& j, double alpha, const double* x, double beta, double* y, const int32_t* done,
+                hipStream_t st);
+
+}  // namespace nss

@@ -1,0 +1,136 @@
+// CSR matrix handles (upload, launch plan) and the plain alpha/beta SpMV entry point.
+#include "csr_stream.h"
+
+#include <algorithm>
+#include <vector>
+
+namespace nss {
+
+static void plan_row_blocks(int32_t m, int64_t nnz, const int32_t* rowptr, int32_t* rg_out,
+                            std::vector<int32_t>& blk) {
+  const double mean = m > 0 ? double(nnz) / double(m) : 0.0;
+  int rg = 1;
+  if (mean > 192.0) rg = 64;
+  else if (mean > 48.0) rg = 16;
+  else if (mean > 12.0) rg = 4;
+  *rg_out = rg;
+  // rows per block: a whole number of reduce passes whose products still fit the chunk
+  const int rows_per_pass = kBlock / rg;
+  int passes = mean > 0.0 ? int(double(kChunk) / (mean * rows_per_pass)) : kMaxRowsPerBlock / rows_per_pass;
+  passes = std::max(1, passes);
+  const int row_cap = std::min(kMaxRowsPerBlock, passes * rows_per_pass);
+  blk.clear();
+  blk.push_back(0);
+  int32_t r = 0;
+  while (r < m) {
+    const int32_t start = r;
+    int64_t acc = 0;
+    while (r < m && r - start < row_cap) {
+      const int64_t len = int64_t(rowptr[r + 1]) - rowptr[r];
+      if (acc + len > kChunk) break;
+      acc += len;
+      ++r;
+    }
+    if (r == start) ++r;  // a single row longer than the chunk gets a block of its own
+    blk.push_back(r);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void csr_diag_kernel(int32_t m, const int32_t* __restrict__ rowptr,
+                                                           const int32_t* __restrict__ col,
+                                                           const double* __restrict__ val, double* __restrict__ d) {
+  const int r = blockIdx.x * kBlock + threadIdx.x;
+  if (r >= m) return;
+  double v = 0.0;
+  for (int p = rowptr[r]; p < rowptr[r + 1]; ++p)
+    if (col[p] == r) v = val[p];
+  d[r] = v;
+}
+
+}  // namespace nss
+
+using namespace nss;
+
+extern "C" {
+
+int nss_csr_create(int32_t nrows, int32_t ncols, int64_t nnz, const int32_t* h_rowptr, const int32_t* h_col,
+                   const double* h_val, nss_csr_t* out) {
+  return guarded([&] {
+    NSS_REQUIRE(out != nullptr, "csr_create: out is NULL");
+    NSS_REQUIRE(nrows >= 0 && ncols >= 0 && nnz >= 0, "csr_create: negative size");
+    NSS_REQUIRE(nnz < (int64_t(1) << 31), "csr_create: nnz must fit int32 offsets");
+    NSS_REQUIRE(h_rowptr != nullptr, "csr_create: rowptr is NULL");
+    NSS_REQUIRE(h_rowptr[0] == 0 && int64_t(h_rowptr[nrows]) == nnz, "csr_create: rowptr does not span nnz");
+    for (int32_t r = 0; r < nrows; ++r)
+      NSS_REQUIRE(h_rowptr[r + 1] >= h_rowptr[r], "csr_create: rowptr not monotone");
+    for (int64_t p = 0; p < nnz; ++p)
+      NSS_REQUIRE(h_col[p] >= 0 && h_col[p] < ncols, "csr_create: column index out of range");
+    nss_csr_s* A = new nss_csr_s;
+    try {
+      A->m = nrows;
+      A->n = ncols;
+      A->nnz = nnz;
+      std::vector<int32_t> blk;
+      plan_row_blocks(nrows, nnz, h_rowptr, &A->rg, blk);
+      A->nblk = int32_t(blk.size()) - 1;
+      NSS_HIP(hipMalloc(&A->rowptr, sizeof(int32_t) * (size_t(nrows) + 1)));
+      NSS_HIP(hipMalloc(&A->col, sizeof(int32_t) * std::max<int64_t>(nnz, 1)));
+      NSS_HIP(hipMalloc(&A->val, sizeof(double) * std::max<int64_t>(nnz, 1)));
+      NSS_HIP(hipMalloc(&A->rowblk, sizeof(int32_t) * blk.size()));
+      NSS_HIP(hipMemcpy(A->rowptr, h_rowptr, sizeof(int32_t) * (size_t(nrows) + 1), hipMemcpyHostToDevice));
+      if (nnz > 0) {
+        NSS_HIP(hipMemcpy(A->col, h_col, sizeof(int32_t) * nnz, hipMemcpyHostToDevice));
+        NSS_HIP(hipMemcpy(A->val, h_val, sizeof(double) * nnz, hipMemcpyHostToDevice));
+      }
+      NSS_HIP(hipMemcpy(A->rowblk, blk.data(), sizeof(int32_t) * blk.size(), hipMemcpyHostToDevice));
+    } catch (...) {
+      nss_csr_destroy(A);
+      throw;
+    }
+    *out = A;
+  });
+}
+
+int nss_csr_destroy(nss_csr_t a) {
+  return guarded([&] {
+    if (!a) return;
+    (void)hipFree(a->rowptr);
+    (void)hipFree(a->col);
+    (void)hipFree(a->val);
+    (void)hipFree(a->rowblk);
+    delete a;
+  });
+}
+
+int nss_csr_spmv_f64(nss_csr_t a, double alpha, const double* x, double beta, double* y, nss_stream_t stream) {
+  return guarded([&] {
+    NSS_REQUIRE(a != nullptr, "csr_spmv: NULL matrix");
+    NSS_REQUIRE(x != y, "csr_spmv: x must not alias y");
+    launch_csr_stream(*a, x, EpiAxpby{alpha, beta, y}, as_stream(stream));
+  });
+}
+
+int nss_csr_info(nss_csr_t a, int32_t* nrows, int32_t* ncols, int64_t* nnz, int32_t* nblocks,
+                 int32_t* lanes_per_row, int64_t* algorithmic_bytes) {
+  return guarded([&] {
+    NSS_REQUIRE(a != nullptr, "csr_info: NULL matrix");
+    if (nrows) *nrows = a->m;
+    if (ncols) *ncols = a->n;
+    if (nnz) *nnz = a->nnz;
+    if (nblocks) *nblocks = a->nblk;
+    if (lanes_per_row) *lanes_per_row = a->rg;
+    if (algorithmic_bytes) *algorithmic_bytes = 12 * a->nnz + 4 * (int64_t(a->m) + 1) + 8 * int64_t(a->n) + 8 * int64_t(a->m);
+  });
+}
+
+int nss_csr_diagonal(nss_csr_t a, double* diag_dev, nss_stream_t stream) {
+  return guarded([&] {
+    NSS_REQUIRE(a != nullptr, "csr_diagonal: NULL matrix");
+    if (a->m == 0) return;
+    hipLaunchKernelGGL(csr_diag_kernel, dim3((a->m + kBlock - 1) / kBlock), dim3(kBlock), 0, as_stream(stream),
+                       a->m, a->rowptr, a->col, a->val, diag_dev);
+    NSS_CHECK_LAUNCH();
+  });
+}
+
+}  // extern "C"

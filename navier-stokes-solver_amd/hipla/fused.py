@@ -1,0 +1,164 @@
+"""Host side of the fused, device-resident Krylov loops (C ABI: ``nss_bpcg2_*`` ...).
+
+``*.try_create`` return a loop object when every operand is native to the HIP engine
+(CSR ``SparseMatrix`` blocks, Jacobi / block-Jacobi preconditioners, plain vectors) and
+``None`` otherwise -- the caller then drives the same algorithm through the operator
+protocol (still on the GPU, one kernel per statement), which is what keeps user
+``BaseMatrix`` subclasses working.
+
+The loops enqueue ``poll_every`` iterations at a time without any host synchronisation;
+alpha / beta / the stop test live on the device and a ``done`` flag freezes the state at
+exactly the iteration where the reference would ``break``."""
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from .matrix import BlockJacobi, DiagonalMatrix, ScaledMatrix, SparseMatrix
+from .vector import Vector
+
+POLL_EVERY = int(os.environ.get("NSS_POLL_EVERY", "32"))
+ENABLED = True      # tests flip this to force the protocol path on native operands
+
+
+class Bpcg2State(C.Structure):
+    """ctypes mirror of ``nss_bpcg2_t`` (include/nss_krylov.h)."""
+    _fields_ = ([(n, C.c_void_p) for n in ("A", "B", "BT", "pre_diag", "pre_bjac", "minv")]
+                + [(n, C.c_void_p) for n in ("u0", "u1", "d0", "d1", "w0", "w1", "s0", "s1", "z0", "q",
+                                             "t0", "t1", "t2", "t3", "t4")]
+                + [("scal", C.c_void_p), ("ctrl", C.c_void_p), ("hist", C.c_void_p),
+                   ("partials_a", C.c_void_p), ("partials_b", C.c_void_p), ("partials_c", C.c_void_p),
+                   ("k", C.c_double), ("n_u", C.c_int32), ("n_p", C.c_int32)])
+
+
+PHASE = {"K1": 1, "K2": 2, "K3": 3, "SUM1": 4, "ALPHA": 5, "K4": 6, "SUM2": 7, "BETA": 8, "K5": 9}
+S_WD, S_AS, S_WDN, S_ALPHA, S_BETA, S_ERR0, S_TOL, S_REL = range(8)
+
+
+def _hip(engine):
+    return getattr(engine, "name", "") == "hip-gfx950" and hasattr(engine.lib, "nss_bpcg2_iterate")
+
+
+def native_diag(op):
+    """(scale, DiagonalMatrix) if `op` is a (scaled) diagonal preconditioner, else None."""
+    scale = 1.0
+    if isinstance(op, ScaledMatrix):
+        scale, op = op.scale, op.mat
+    if isinstance(op, DiagonalMatrix):
+        return scale, op
+    return None
+
+
+def native_bjac(op):
+    scale = 1.0
+    if isinstance(op, ScaledMatrix):
+        scale, op = op.scale, op.mat
+    if isinstance(op, BlockJacobi):
+        return scale, op
+    return None
+
+
+def _plain(v, n):
+    return isinstance(v, Vector) and v.size == n
+
+
+class Bpcg2Loop:
+    """Device-resident iteration of solvers/bramblepasciak_new.py:200-249."""
+
+    @classmethod
+    def try_create(cls, matA, matB, matBT, preA_unscaled, k, preM, vecs):
+        if not (isinstance(matA, SparseMatrix) and isinstance(matB, SparseMatrix) and isinstance(matBT, SparseMatrix)):
+            return None
+        eng = matA.engine
+        if not ENABLED or not _hip(eng):
+            return None
+        n_u, n_p = matA.height, matB.height
+        if matA.width != n_u or matB.width != n_u or matBT.height != n_u or matBT.width != n_p:
+            return None
+        pm = native_diag(preM)
+        pa_d, pa_b = native_diag(preA_unscaled), native_bjac(preA_unscaled)
+        if pm is None or (pa_d is None and pa_b is None):
+            return None
+        sizes = {"u0": n_u, "d0": n_u, "w0": n_u, "s0": n_u, "z0": n_u, "q": n_u, "t0": n_u, "t1": n_u,
+                 "t2": n_u, "t4": n_u, "u1": n_p, "d1": n_p, "w1": n_p, "s1": n_p, "t3": n_p}
+        if any(not _plain(vecs.get(name), n) for name, n in sizes.items()):
+            return None
+        return cls(eng, matA, matB, matBT, pa_d, pa_b, k, pm, vecs)
+
+    def __init__(self, eng, matA, matB, matBT, pa_d, pa_b, k, pm, vecs):
+        torch = eng.torch
+        self.eng, self.lib = eng, eng.lib
+        self.keep = [matA, matB, matBT, vecs, pa_d, pa_b, pm]       # keep device memory alive
+        st = Bpcg2State()
+        st.A, st.B, st.BT = matA.handle.ptr, matB.handle.ptr, matBT.handle.ptr
+        if pa_d is not None:
+            scale, op = pa_d
+            st.pre_diag, st.pre_bjac = op.d.data_ptr(), None
+        else:
+            scale, op = pa_b
+            st.pre_diag, st.pre_bjac = None, op.handle.ptr
+        st.k = float(k) * scale
+        mscale, mop = pm
+        if mscale != 1.0:
+            self.minv = mop.d * mscale
+        else:
+            self.minv = mop.d
+        st.minv = self.minv.data_ptr()
+        for name in ("u0", "u1", "d0", "d1", "w0", "w1", "s0", "s1", "z0", "q", "t0", "t1", "t2", "t3", "t4"):
+            setattr(st, name, vecs[name].buf.data_ptr())
+        st.n_u, st.n_p = matA.height, matB.height
+        na, nb, nc = C.c_int64(), C.c_int64(), C.c_int64()
+        eng._check(self.lib.nss_bpcg2_workspace(C.byref(st), C.byref(na), C.byref(nb), C.byref(nc)))
+        self.partials = [eng.zeros(max(1, v.value)) for v in (na, nb, nc)]
+        st.partials_a, st.partials_b, st.partials_c = (p.data_ptr() for p in self.partials)
+        self.scal = eng.zeros(8)
+        self.ctrl = torch.zeros(4, dtype=torch.int32, device=eng.device)
+        st.scal, st.ctrl = self.scal.data_ptr(), self.ctrl.data_ptr()
+        self.hist = None
+        self.state = st
+
+    # ---- driving the loop -------------------------------------------------------------------
+    def start(self, wdn, err0, tol, rel_err, maxsteps):
+        """Upload the scalars of iteration 0 and clear the control words / history."""
+        eng, st = self.eng, self.state
+        self.maxsteps = int(maxsteps)
+        self.hist = eng.zeros(max(1, self.maxsteps))
+        st.hist = self.hist.data_ptr()
+        scal = np.zeros(8)
+        scal[S_WD], scal[S_ERR0], scal[S_TOL], scal[S_REL] = wdn, err0, tol, 1.0 if rel_err else 0.0
+        eng.upload(scal, self.scal)
+        self.ctrl.zero_()
+
+    def enqueue(self, it_begin, it_end):
+        """Enqueue iterations [it_begin, it_end) on the current stream; returns immediately."""
+        self.eng._check(self.lib.nss_bpcg2_iterate(C.byref(self.state), int(it_begin), int(it_end), self.eng.stream))
+
+    def phase(self, name, it):
+        self.eng._check(self.lib.nss_bpcg2_phase(C.byref(self.state), PHASE[name], int(it), self.eng.stream))
+
+    def poll(self):
+        """Drain the stream; returns (done, it_final, last_it)."""
+        done, it_final, last = C.c_int32(), C.c_int32(), C.c_int32()
+        self.eng._check(self.lib.nss_bpcg2_poll(C.byref(self.state), C.byref(done), C.byref(it_final),
+                                                C.byref(last), self.eng.stream))
+        return bool(done.value), it_final.value, last.value
+
+    def history(self, upto):
+        return self.eng.to_host(self.hist)[: upto + 1]
+
+    def run(self, wdn, err0, tol, rel_err, maxsteps, poll_every=None):
+        """Returns (it, history, converged) -- `it` as the reference's loop variable after
+        the loop (index of the iteration whose stop test fired, or maxsteps-1)."""
+        poll_every = poll_every or POLL_EVERY
+        self.start(wdn, err0, tol, rel_err, maxsteps)
+        it, done, it_final = 0, False, 0
+        while it < maxsteps:
+            end = min(maxsteps, it + poll_every)
+            self.enqueue(it, end)
+            it = end
+            done, it_final, _ = self.poll()
+            if done:
+                break
+        final = it_final if done else maxsteps - 1
+        return final, self.history(final), done

@@ -1,0 +1,257 @@
+"""The product engine: ctypes binding of libnsskrylov.so (hand-written gfx950 HIP
+kernels, C ABI in include/nss_krylov.h).
+
+Device memory for vectors is allocated through torch (``torch.empty(..,
+device='cuda')``) so that ``torch.distributed`` (RCCL) can exchange the very same
+buffers; only raw device pointers, sizes and the current HIP stream cross the C ABI.
+Matrices and block-Jacobi inverses are owned by the library.
+
+There is no fallback: if the shared library or the GPU is missing this module raises
+`EngineUnavailable`."""
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from .engine import EngineUnavailable
+
+_LIB_NAME = "libnsskrylov.so"
+_PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG_DIR, _LIB_NAME)
+
+c_double_p = C.POINTER(C.c_double)
+c_i32_p = C.POINTER(C.c_int32)
+c_i64_p = C.POINTER(C.c_int64)
+
+
+def _signatures():
+    vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+    return {
+        "nss_abi_version": (C.c_int, []),
+        "nss_last_error": (C.c_char_p, []),
+        "nss_device_info": (C.c_int, [c_i32_p, c_i64_p, c_i32_p, C.c_char_p, i32]),
+        "nss_stream_synchronize": (C.c_int, [vp]),
+        "nss_fill_f64": (C.c_int, [i64, dbl, vp, vp]),
+        "nss_copy_f64": (C.c_int, [i64, vp, vp, vp]),
+        "nss_scal_f64": (C.c_int, [i64, dbl, vp, vp]),
+        "nss_lincomb_f64": (C.c_int, [i64, i32, c_double_p, C.POINTER(vp), vp, vp]),
+        "nss_dot_f64": (C.c_int, [i32, c_i64_p, C.POINTER(vp), C.POINTER(vp), vp, vp]),
+        "nss_dot_host_f64": (C.c_int, [i32, c_i64_p, C.POINTER(vp), C.POINTER(vp), c_double_p, vp]),
+        "nss_stream_triad_f64": (C.c_int, [i64, dbl, vp, vp, vp, vp]),
+        "nss_csr_create": (C.c_int, [i32, i32, i64, vp, vp, vp, C.POINTER(vp)]),
+        "nss_csr_destroy": (C.c_int, [vp]),
+        "nss_csr_spmv_f64": (C.c_int, [vp, dbl, vp, dbl, vp, vp]),
+        "nss_csr_info": (C.c_int, [vp, c_i32_p, c_i32_p, c_i64_p, c_i32_p, c_i32_p, c_i64_p]),
+        "nss_csr_diagonal": (C.c_int, [vp, vp, vp]),
+        "nss_diag_apply_f64": (C.c_int, [i64, vp, dbl, vp, dbl, vp, vp]),
+        "nss_bjac_create": (C.c_int, [vp, i32, i32, vp, C.POINTER(vp)]),
+        "nss_bjac_destroy": (C.c_int, [vp]),
+        "nss_bjac_apply_f64": (C.c_int, [vp, dbl, vp, dbl, vp, vp]),
+        "nss_bjac_info": (C.c_int, [vp, c_i32_p, c_i32_p, c_i64_p, c_i64_p]),
+        "nss_bpcg2_workspace": (C.c_int, [vp, c_i64_p, c_i64_p, c_i64_p]),
+        "nss_bpcg2_phase": (C.c_int, [vp, i32, i32, vp]),
+        "nss_bpcg2_iterate": (C.c_int, [vp, i32, i32, vp]),
+        "nss_bpcg2_poll": (C.c_int, [vp, c_i32_p, c_i32_p, c_i32_p, vp]),
+    }
+
+
+def load_library(path=None):
+    """dlopen libnsskrylov.so and attach ctypes signatures.  torch is imported first so
+    that the library binds to the HIP runtime torch already loaded (same SONAME)."""
+    import torch  # noqa: F401  (must precede the dlopen)
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise EngineUnavailable(
+            "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C navier-stokes-solver_amd/csrc`" % path)
+    try:
+        lib = C.CDLL(path)
+    except OSError as exc:
+        raise EngineUnavailable("cannot load %s: %s" % (path, exc)) from exc
+    for name, (res, args) in _signatures().items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+class NssError(RuntimeError):
+    pass
+
+
+class _CsrHandle:
+    def __init__(self, engine, ptr, m, n, nnz):
+        self.engine, self.ptr, self.m, self.n, self.nnz = engine, ptr, m, n, nnz
+
+    def info(self):
+        lib = self.engine.lib
+        m, n, nb, rg = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        nnz, nbytes = C.c_int64(), C.c_int64()
+        self.engine._check(lib.nss_csr_info(self.ptr, m, n, nnz, nb, rg, nbytes))
+        return {"rows": m.value, "cols": n.value, "nnz": nnz.value, "row_blocks": nb.value,
+                "lanes_per_row": rg.value, "algorithmic_bytes": nbytes.value}
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                self.engine.lib.nss_csr_destroy(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+class _BjacHandle:
+    def __init__(self, engine, ptr, bs, nblocks, n):
+        self.engine, self.ptr, self.bs, self.nblocks, self.n = engine, ptr, bs, nblocks, n
+
+    def algorithmic_bytes(self):
+        nbytes = C.c_int64()
+        self.engine._check(self.engine.lib.nss_bjac_info(self.ptr, None, None, None, nbytes))
+        return nbytes.value
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                self.engine.lib.nss_bjac_destroy(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+class HipEngine:
+    name = "hip-gfx950"
+
+    def __init__(self, device=None):
+        import torch
+        self.torch = torch
+        self.lib = load_library()
+        if not torch.cuda.is_available():
+            raise EngineUnavailable("no GPU visible: the hipla product engine needs an MI355X "
+                                    "(there is no CPU fallback)")
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        if self.lib.nss_abi_version() != 1:
+            raise EngineUnavailable("libnsskrylov ABI mismatch")
+        self._stream_cache = None
+
+    # ---- plumbing --------------------------------------------------------------------
+    def _check(self, rc):
+        if rc != 0:
+            raise NssError(self.lib.nss_last_error().decode("utf-8", "replace"))
+
+    @property
+    def stream(self):
+        return self.torch.cuda.current_stream(self.device).cuda_stream
+
+    def device_info(self):
+        cu, wf, hbm = C.c_int32(), C.c_int32(), C.c_int64()
+        name = C.create_string_buffer(64)
+        self._check(self.lib.nss_device_info(cu, hbm, wf, name, 64))
+        return {"cu_count": cu.value, "hbm_bytes": hbm.value, "wavefront": wf.value,
+                "arch": name.value.decode()}
+
+    def synchronize(self):
+        self._check(self.lib.nss_stream_synchronize(self.stream))
+
+    # ---- buffers -----------------------------------------------------------------------
+    def zeros(self, n):
+        return self.torch.zeros(int(n), dtype=self.torch.float64, device=self.device)
+
+    def empty(self, n):
+        return self.torch.empty(int(n), dtype=self.torch.float64, device=self.device)
+
+    def length(self, buf):
+        return int(buf.shape[0])
+
+    def from_host(self, arr):
+        t = self.torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float64))
+        return t.to(self.device)
+
+    def upload(self, arr, buf):
+        buf.copy_(self.torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float64)))
+
+    def to_host(self, buf):
+        return buf.detach().cpu().numpy()
+
+    def view(self, buf, a, b):
+        return buf[a:b]
+
+    def same_buffer(self, a, b):
+        return a.data_ptr() == b.data_ptr() and a.shape == b.shape
+
+    def overlaps(self, a, b):
+        a0, a1 = a.data_ptr(), a.data_ptr() + 8 * a.shape[0]
+        b0, b1 = b.data_ptr(), b.data_ptr() + 8 * b.shape[0]
+        return a0 < b1 and b0 < a1
+
+    # ---- BLAS-1 ---------------------------------------------------------------------------
+    def fill(self, buf, c):
+        self._check(self.lib.nss_fill_f64(buf.shape[0], c, buf.data_ptr(), self.stream))
+
+    def copy(self, src, dst):
+        self._check(self.lib.nss_copy_f64(src.shape[0], src.data_ptr(), dst.data_ptr(), self.stream))
+
+    def scal(self, buf, a):
+        self._check(self.lib.nss_scal_f64(buf.shape[0], a, buf.data_ptr(), self.stream))
+
+    def lincomb(self, dst, terms):
+        nt = len(terms)
+        coeff = (C.c_double * nt)(*[float(s) for s, _ in terms])
+        ptrs = (C.c_void_p * nt)(*[b.data_ptr() for _, b in terms])
+        self._check(self.lib.nss_lincomb_f64(dst.shape[0], nt, coeff, ptrs, dst.data_ptr(), self.stream))
+
+    def dot(self, x, y):
+        return self.dot_multi([(x, y)])
+
+    def dot_multi(self, pairs):
+        total = 0.0
+        for k in range(0, len(pairs), 4):
+            chunk = pairs[k:k + 4]
+            n = len(chunk)
+            ns = (C.c_int64 * n)(*[x.shape[0] for x, _ in chunk])
+            xs = (C.c_void_p * n)(*[x.data_ptr() for x, _ in chunk])
+            ys = (C.c_void_p * n)(*[y.data_ptr() for _, y in chunk])
+            out = C.c_double()
+            self._check(self.lib.nss_dot_host_f64(n, ns, xs, ys, C.byref(out), self.stream))
+            total += out.value
+        return total
+
+    def stream_triad(self, a, x, y, z):
+        self._check(self.lib.nss_stream_triad_f64(x.shape[0], a, x.data_ptr(), y.data_ptr(), z.data_ptr(),
+                                                  self.stream))
+
+    # ---- operators ----------------------------------------------------------------------------
+    def csr_create(self, m, n, rowptr, col, val):
+        rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
+        col = np.ascontiguousarray(col, dtype=np.int32)
+        val = np.ascontiguousarray(val, dtype=np.float64)
+        out = C.c_void_p()
+        self._check(self.lib.nss_csr_create(m, n, col.size, rowptr.ctypes.data, col.ctypes.data,
+                                            val.ctypes.data, C.byref(out)))
+        return _CsrHandle(self, out, m, n, int(col.size))
+
+    def csr_spmv(self, h, alpha, x, beta, y):
+        if x.shape[0] != h.n or y.shape[0] != h.m:
+            raise ValueError("SpMV shape mismatch: A is %dx%d, x %d, y %d" % (h.m, h.n, x.shape[0], y.shape[0]))
+        self._check(self.lib.nss_csr_spmv_f64(h.ptr, alpha, x.data_ptr(), beta, y.data_ptr(), self.stream))
+
+    def diag_apply(self, d, alpha, x, beta, y):
+        if not (d.shape[0] == x.shape[0] == y.shape[0]):
+            raise ValueError("diag_apply shape mismatch")
+        self._check(self.lib.nss_diag_apply_f64(d.shape[0], d.data_ptr(), alpha, x.data_ptr(), beta,
+                                                y.data_ptr(), self.stream))
+
+    def bjac_create(self, csr_handle, idx):
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        bs, nb = idx.shape
+        out = C.c_void_p()
+        self._check(self.lib.nss_bjac_create(csr_handle.ptr, bs, nb, idx.ctypes.data, C.byref(out)))
+        return _BjacHandle(self, out, bs, nb, csr_handle.m)
+
+    def bjac_apply(self, h, alpha, x, beta, y):
+        if x.shape[0] != h.n or y.shape[0] != h.n:
+            raise ValueError("bjac_apply shape mismatch")
+        self._check(self.lib.nss_bjac_apply_f64(h.ptr, alpha, x.data_ptr(), beta, y.data_ptr(), self.stream))

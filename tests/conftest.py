@@ -39,3 +39,14 @@ def hip_engine():
 
 def golden_path(name):
     return os.path.join(GOLDEN, name + ".npz")
+
+
+def iteration_tolerance(d):
+    """Allowed |iterations - golden|.  SURVEY.md section 8c proposed +-max(2, 1 %); measured here,
+    the CPU oracle itself moves by up to ~2 % when only the summation order of its inner
+    products changes (296 -> 302 on stokes2d_n12_jacobi_bpcg1: the error functional is not
+    monotone near the tolerance).  Every fixture records that spread
+    (``iterations_perturbed``); the band used is max(3, 3 %, twice the recorded spread)."""
+    ref = int(d["iterations"])
+    spread = abs(ref - int(d["iterations_perturbed"])) if "iterations_perturbed" in d else 0
+    return max(3, int(0.03 * ref + 0.999), 2 * spread)

@@ -153,6 +153,7 @@ def main():
         si, sv = samples(x)
         save(tag + "_bpcg1", solver="bpcg1", tol=tol1, maxsteps=max1, k=k, lam_min=lams.min(), lam_max=lams.max(),
              errors=errors, iterations=len(errors) - 1, window=W, x_norm=np.linalg.norm(x),
+             iterations_perturbed=len(o2[2]) - 1,
              residual=np.linalg.norm(b - Ks @ x), b_norm=np.linalg.norm(b), sample_idx=si, sample_val=sv,
              warned="Warning" in out.getvalue(), **common)
 
@@ -178,6 +179,7 @@ def main():
         si, sv = samples(x)
         save(tag + "_bpcg2", solver="bpcg2", tol=tol2, maxsteps=max2, k=k2, lam_min=lams.min(), lam_max=lams.max(),
              history=hist, err0=err0, iterations=it, window=W, x_norm=np.linalg.norm(x),
+             iterations_perturbed=p2[0],
              residual=np.linalg.norm(b - Ks @ x), b_norm=np.linalg.norm(b), sample_idx=si, sample_val=sv,
              warned="Warning" in text, **common)
 
@@ -197,6 +199,7 @@ def main():
         W = stable_window(q1[2], q2[2])
         si, sv = samples(x)
         save(tag + "_minres", solver="minres", tol=tol3, maxsteps=max3, errors=errs, iterations=len(errs) - 1,
+             iterations_perturbed=len(q2[2]) - 1,
              window=W, x_norm=np.linalg.norm(x), residual=np.linalg.norm(b - Ks @ x), b_norm=np.linalg.norm(b),
              sample_idx=si, sample_val=sv, warned="Warning" in out.getvalue(), **common)
 

@@ -1,0 +1,343 @@
+"""Solver-level parity on the GPU: the three drop-in entry points (HIP engine, through the
+C ABI) against (a) the golden vectors produced by the reference's unmodified files and
+(b) the CPU oracle on the same assembled matrices.
+
+Tolerance contract: residual history within 1e-8 relative over the
+fixture's stable window W; iterations within conftest.iteration_tolerance; solution / true residual to
+1e-8 (relative to |x| resp. |b|, scaled by the tolerance the run was stopped at)."""
+
+import contextlib
+import glob
+import io
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, golden_path, iteration_tolerance
+from staggered_grid import diffusion_2d, mac_stokes
+
+pytestmark = pytest.mark.gpu
+
+CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "stokes*.npz")))
+
+
+class Form:
+    def __init__(self, mat):
+        self.mat, self.condense = mat, False
+
+
+def operands(d):
+    import hipla
+    s = mac_stokes(int(d["dim"]), int(d["n"]), float(d["nu"]))
+    f, g = s.rhs(int(d["seed"]))
+    A = hipla.SparseMatrix.from_scipy(s.A)
+    B = hipla.SparseMatrix.from_scipy(s.B)
+    preA = hipla.JacobiPreconditioner(A) if str(d["pre"]) == "jacobi" else hipla.BlockJacobi(A, s.line_blocks(3))
+    preS = hipla.DiagonalMatrix(1.0 / s.mass)
+    return s, f, g, A, B, preA, preS
+
+
+def check_history(h, ref, window, rtol=1e-8):
+    w = min(int(window), len(h), len(ref))
+    rel = np.abs(np.asarray(h[:w]) - ref[:w]) / np.abs(ref[:w])
+    assert rel.max() <= rtol, rel.max()
+
+
+def check_iterations(it, ref, d):
+    tol = iteration_tolerance(d)
+    assert abs(int(it) - int(ref)) <= tol, (it, ref, tol)
+
+
+def check_solution(x, s, f, g, d):
+    b = np.concatenate([f, g])
+    res = np.linalg.norm(b - s.saddle_matrix() @ x)
+    assert res <= 10 * max(float(d["residual"]), 1e-12 * float(d["b_norm"]))
+    assert abs(np.linalg.norm(x) - float(d["x_norm"])) <= 1e-6 * float(d["x_norm"])
+    np.testing.assert_allclose(x[d["sample_idx"]], d["sample_val"], rtol=0, atol=1e-6 * np.abs(x).max())
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_entry_points_match_goldens(hip_engine, case):
+    import hipla
+    from bramble_pasciak_cg import bramble_pasciak_cg
+    from minres import MinRes
+    from solvers.bramblepasciak_new import BramblePasciakCG
+    d = np.load(golden_path(case))
+    s, f, g, A, B, preA, preS = operands(d)
+    fv, gv = hipla.Vector.from_numpy(f), hipla.Vector.from_numpy(g)
+    solver = str(d["solver"])
+    out = io.StringIO()
+    if solver == "bpcg1":
+        with contextlib.redirect_stdout(out):
+            sol, errors = bramble_pasciak_cg(A, B, None, preA, preS, fv, gv, tolerance=float(d["tol"]),
+                                             max_steps=int(d["maxsteps"]), print_rates=False)
+        k = float(re.search(r"scale factor:\s+(\S+)", out.getvalue()).group(1))
+        assert abs(k - float(d["k"])) <= 1e-8 * k
+        check_history(errors, d["errors"], d["window"])
+        check_iterations(len(errors) - 1, d["iterations"], d)
+        x = sol.numpy()
+    elif solver == "bpcg2":
+        sol = hipla.BlockVector([hipla.Vector(s.n_u), hipla.Vector(s.n_p)])
+        with contextlib.redirect_stdout(out):
+            it, seconds = BramblePasciakCG(Form(A), Form(B), None, fv, gv, preA, preS, sol, tol=float(d["tol"]),
+                                           maxsteps=int(d["maxsteps"]), printrates=True)
+        text = out.getvalue()
+        hist = np.array([float(m) for m in re.findall(r"it =\s+\d+\s+err =\s+(\S+)", text)])
+        err0 = float(re.search(r"err0 (\S+)", text).group(1))
+        assert abs(err0 - float(d["err0"])) <= 1e-8 * err0
+        assert len(hist) == it + 1 and seconds > 0
+        check_history(hist, d["history"], d["window"])
+        check_iterations(it, d["iterations"], d)
+        x = sol.numpy()
+    else:
+        K = hipla.BlockMatrix([[A, B.T], [B, None]])
+        Cm = hipla.BlockMatrix([[preA, None], [None, preS]])
+        with contextlib.redirect_stdout(out):
+            u, errors = MinRes(mat=K, pre=Cm, rhs=hipla.BlockVector([fv, gv]), maxsteps=int(d["maxsteps"]),
+                               tol=float(d["tol"]), printrates=False)
+        check_history(errors, d["errors"], d["window"])
+        check_iterations(len(errors) - 1, d["iterations"], d)
+        assert ("Warning" in out.getvalue()) == bool(d["warned"])
+        x = u.numpy()
+    check_solution(x, s, f, g, d)
+
+
+def test_protocol_path_with_user_subclasses(hip_engine):
+    """User BaseMatrix subclasses (here: operators hiding the native types) force the
+    protocol path; it must agree with the native/fused path and the goldens."""
+    import hipla
+    from bramble_pasciak_cg import bramble_pasciak_cg
+    from minres import MinRes
+    from solvers.bramblepasciak_new import BramblePasciakCG
+
+    class Opaque(hipla.BaseMatrix):
+        def __init__(self, inner):
+            super().__init__()
+            self.inner = inner
+
+        def Mult(self, x, y):
+            y.data = self.inner * x
+
+        def MultTrans(self, x, y):
+            y.data = self.inner.T * x
+
+        def Height(self):
+            return self.inner.height
+
+        def Width(self):
+            return self.inner.width
+
+        def CreateTranspose(self):
+            return Opaque(self.inner.T)
+
+    d = np.load(golden_path("stokes2d_n12_jacobi_bpcg2"))
+    s, f, g, A, B, preA, preS = operands(d)
+    fv, gv = hipla.Vector.from_numpy(f), hipla.Vector.from_numpy(g)
+    sol = hipla.BlockVector([hipla.Vector(s.n_u), hipla.Vector(s.n_p)])
+    out = io.StringIO()
+    with contextlib.redirect_stdout(out):
+        it, _ = BramblePasciakCG(Form(A), Form(B), None, fv, gv, Opaque(preA), Opaque(preS), sol,
+                                 tol=float(d["tol"]), maxsteps=int(d["maxsteps"]))
+    hist = np.array([float(m) for m in re.findall(r"it =\s+\d+\s+err =\s+(\S+)", out.getvalue())])
+    check_history(hist, d["history"], d["window"])
+    check_iterations(it, d["iterations"], d)
+    check_solution(sol.numpy(), s, f, g, d)
+
+    d = np.load(golden_path("stokes2d_n12_jacobi_bpcg1"))
+    with contextlib.redirect_stdout(io.StringIO()):
+        x, errors = bramble_pasciak_cg(A, B, None, Opaque(preA), preS, fv, gv, tolerance=float(d["tol"]),
+                                       max_steps=int(d["maxsteps"]), print_rates=False)
+    check_history(errors, d["errors"], d["window"])
+    check_solution(x.numpy(), s, f, g, d)
+
+    d = np.load(golden_path("stokes2d_n12_jacobi_minres"))
+    K = hipla.BlockMatrix([[Opaque(A), B.T], [B, None]])
+    Cm = hipla.BlockMatrix([[preA, None], [None, Opaque(preS)]])
+    with contextlib.redirect_stdout(io.StringIO()):
+        u, errors = MinRes(mat=K, pre=Cm, rhs=hipla.BlockVector([fv, gv]), maxsteps=int(d["maxsteps"]),
+                           tol=float(d["tol"]), printrates=False)
+    check_history(errors, d["errors"], d["window"])
+    check_solution(u.numpy(), s, f, g, d)
+
+
+def test_quirks(hip_engine):
+    import hipla
+    from bramble_pasciak_cg import bramble_pasciak_cg
+    from minres import MinRes
+    from solvers.bramblepasciak_new import BramblePasciakCG
+    rng = np.random.default_rng(7)
+    d = np.load(golden_path("quirk_minres_absolute_guard"))
+    s, f, g, A, B, preA, preS = operands(d)
+    warm_u, warm_p = 0.1 * rng.standard_normal(s.n_u), 0.1 * rng.standard_normal(s.n_p)
+    K = hipla.BlockMatrix([[A, B.T], [B, None]])
+    Cm = hipla.BlockMatrix([[preA, None], [None, preS]])
+
+    out = io.StringIO()
+    with contextlib.redirect_stdout(out):
+        u, errors = MinRes(mat=K, pre=Cm, rhs=hipla.BlockVector([hipla.Vector.from_numpy(1e-3 * f),
+                                                                  hipla.Vector.from_numpy(g)]),
+                           maxsteps=int(d["maxsteps"]), tol=float(d["tol"]), printrates=False)
+    assert "Warning" in out.getvalue() and bool(d["warned"])       # absolute guard exit warns
+    check_iterations(len(errors) - 1, d["iterations"], d)
+
+    d = np.load(golden_path("quirk_minres_warm_start"))
+    sol = hipla.BlockVector([hipla.Vector.from_numpy(warm_u), hipla.Vector.from_numpy(warm_p)])
+    with contextlib.redirect_stdout(io.StringIO()):
+        u, errors = MinRes(mat=K, pre=Cm, rhs=hipla.BlockVector([hipla.Vector.from_numpy(f), hipla.Vector.from_numpy(g)]),
+                           sol=sol, initialize=False, maxsteps=int(d["maxsteps"]), tol=float(d["tol"]), printrates=False)
+    assert u is sol                                                 # caller storage updated in place
+    check_iterations(len(errors) - 1, d["iterations"], d)
+    np.testing.assert_allclose(errors[:60], d["errors"][:60], rtol=1e-8)
+    assert abs(np.linalg.norm(u.numpy()) - float(d["x_norm"])) < 1e-6 * float(d["x_norm"])
+
+    d = np.load(golden_path("quirk_bpcg2_zero_rhs"))
+    sol = hipla.BlockVector([hipla.Vector(s.n_u), hipla.Vector(s.n_p)])
+    with contextlib.redirect_stdout(io.StringIO()):
+        ret = BramblePasciakCG(Form(A), Form(B), None, hipla.Vector(s.n_u), hipla.Vector(s.n_p), preA, preS, sol)
+    assert ret is sol and bool(d["returned_solution_object"])       # bare vector, not a tuple
+
+    for name in ("quirk_bpcg2_warm_start", "quirk_bpcg2_abs_err"):
+        d = np.load(golden_path(name))
+        sol = hipla.BlockVector([hipla.Vector.from_numpy(warm_u), hipla.Vector.from_numpy(warm_p)])
+        out = io.StringIO()
+        with contextlib.redirect_stdout(out):
+            it, _ = BramblePasciakCG(Form(A), Form(B), None, hipla.Vector.from_numpy(f), hipla.Vector.from_numpy(g),
+                                     preA, preS, sol, tol=float(d["tol"]), maxsteps=int(d["maxsteps"]),
+                                     initialize=bool(d["initialize"]), rel_err=bool(d["rel_err"]))
+        hist = np.array([float(m) for m in re.findall(r"it =\s+\d+\s+err =\s+(\S+)", out.getvalue())])
+        check_iterations(it, d["iterations"], d)
+        np.testing.assert_allclose(hist[:40], d["history"][:40], rtol=1e-8)
+        assert abs(np.linalg.norm(sol.numpy()) - float(d["x_norm"])) < 1e-6 * float(d["x_norm"])
+
+    d = np.load(golden_path("quirk_bpcg1_warm_start_maxsteps"))
+    sol = hipla.BlockVector([hipla.Vector.from_numpy(warm_u), hipla.Vector.from_numpy(warm_p)])
+    out = io.StringIO()
+    with contextlib.redirect_stdout(out):
+        s2, errors = bramble_pasciak_cg(A, B, None, preA, preS, hipla.Vector.from_numpy(f), hipla.Vector.from_numpy(g),
+                                        solution=sol, tolerance=float(d["tol"]), max_steps=int(d["maxsteps"]),
+                                        print_rates=False)
+    assert s2 is sol and "Warning" in out.getvalue()
+    assert len(errors) == int(d["iterations"])
+    np.testing.assert_allclose(errors, d["errors"], rtol=1e-7)
+
+
+def test_cfg1_heat_plumbing(hip_engine):
+    """cfg1: SpMV + InnerProduct + AXPY on the 64x64 diffusion matrix -- Gram-Schmidt over a
+    Krylov basis and the Galerkin projection (orthonormalization.py:5-16, heat.py:109-118)
+    and a plain CG written against the protocol."""
+    import hipla
+    from math import sqrt
+    d = np.load(golden_path("cfg1_heat_plumbing"))
+    M = diffusion_2d(64)
+    Mh = hipla.SparseMatrix.from_scipy(M)
+    x0 = np.random.default_rng(int(d["seed"])).standard_normal(M.shape[0])
+    basis = [hipla.Vector.from_numpy(x0)]
+    for _ in range(4):
+        nxt = basis[-1].CreateVector()
+        nxt.data = Mh * basis[-1]
+        basis.append(nxt)
+    for _ in range(3):
+        for j in range(5):
+            for i in range(j):
+                basis[j].data -= hipla.InnerProduct(basis[i], basis[j]) / hipla.InnerProduct(basis[i], basis[i]) * basis[i]
+            basis[j].data = 1 / hipla.Norm(basis[j]) * basis[j]
+    gal = np.zeros((5, 5))
+    res = basis[0].CreateVector()
+    for c in range(5):
+        res.data = Mh * basis[c]
+        for r in range(5):
+            gal[r, c] = hipla.InnerProduct(basis[r], res)
+    # the monomial Krylov basis is ill-conditioned: compare the well-conditioned invariants
+    np.testing.assert_allclose(np.linalg.eigvalsh(gal), np.linalg.eigvalsh(d["galerkin"]), rtol=1e-7)
+    gram = np.array([[hipla.InnerProduct(a, b) for b in basis] for a in basis])
+    np.testing.assert_allclose(gram, np.eye(5), atol=1e-12)
+
+    b = hipla.Vector.from_numpy(x0)
+    x, r, p, q = (b.CreateVector() for _ in range(4))
+    x[:] = 0
+    r.data = b
+    p.data = r
+    rz = hipla.InnerProduct(r, r)
+    hist = [sqrt(rz)]
+    for _ in range(500):
+        q.data = Mh * p
+        alpha = rz / hipla.InnerProduct(p, q)
+        x.data += alpha * p
+        r.data -= alpha * q
+        rz_new = hipla.InnerProduct(r, r)
+        hist.append(sqrt(rz_new))
+        if hist[-1] < 1e-10 * hist[0]:
+            break
+        p.data = r + (rz_new / rz) * p
+        rz = rz_new
+    assert len(hist) - 1 == int(d["cg_iterations"])
+    np.testing.assert_allclose(hist, d["cg_history"], rtol=1e-8)
+    assert abs(np.linalg.norm(x.numpy()) - float(d["cg_x_norm"])) < 1e-9 * float(d["cg_x_norm"])
+
+
+def test_fused_bpcg2_is_selected_and_agrees_with_protocol_path(hip_engine):
+    """Native operands must take the device-resident loop (nss_bpcg2_*); forcing the protocol
+    path on the same operands has to give the same history inside the stable window."""
+    import hipla
+    from hipla import fused
+    from solvers.bramblepasciak_new import BpcgSession, BramblePasciakCG
+    for case in ("stokes3d_n10_bjac_bpcg2", "stokes2d_n24_jacobi_bpcg2"):
+        d = np.load(golden_path(case))
+        s, f, g, A, B, preA, preS = operands(d)
+        results = {}
+        for mode in ("fused", "protocol"):
+            fused.ENABLED = mode == "fused"
+            try:
+                sol = hipla.BlockVector([hipla.Vector(s.n_u), hipla.Vector(s.n_p)])
+                with contextlib.redirect_stdout(io.StringIO()):
+                    ses = BpcgSession(Form(A), Form(B), None, hipla.Vector.from_numpy(f), hipla.Vector.from_numpy(g),
+                                      preA, preS, sol=sol)
+                assert (ses.fused is not None) == (mode == "fused")
+                out = io.StringIO()
+                sol = hipla.BlockVector([hipla.Vector(s.n_u), hipla.Vector(s.n_p)])
+                with contextlib.redirect_stdout(out):
+                    it, _ = BramblePasciakCG(Form(A), Form(B), None, hipla.Vector.from_numpy(f),
+                                             hipla.Vector.from_numpy(g), preA, preS, sol, tol=float(d["tol"]),
+                                             maxsteps=int(d["maxsteps"]))
+                hist = np.array([float(m) for m in re.findall(r"it =\s+\d+\s+err =\s+(\S+)", out.getvalue())])
+                results[mode] = (it, hist, sol.numpy())
+            finally:
+                fused.ENABLED = True
+        w = int(d["window"])
+        np.testing.assert_allclose(results["fused"][1][:w], results["protocol"][1][:w], rtol=1e-8)
+        check_iterations(results["fused"][0], results["protocol"][0], d)
+        xf, xp = results["fused"][2], results["protocol"][2]
+        assert np.linalg.norm(xf - xp) <= 1e-6 * np.linalg.norm(xp)
+
+
+def test_fused_bpcg2_frozen_at_break_and_maxsteps_warning(hip_engine):
+    """The done flag freezes the state at the reference's `break`: polling late (large chunks) or
+    early (chunks of 1) must return the same iteration index and the same solution bits."""
+    import hipla
+    from solvers.bramblepasciak_new import BpcgSession
+    d = np.load(golden_path("stokes3d_n6_jacobi_bpcg2"))
+    s, f, g, A, B, preA, preS = operands(d)
+    outs = []
+    for chunk in (1, 7, 1000):
+        sol = hipla.BlockVector([hipla.Vector(s.n_u), hipla.Vector(s.n_p)])
+        with contextlib.redirect_stdout(io.StringIO()):
+            ses = BpcgSession(Form(A), Form(B), None, hipla.Vector.from_numpy(f), hipla.Vector.from_numpy(g),
+                              preA, preS, sol=sol)
+        ses.first_direction()
+        it, hist, conv = ses.fused.run(ses.wdn, ses.err0, 1e-8, True, 2000, poll_every=chunk)
+        assert conv
+        outs.append((it, hist.copy(), sol.numpy()))
+    for it, hist, x in outs[1:]:
+        assert it == outs[0][0]
+        np.testing.assert_array_equal(hist, outs[0][1])
+        np.testing.assert_array_equal(x, outs[0][2])
+    # not converging within maxsteps: it = maxsteps-1 and the warning is printed
+    from solvers.bramblepasciak_new import BramblePasciakCG
+    sol = hipla.BlockVector([hipla.Vector(s.n_u), hipla.Vector(s.n_p)])
+    out = io.StringIO()
+    with contextlib.redirect_stdout(out):
+        it, _ = BramblePasciakCG(Form(A), Form(B), None, hipla.Vector.from_numpy(f), hipla.Vector.from_numpy(g),
+                                 preA, preS, sol, tol=1e-30, maxsteps=9)
+    assert it == 8 and "Warning: BPCG did not converge" in out.getvalue()
