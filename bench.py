@@ -32,7 +32,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--n", type=int, default=136, help="MAC grid cells per direction (136 -> 1.0e7 DoF)")
+    ap.add_argument("--grid", dest="n", type=int, default=136, help="MAC grid cells per direction (136 -> 1.0e7 DoF)")
     ap.add_argument("--dim", type=int, default=3)
     ap.add_argument("--nu", type=float, default=0.01, help="1/Re")
     ap.add_argument("--pre", default="bjac3", choices=["bjac3", "jacobi"])
@@ -70,8 +70,15 @@ def main():
     import torch.distributed as dist
 
     if world > 1:
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # NSS_DIST_BACKEND=gloo lets several ranks share one GPU for rehearsals (RCCL refuses
+        # that); the driver's runs use the default: one rank per GPU over RCCL / xGMI.
+        backend = os.environ.get("NSS_DIST_BACKEND", "nccl")
+        device = local_rank % max(1, torch.cuda.device_count())
+        torch.cuda.set_device(device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend)
     if args.gpus != world and rank == 0:
         print("note: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
 
@@ -79,8 +86,10 @@ def main():
     from solvers.bramblepasciak_new import BpcgSession
     from staggered_grid import mac_stokes
 
+    import contextlib
     eng = hipla.get_engine()
     info = eng.device_info()
+    quiet = contextlib.redirect_stdout(sys.stderr)      # stdout carries the ONE JSON line only
     K, W = args.steps, args.warmup
     total_its = W + K
 
@@ -133,8 +142,9 @@ def main():
     preM = hipla.DiagonalMatrix(1.0 / sysm.mass)
     sol = hipla.BlockVector([hipla.Vector(sysm.n_u), hipla.Vector(sysm.n_p)])
     t_setup = time.perf_counter()
-    ses = BpcgSession(Form(A), Form(B), None, hipla.Vector.from_numpy(f), hipla.Vector.from_numpy(g),
-                      preA, preM, sol=sol, initialize=True)
+    with quiet:
+        ses = BpcgSession(Form(A), Form(B), None, hipla.Vector.from_numpy(f), hipla.Vector.from_numpy(g),
+                          preA, preM, sol=sol, initialize=True)
     loop = ses.fused
     if loop is None:
         raise RuntimeError("fused BPCG loop unavailable for native operands")

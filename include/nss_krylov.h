@@ -63,6 +63,11 @@ NSS_API int nss_dot_f64(int32_t npairs, const int64_t* h_n, const double* const*
 /* same, then waits and returns the value on the host */
 NSS_API int nss_dot_host_f64(int32_t npairs, const int64_t* h_n, const double* const* h_x,
                              const double* const* h_y, double* h_result, nss_stream_t stream);
+/* dst[i] = src[idx[i]], i < n: packs the entries a neighbouring slab needs into a contiguous
+ * send buffer (multi-GPU halo exchange; no reference counterpart -- the
+ * reference is single-process).  idx is a DEVICE int32 array. */
+NSS_API int nss_gather_f64(int64_t n, const int32_t* idx, const double* src, double* dst,
+                           nss_stream_t stream);
 /* z = x + a*y : STREAM-triad, the roofline denominator measured in the same run
  *  */
 NSS_API int nss_stream_triad_f64(int64_t n, double a, const double* x, const double* y,
@@ -143,6 +148,10 @@ NSS_API int nss_bpcg2_workspace(const nss_bpcg2_t* s, int64_t* partials_a, int64
 /* one phase of iteration `it` (row-partitioned runs all-reduce scal[as_s] / scal[wdn] and exchange
  * halos between phases) */
 NSS_API int nss_bpcg2_phase(const nss_bpcg2_t* s, int32_t which, int32_t it, nss_stream_t stream);
+/* phases first..last (inclusive, in enum order) of iteration `it` in one call: the stretch
+ * between two communication points of the row-partitioned loop */
+NSS_API int nss_bpcg2_phases(const nss_bpcg2_t* s, int32_t first, int32_t last, int32_t it,
+                             nss_stream_t stream);
 /* enqueue iterations [it_begin, it_end) back to back (single GPU): no host synchronisation */
 NSS_API int nss_bpcg2_iterate(const nss_bpcg2_t* s, int32_t it_begin, int32_t it_end, nss_stream_t stream);
 /* wait for the stream and read ctrl: done flag, iteration at which the stop test fired, last

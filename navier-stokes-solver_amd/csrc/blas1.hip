@@ -135,6 +135,12 @@ __global__ __launch_bounds__(kBlock) void diag_kernel(int64_t n, const double* _
   }
 }
 
+__global__ __launch_bounds__(kBlock) void gather_kernel(int64_t n, const int32_t* __restrict__ idx,
+                                                         const double* __restrict__ src, double* __restrict__ dst) {
+  const int64_t stride = int64_t(gridDim.x) * kBlock;
+  for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride) dst[i] = src[idx[i]];
+}
+
 // ---- dot: stage 1 = per-workgroup partial sums of up to 4 vector pairs ----------------
 struct DotArgs {
   const double* x[4];
@@ -307,6 +313,15 @@ int nss_dot_host_f64(int32_t npairs, const int64_t* h_n, const double* const* h_
     NSS_HIP(hipMemcpyAsync(s.host, s.result, sizeof(double), hipMemcpyDeviceToHost, st));
     NSS_HIP(hipStreamSynchronize(st));
     *h_result = s.host[0];
+  });
+}
+
+int nss_gather_f64(int64_t n, const int32_t* idx, const double* src, double* dst, nss_stream_t stream) {
+  return guarded([&] {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(gather_kernel, dim3(stream_grid(n, kBlock)), dim3(kBlock), 0, as_stream(stream), n, idx, src,
+                       dst);
+    NSS_CHECK_LAUNCH();
   });
 }
 

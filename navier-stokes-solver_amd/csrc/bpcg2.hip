@@ -271,6 +271,14 @@ int nss_bpcg2_phase(const nss_bpcg2_t* s, int32_t which, int32_t it, nss_stream_
   });
 }
 
+int nss_bpcg2_phases(const nss_bpcg2_t* s, int32_t first, int32_t last, int32_t it, nss_stream_t stream) {
+  return guarded([&] {
+    check_state(s);
+    NSS_REQUIRE(first >= NSS_BPCG2_K1 && last <= NSS_BPCG2_K5 && first <= last, "bpcg2_phases: bad phase range");
+    for (int ph = first; ph <= last; ++ph) phase(*s, ph, it, as_stream(stream));
+  });
+}
+
 int nss_bpcg2_iterate(const nss_bpcg2_t* s, int32_t it_begin, int32_t it_end, nss_stream_t stream) {
   return guarded([&] {
     check_state(s);

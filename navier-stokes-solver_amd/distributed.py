@@ -1,0 +1,425 @@
+"""Row-partitioned multi-GPU execution of the Stokes solve path.
+
+One process per GPU.  Rank r owns a contiguous *slab* of rows: the velocity rows of
+``A`` and ``B^T``, the pressure rows of ``B`` and the matching slices of every vector;
+block-Jacobi blocks and the lumped mass are partition-local.  Two kinds of
+communication, both over ``torch.distributed`` (backend "nccl" = RCCL over xGMI on the
+GPU box, "gloo" in the CPU tests):
+
+* inner products: local deterministic reduction on the device, then ``all_reduce(SUM)`` of
+  one double (2 per BPCG iteration, sequentially dependent);
+* SpMV operands: *neighbour halo exchange*, not an all-gather -- a slab boundary is one
+  grid plane (about 3 n^2 doubles for A's operand, n^2 for B's and B^T's), three orders of
+  magnitude less than the full vector.  Halo entries are appended behind the owned entries
+  of the operand (``[owned | from rank 0 | from rank 1 | ...]``), the local CSR blocks are
+  renumbered accordingly once at set-up, and one ``all_to_all_single`` with split sizes
+  fills the tail directly (zero-copy receive).
+
+The reference is single-process (no MPI / NCCL anywhere); this layer
+is new.  Everything here is host logic over the engine interface, so the same code runs
+on the numpy checker engine in the gloo tests."""
+
+import numpy as np
+import scipy.sparse as sp
+
+from hipla import BaseMatrix, BlockJacobi, DiagonalMatrix, InnerProduct, SparseMatrix, Vector
+from hipla.engine import get_engine
+
+
+# --------------------------------------------------------------------------------------
+# partition + halo bookkeeping (pure numpy)
+# --------------------------------------------------------------------------------------
+def even_offsets(n, nranks):
+    """Fallback partition for matrices without a slab hint: equal row counts."""
+    return np.round(np.arange(nranks + 1) * n / nranks).astype(np.int64)
+
+
+def localize_rows(mat, row_range, col_offsets, rank):
+    """Cut rows [r0, r1) out of the global CSR `mat` and renumber its columns for `rank`:
+    owned columns -> [0, n_owned), ghost columns -> n_owned + position in the ghost list,
+    which is sorted by (owner rank, global index).  Returns (local csr, ghost global ids)."""
+    r0, r1 = int(row_range[0]), int(row_range[1])
+    c0, c1 = int(col_offsets[rank]), int(col_offsets[rank + 1])
+    loc = sp.csr_matrix(mat[r0:r1, :])
+    loc.sort_indices()
+    cols = loc.indices.astype(np.int64)
+    owned = (cols >= c0) & (cols < c1)
+    ghosts = np.unique(cols[~owned])            # global ids ascending == sorted by owner, then id
+    new = np.empty_like(cols)
+    new[owned] = cols[owned] - c0
+    new[~owned] = (c1 - c0) + np.searchsorted(ghosts, cols[~owned])
+    out = sp.csr_matrix((loc.data, new.astype(np.int32), loc.indptr), shape=(r1 - r0, (c1 - c0) + ghosts.size))
+    out.sort_indices()
+    return out, ghosts
+
+
+class HaloPlan:
+    """Who sends what to whom for one operand layout."""
+
+    def __init__(self, rank, nranks, n_owned, ghosts, col_offsets):
+        self.rank, self.nranks, self.n_owned = rank, nranks, int(n_owned)
+        self.ghosts = np.asarray(ghosts, dtype=np.int64)
+        self.n_ghost = int(self.ghosts.size)
+        self.col_offsets = np.asarray(col_offsets, dtype=np.int64)
+        owner = np.searchsorted(self.col_offsets, self.ghosts, side="right") - 1
+        self.recv_counts = np.bincount(owner, minlength=nranks).astype(np.int64)
+        self.send_counts = np.zeros(nranks, dtype=np.int64)
+        self.send_idx = np.zeros(0, dtype=np.int32)
+
+    def requests(self):
+        """ghost ids wanted from each owner (what travels in the set-up all-gather)."""
+        cuts = np.concatenate([[0], np.cumsum(self.recv_counts)])
+        return [self.ghosts[cuts[q]:cuts[q + 1]] for q in range(self.nranks)]
+
+    def finalize(self, wanted_from_me):
+        """`wanted_from_me[q]` = global ids rank q needs from this rank."""
+        c0 = int(self.col_offsets[self.rank])
+        c1 = int(self.col_offsets[self.rank + 1])
+        idx = []
+        for q, ids in enumerate(wanted_from_me):
+            ids = np.asarray(ids, dtype=np.int64)
+            if ids.size and (ids.min() < c0 or ids.max() >= c1):
+                raise ValueError("rank %d asked rank %d for entries it does not own" % (q, self.rank))
+            self.send_counts[q] = ids.size
+            idx.append((ids - c0).astype(np.int32))
+        self.send_idx = np.concatenate(idx) if idx else np.zeros(0, dtype=np.int32)
+        return self
+
+
+# --------------------------------------------------------------------------------------
+# communicators
+# --------------------------------------------------------------------------------------
+class TorchComm:
+    """torch.distributed (RCCL on GPUs, gloo on CPUs).  Buffers are engine buffers: torch
+    tensors for the HIP engine, numpy arrays (shared memory with torch) for the checker."""
+
+    def __init__(self, dist, engine=None):
+        import torch
+        self.dist, self.torch = dist, torch
+        self.engine = engine if engine is not None else get_engine()
+        self.rank, self.size = dist.get_rank(), dist.get_world_size()
+        # gloo cannot move device buffers: stage them through the host (used when several
+        # ranks share one GPU in the tests; the GPU box runs RCCL, which takes them directly)
+        self.stage = dist.get_backend() == "gloo"
+
+    def _t(self, buf):
+        return buf if isinstance(buf, self.torch.Tensor) else self.torch.from_numpy(buf)
+
+    def allreduce_sum(self, buf):
+        if self.size == 1:
+            return
+        t = self._t(buf)
+        if self.stage and t.is_cuda:
+            h = t.cpu()
+            self.dist.all_reduce(h, op=self.dist.ReduceOp.SUM)
+            t.copy_(h)
+        else:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+
+    def allreduce_scalar(self, value):
+        if self.size == 1:
+            return float(value)
+        t = self.torch.tensor([float(value)], dtype=self.torch.float64, device=self._scalar_device())
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return float(t.item())
+
+    def _scalar_device(self):
+        return "cpu" if self.stage else getattr(self.engine, "device", "cpu")
+
+    def gather_objects(self, obj):
+        out = [None] * self.size
+        self.dist.all_gather_object(out, obj)
+        return out
+
+    def gather_requests(self, mine, compute_for_rank):
+        """requests[q][p] = global ids rank q wants from rank p (set-up only)."""
+        return self.gather_objects(mine)
+
+    def exchange(self, plan, sendbuf, ext):
+        """Fill ext[n_owned:] with the ghost entries; `sendbuf` already holds the packed
+        entries for every destination (ordered by destination rank)."""
+        if self.size == 1 or (plan.n_ghost == 0 and sendbuf.shape[0] == 0):
+            return
+        tail, send = self._t(ext)[plan.n_owned:], self._t(sendbuf)
+        outs, ins = [int(c) for c in plan.recv_counts], [int(c) for c in plan.send_counts]
+        if self.stage and tail.is_cuda:
+            h = self.torch.empty(tail.shape, dtype=tail.dtype)
+            self.dist.all_to_all_single(h, send.cpu(), output_split_sizes=outs, input_split_sizes=ins)
+            tail.copy_(h)
+        else:
+            self.dist.all_to_all_single(tail, send, output_split_sizes=outs, input_split_sizes=ins)
+
+
+# --------------------------------------------------------------------------------------
+# distributed operands
+# --------------------------------------------------------------------------------------
+class HaloVector(Vector):
+    """Owned entries of an SpMV operand; ``ext`` is the underlying buffer
+    ``[owned | ghosts]`` the local CSR block indexes into."""
+
+    def __init__(self, dmat):
+        eng = dmat.engine
+        self.ext = eng.zeros(dmat.plan.n_owned + dmat.plan.n_ghost)
+        super().__init__(buf=eng.view(self.ext, 0, dmat.plan.n_owned), engine=eng)
+        self.plan = dmat.plan
+
+
+class DistSparseMatrix(BaseMatrix):
+    """Rows [row_offsets[r], row_offsets[r+1]) of a global CSR matrix on rank r.
+
+    ``Mult`` / ``MultAdd`` = halo exchange of the operand + local CSR SpMV.  Operands that
+    are `HaloVector`s of this matrix are exchanged in place; any other vector is first
+    copied into the matrix's private operand buffer."""
+
+    def __init__(self, global_csr, row_offsets, col_offsets, comm, engine=None):
+        super().__init__()
+        self.comm = comm
+        self.engine = engine if engine is not None else get_engine()
+        r = comm.rank
+        self.row_offsets = np.asarray(row_offsets, dtype=np.int64)
+        self.col_offsets = np.asarray(col_offsets, dtype=np.int64)
+        self.row_offset = int(self.row_offsets[r])
+        self.n_rows = int(self.row_offsets[r + 1] - self.row_offsets[r])
+        self.n_cols_owned = int(self.col_offsets[r + 1] - self.col_offsets[r])
+        self.global_shape = global_csr.shape
+        loc, ghosts = localize_rows(global_csr, (self.row_offsets[r], self.row_offsets[r + 1]), self.col_offsets, r)
+        self.local_scipy = loc
+        self.local = SparseMatrix.from_scipy(loc, engine=self.engine)
+        self.plan = HaloPlan(r, comm.size, self.n_cols_owned, ghosts, self.col_offsets)
+        def requests_of(q):
+            _, gq = localize_rows(global_csr, (self.row_offsets[q], self.row_offsets[q + 1]), self.col_offsets, q)
+            return HaloPlan(q, comm.size, self.col_offsets[q + 1] - self.col_offsets[q], gq, self.col_offsets).requests()
+
+        wanted = comm.gather_requests(self.plan.requests(), requests_of)   # wanted[q][p] = ids q wants from p
+        self.plan.finalize([wanted[q][r] for q in range(comm.size)])
+        self._send_idx = self.engine.index_buffer(self.plan.send_idx)
+        self._sendbuf = self.engine.zeros(max(1, int(self.plan.send_idx.size)))[: int(self.plan.send_idx.size)]
+        self._private = None
+        self._transpose = None
+
+    # shapes are the LOCAL ones: vectors of this rank have the owned sizes
+    def Height(self):
+        return self.n_rows
+
+    def Width(self):
+        return self.n_cols_owned
+
+    def CreateColVector(self):
+        return Vector(self.n_rows, engine=self.engine)
+
+    def CreateRowVector(self):
+        return Vector(self.n_cols_owned, engine=self.engine)
+
+    def operand(self):
+        return HaloVector(self)
+
+    def pack(self, hv):
+        """Gather the owned entries other ranks need into the contiguous send buffer."""
+        if self.plan.send_idx.size:
+            self.engine.gather(self._send_idx, hv.buf, self._sendbuf)
+        return self._sendbuf
+
+    def exchange(self, hv):
+        """Make the ghost tail of `hv.ext` current (pack -> all_to_all -> tail)."""
+        if self.comm.size == 1:
+            return
+        self.comm.exchange(self.plan, self.pack(hv), hv.ext)
+
+    def _operand_for(self, x):
+        if isinstance(x, HaloVector) and x.plan is self.plan:
+            return x
+        if self._private is None:
+            self._private = HaloVector(self)
+        self.engine.copy(x.buf, self._private.buf)
+        return self._private
+
+    def Mult(self, x, y):
+        hv = self._operand_for(x)
+        self.exchange(hv)
+        self.engine.csr_spmv(self.local.handle, 1.0, hv.ext, 0.0, y.buf)
+
+    def MultAdd(self, s, x, y):
+        hv = self._operand_for(x)
+        self.exchange(hv)
+        self.engine.csr_spmv(self.local.handle, float(s), hv.ext, 1.0, y.buf)
+
+    def MultTrans(self, x, y):
+        self.CreateTranspose().Mult(x, y)
+
+    def MultTransAdd(self, s, x, y):
+        self.CreateTranspose().MultAdd(s, x, y)
+
+    def attach_transpose(self, t):
+        self._transpose, t._transpose = t, self
+
+    def CreateTranspose(self):
+        if self._transpose is None:
+            raise RuntimeError("distributed transpose must be attached at set-up (attach_transpose)")
+        return self._transpose
+
+    @property
+    def T(self):
+        return self.CreateTranspose()
+
+
+class DistInner:
+    """Global inner product: local deterministic dot + all_reduce."""
+
+    def __init__(self, comm):
+        self.comm = comm
+
+    def __call__(self, a, b):
+        return self.comm.allreduce_scalar(InnerProduct(a, b))
+
+
+class Form:
+    def __init__(self, mat):
+        self.mat, self.condense = mat, False
+
+
+class DistributedStokes:
+    """The operands of the Stokes solve on this rank: A, B, B^T as `DistSparseMatrix`,
+    block-Jacobi / Jacobi preA and lumped-mass preM restricted to the slab."""
+
+    def __init__(self, sysm, blocks, comm, engine=None, partition=None):
+        self.comm = comm
+        self.engine = engine if engine is not None else get_engine()
+        r, size = comm.rank, comm.size
+        vel, prs = partition if partition is not None else sysm.partition(size)
+        self.vel, self.prs = np.asarray(vel, dtype=np.int64), np.asarray(prs, dtype=np.int64)
+        self.n_u, self.n_p = int(self.vel[r + 1] - self.vel[r]), int(self.prs[r + 1] - self.prs[r])
+        BT = sysm.B.T.tocsr()
+        BT.sort_indices()
+        self.A = DistSparseMatrix(sysm.A, self.vel, self.vel, comm, self.engine)
+        self.B = DistSparseMatrix(sysm.B, self.prs, self.vel, comm, self.engine)
+        self.BT = DistSparseMatrix(BT, self.vel, self.prs, comm, self.engine)
+        self.B.attach_transpose(self.BT)
+        v0, v1 = int(self.vel[r]), int(self.vel[r + 1])
+        # block-Jacobi on the diagonal block of the slab (blocks never straddle slabs)
+        a_diag = sp.csr_matrix(sysm.A[v0:v1, v0:v1])
+        a_diag.sort_indices()
+        self.A_diag = SparseMatrix.from_scipy(a_diag, engine=self.engine)
+        if blocks is not None:
+            blocks = np.asarray(blocks, dtype=np.int64)
+            live = blocks >= 0
+            first = np.where(live, blocks, np.int64(1) << 62).min(axis=0)
+            last = blocks.max(axis=0)
+            mine = (first >= v0) & (first < v1)
+            if np.any(mine & ~(last < v1)):
+                raise ValueError("a block-Jacobi block straddles the slab boundary")
+            loc = blocks[:, mine]
+            loc = np.where(loc >= 0, loc - v0, -1).astype(np.int32)
+            self.preA = BlockJacobi(self.A_diag, np.ascontiguousarray(loc))
+        else:
+            from hipla import JacobiPreconditioner
+            self.preA = JacobiPreconditioner(self.A_diag)
+        p0, p1 = int(self.prs[r]), int(self.prs[r + 1])
+        self.preM = DiagonalMatrix(1.0 / sysm.mass[p0:p1], engine=self.engine)
+        self.inner = DistInner(comm)
+
+    def local_slices(self):
+        r = self.comm.rank
+        return slice(int(self.vel[r]), int(self.vel[r + 1])), slice(int(self.prs[r]), int(self.prs[r + 1]))
+
+    def halo_doubles(self):
+        return {"A_operand": self.A.plan.n_ghost, "B_operand": self.B.plan.n_ghost,
+                "BT_operand": self.BT.plan.n_ghost}
+
+
+class DistributedBpcg2:
+    """Row-partitioned Bramble-Pasciak CG (v2) on this rank: set-up through the operator
+    protocol with distributed operands (halo + all_reduce inside ``Mult`` / inner product),
+    iteration through the fused device phases (``nss_bpcg2_phase``) with the three halo
+    exchanges and two all-reduces in between."""
+
+    # (kind, argument): device phases between two communication points go down in one C call
+    SCHEDULE = (("halo", "s1"), ("phases", ("K1", "K1")), ("halo", "t1"), ("phases", ("K2", "K2")),
+                ("halo", "t4"), ("phases", ("K3", "SUM1")), ("allreduce", 1), ("phases", ("ALPHA", "SUM2")),
+                ("allreduce", 2), ("phases", ("BETA", "K5")))
+
+    def __init__(self, sysm, f, g, blocks, dist, engine=None, comm=None, quiet=True):
+        import contextlib
+        import io
+        from hipla import BlockVector
+        from solvers.bramblepasciak_new import BpcgSession
+        self.engine = engine if engine is not None else get_engine()
+        self.comm = comm if comm is not None else TorchComm(dist, self.engine)
+        ops = self.ops = DistributedStokes(sysm, blocks, self.comm, self.engine)
+        us, ps = ops.local_slices()
+        fv = Vector.from_numpy(np.asarray(f)[us], engine=self.engine)
+        gv = Vector.from_numpy(np.asarray(g)[ps], engine=self.engine)
+        self.sol = BlockVector([Vector(ops.n_u, engine=self.engine), Vector(ops.n_p, engine=self.engine)])
+        # operands of the three SpMVs of the loop live in halo-extended buffers
+        self.t1, self.t4, self.s1 = ops.A.operand(), ops.B.operand(), ops.BT.operand()
+        sink = io.StringIO() if quiet or self.comm.rank != 0 else None
+        with (contextlib.redirect_stdout(sink) if sink is not None else contextlib.nullcontext()):
+            ses = BpcgSession(Form(ops.A), Form(ops.B), None, fv, gv, ops.preA, ops.preM, sol=self.sol,
+                              initialize=True, inner=ops.inner,
+                              workspace=dict(t1=self.t1, t4=self.t4, s1=self.s1))
+        self.k, self.wdn, self.err0 = ses.k, ses.wdn, ses.err0
+        self.first_direction = ses.first_direction
+        self._attach(dict(u0=ses.u[0], u1=ses.u[1], d0=ses.d[0], d1=ses.d[1], w0=ses.w[0], w1=ses.w[1],
+                          s0=ses.s[0], s1=self.s1, z0=ses.z[0], q=ses.As0, t0=ses.t0, t1=self.t1, t2=ses.t2,
+                          t3=ses.t3, t4=self.t4))
+        self.ses = ses
+
+    @classmethod
+    def from_state(cls, ops, k, wdn, err0, vecs):
+        """Attach the fused loop to an already prepared state (`vecs`: the owned slices of
+        u, d, w, s, z0, q = A s0; t1 / t4 / s1 must be `HaloVector`s of ops.A / ops.B / ops.BT)."""
+        self = cls.__new__(cls)
+        self.engine, self.comm, self.ops = ops.engine, ops.comm, ops
+        self.k, self.wdn, self.err0 = k, wdn, err0
+        self.t1, self.t4, self.s1 = vecs["t1"], vecs["t4"], vecs["s1"]
+        self.first_direction = lambda: None
+        self._attach(vecs)
+        return self
+
+    def _attach(self, vecs):
+        from hipla.fused import Bpcg2Loop
+        ops = self.ops
+        self.vecs = vecs
+        self.loop = Bpcg2Loop.try_create(ops.A.local, ops.B.local, ops.BT.local, ops.preA, self.k, ops.preM, vecs,
+                                         distributed=True)
+        if self.loop is None:
+            raise RuntimeError("fused distributed BPCG loop needs the HIP engine and native operands")
+        self.halo = {"s1": (ops.BT, self.s1), "t1": (ops.A, self.t1), "t4": (ops.B, self.t4)}
+
+    def start(self, tol, maxsteps, rel_err=True):
+        self.first_direction()
+        self.loop.start(self.wdn, self.err0, tol, rel_err, maxsteps)
+
+    def iterate(self, it_begin, it_end):
+        loop, comm = self.loop, self.comm
+        for it in range(it_begin, it_end):
+            for kind, what in self.SCHEDULE:
+                if kind == "phases":
+                    loop.phases(what[0], what[1], it)
+                elif kind == "halo":
+                    mat, hv = self.halo[what]
+                    mat.exchange(hv)
+                else:
+                    comm.allreduce_sum(loop.scal[what:what + 1])
+
+    def poll(self):
+        return self.loop.poll()
+
+    def history(self, upto):
+        return self.loop.history(upto)
+
+    def halo_summary(self):
+        return self.ops.halo_doubles()
+
+    def solve(self, tol=1e-10, maxsteps=100000, poll_every=16):
+        """Full solve; returns (it, converged).  Every rank takes the same decision because
+        the all-reduced scalars are bit-identical on all ranks."""
+        self.start(tol, maxsteps)
+        it, done, it_final = 0, False, 0
+        while it < maxsteps:
+            end = min(maxsteps, it + poll_every)
+            self.iterate(it, end)
+            it = end
+            done, it_final, _ = self.poll()
+            if done:
+                break
+        return (it_final if done else maxsteps - 1), done

@@ -84,15 +84,17 @@ def lanczos_ritz(mat, pre, start, tol=1e-10, maxsteps=2000, check_every=5, dot=I
     return ritz
 
 
-def EigenValues_Preconditioner(mat, pre, tol=1e-10):
+def EigenValues_Preconditioner(mat, pre, tol=1e-10, inner=InnerProduct):
     """Returns the Ritz values (ascending numpy array) of ``pre * mat``; callers use
-    ``min``/``max`` (bramble_pasciak_cg.py:71,74)."""
+    ``min``/``max`` (bramble_pasciak_cg.py:71,74).  ``inner`` is the (global) inner product;
+    a row-partitioned operator exposes ``row_offset`` so that every rank fills its slice of
+    the same global start vector."""
     start = mat.CreateColVector()
+    off = int(getattr(mat, "row_offset", 0))
     if isinstance(start, BlockVector):
-        off = 0
         for c in start.components:
             c.set_from(lanczos_start_values(off, len(c)))
             off += len(c)
     else:
-        start.set_from(lanczos_start_values(0, len(start)))
-    return lanczos_ritz(mat, pre, start, tol=tol)
+        start.set_from(lanczos_start_values(off, len(start)))
+    return lanczos_ritz(mat, pre, start, tol=tol, dot=inner)

@@ -67,14 +67,21 @@ class Bpcg2Loop:
     """Device-resident iteration of solvers/bramblepasciak_new.py:200-249."""
 
     @classmethod
-    def try_create(cls, matA, matB, matBT, preA_unscaled, k, preM, vecs):
+    def try_create(cls, matA, matB, matBT, preA_unscaled, k, preM, vecs, distributed=False):
+        """`distributed`: the matrices are the local row blocks of a partitioned run -- their
+        column spaces carry halo entries behind the owned ones and t1 / t4 / s1 are the owned
+        views of halo-extended buffers (same base pointer)."""
         if not (isinstance(matA, SparseMatrix) and isinstance(matB, SparseMatrix) and isinstance(matBT, SparseMatrix)):
             return None
         eng = matA.engine
         if not ENABLED or not _hip(eng):
             return None
         n_u, n_p = matA.height, matB.height
-        if matA.width != n_u or matB.width != n_u or matBT.height != n_u or matBT.width != n_p:
+        if matBT.height != n_u:
+            return None
+        if not distributed and (matA.width != n_u or matB.width != n_u or matBT.width != n_p):
+            return None
+        if distributed and (matA.width < n_u or matB.width < n_u or matBT.width < n_p):
             return None
         pm = native_diag(preM)
         pa_d, pa_b = native_diag(preA_unscaled), native_bjac(preA_unscaled)
@@ -136,6 +143,10 @@ class Bpcg2Loop:
 
     def phase(self, name, it):
         self.eng._check(self.lib.nss_bpcg2_phase(C.byref(self.state), PHASE[name], int(it), self.eng.stream))
+
+    def phases(self, first, last, it):
+        self.eng._check(self.lib.nss_bpcg2_phases(C.byref(self.state), PHASE[first], PHASE[last], int(it),
+                                                  self.eng.stream))
 
     def poll(self):
         """Drain the stream; returns (done, it_final, last_it)."""

@@ -39,6 +39,7 @@ def _signatures():
         "nss_dot_f64": (C.c_int, [i32, c_i64_p, C.POINTER(vp), C.POINTER(vp), vp, vp]),
         "nss_dot_host_f64": (C.c_int, [i32, c_i64_p, C.POINTER(vp), C.POINTER(vp), c_double_p, vp]),
         "nss_stream_triad_f64": (C.c_int, [i64, dbl, vp, vp, vp, vp]),
+        "nss_gather_f64": (C.c_int, [i64, vp, vp, vp, vp]),
         "nss_csr_create": (C.c_int, [i32, i32, i64, vp, vp, vp, C.POINTER(vp)]),
         "nss_csr_destroy": (C.c_int, [vp]),
         "nss_csr_spmv_f64": (C.c_int, [vp, dbl, vp, dbl, vp, vp]),
@@ -51,6 +52,7 @@ def _signatures():
         "nss_bjac_info": (C.c_int, [vp, c_i32_p, c_i32_p, c_i64_p, c_i64_p]),
         "nss_bpcg2_workspace": (C.c_int, [vp, c_i64_p, c_i64_p, c_i64_p]),
         "nss_bpcg2_phase": (C.c_int, [vp, i32, i32, vp]),
+        "nss_bpcg2_phases": (C.c_int, [vp, i32, i32, i32, vp]),
         "nss_bpcg2_iterate": (C.c_int, [vp, i32, i32, vp]),
         "nss_bpcg2_poll": (C.c_int, [vp, c_i32_p, c_i32_p, c_i32_p, vp]),
     }
@@ -218,6 +220,15 @@ class HipEngine:
             self._check(self.lib.nss_dot_host_f64(n, ns, xs, ys, C.byref(out), self.stream))
             total += out.value
         return total
+
+    def index_buffer(self, idx):
+        t = self.torch.from_numpy(np.ascontiguousarray(idx, dtype=np.int32))
+        return t.to(self.device)
+
+    def gather(self, idx, src, dst):
+        """dst[i] = src[idx[i]] (halo pack)."""
+        self._check(self.lib.nss_gather_f64(idx.shape[0], idx.data_ptr(), src.data_ptr(), dst.data_ptr(),
+                                            self.stream))
 
     def stream_triad(self, a, x, y, z):
         self._check(self.lib.nss_stream_triad_f64(x.shape[0], a, x.data_ptr(), y.data_ptr(), z.data_ptr(),

@@ -70,8 +70,14 @@ class BpcgSession:
     ``w``, search direction ``s`` and ``wdn = <w,d>``.  ``fused`` is the device-resident loop
     when the operands are native, else ``None``."""
 
-    def __init__(self, blfA, blfB, matC, f, g, preA_unscaled, preM, sol=None, initialize=True, k=None):
+    def __init__(self, blfA, blfB, matC, f, g, preA_unscaled, preM, sol=None, initialize=True, k=None,
+                 inner=InnerProduct, workspace=None):
+        """``inner`` is the inner product (a row-partitioned run passes the all-reducing one);
+        ``workspace`` may pre-allocate ``t1``, ``t4`` and ``s1`` (the SpMV operands of the loop)
+        in halo-extended buffers."""
         self.blfA = blfA
+        self.inner = inner
+        workspace = workspace or {}
         matA = self.matA = _CondensedA(blfA) if blfA.condense else blfA.mat
         matB = self.matB = blfB.mat
         self.preM = preM
@@ -81,7 +87,7 @@ class BpcgSession:
         if k is None:
             timer_prepev = Timer("BPCG-Preparation-EV")
             timer_prepev.Start()
-            lams = EigenValues_Preconditioner(mat=matA, pre=preA_unscaled, tol=1e-3)
+            lams = EigenValues_Preconditioner(mat=matA, pre=preA_unscaled, tol=1e-3, inner=inner)
             timer_prepev.Stop()
             k = 1. / min(lams) + 1e-3                   # :118
             print("condition", max(lams) / min(lams))
@@ -102,13 +108,15 @@ class BpcgSession:
             u[:] = 0.0
         d, w, v = rhs.CreateVector(), rhs.CreateVector(), rhs.CreateVector()
         z, z_old, s = rhs.CreateVector(), rhs.CreateVector(), rhs.CreateVector()
+        if "s1" in workspace:
+            s = BlockVector([s[0], workspace["s1"]])
         self.d, self.w, self.v, self.z, self.z_old, self.s = d, w, v, z, z_old, s
 
         t0 = self.t0 = blfA.mat.CreateColVector()
-        t1 = self.t1 = blfA.mat.CreateColVector()
+        t1 = self.t1 = workspace["t1"] if "t1" in workspace else blfA.mat.CreateColVector()
         t2 = self.t2 = blfA.mat.CreateColVector()
         t3 = self.t3 = matB.CreateColVector()
-        t4 = self.t4 = t1.CreateVector()
+        t4 = self.t4 = workspace["t4"] if "t4" in workspace else blfA.mat.CreateColVector()
         self.As0 = blfA.mat.CreateColVector()
         self.BTs1 = matB.CreateRowVector()
 
@@ -129,7 +137,7 @@ class BpcgSession:
         w[0].data = pr[0] - t1
         w[1].data = pr[1] - preM * t3
 
-        self.wdn = InnerProduct(w, d)                    # :185
+        self.wdn = inner(w, d)                           # :185
         self.err0 = sqrt(abs(self.wdn))
         s.data = w                                       # :189
 
@@ -151,7 +159,7 @@ class BpcgSession:
         blfA, matA, matB, matBT, preA, preM = self.blfA, self.matA, self.matB, self.matBT, self.preA, self.preM
         u, d, w, v, z, z_old, s = self.u, self.d, self.w, self.v, self.z, self.z_old, self.s
         t0, t1, t2, t3, t4, As0, BTs1 = self.t0, self.t1, self.t2, self.t3, self.t4, self.As0, self.BTs1
-        wdn, err0 = self.wdn, self.err0
+        wdn, err0, InnerProduct = self.wdn, self.err0, self.inner
         alpha = beta = 0.0
         converged = False
         for it in range(maxsteps):

@@ -71,6 +71,12 @@ class NumpyEngine:
             acc += s * b
         dst[:] = acc
 
+    def index_buffer(self, idx):
+        return np.array(idx, dtype=np.int32, copy=True)
+
+    def gather(self, idx, src, dst):
+        dst[:] = src[idx]
+
     def dot(self, x, y):
         return float(np.dot(x, y))
 

@@ -1,0 +1,102 @@
+"""Worker of the multi-process tests (world_size ranks, spawned by test_distributed*.py).
+
+mode "cpu": gloo backend, numpy checker engine -> exercises partition / halo / all-reduce host
+logic and the protocol-path BPCG / MINRES loops on distributed operands.
+mode "gpu": gloo backend with host staging, HIP engine, all ranks on the one visible GPU ->
+exercises the fused distributed loop (nss_bpcg2_phase + halo exchanges + all-reduces)."""
+
+import contextlib
+import io
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "navier-stokes-solver_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def run(rank, world, mode, init_file, out_dir, dim, n, pre, tol, maxsteps):
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method="file://" + init_file, rank=rank, world_size=world)
+    import hipla
+    if mode == "cpu":
+        from oracle.numpy_engine import NumpyEngine
+        hipla.set_engine(NumpyEngine())
+    else:
+        torch.cuda.set_device(0)
+        hipla.set_engine(None)
+    eng = hipla.get_engine()
+    from distributed import DistributedBpcg2, DistributedStokes, Form, TorchComm
+    from minres import MinRes
+    from solvers.bramblepasciak_new import BpcgSession
+    from staggered_grid import mac_stokes
+
+    sysm = mac_stokes(dim, n, 0.01)
+    f, g = sysm.rhs(0)
+    blocks = sysm.line_blocks(3) if pre == "bjac" else None
+    comm = TorchComm(dist, eng)
+    res = {}
+
+    ops = DistributedStokes(sysm, blocks, comm, eng)
+    us, ps = ops.local_slices()
+    res["slices"] = np.array([us.start, us.stop, ps.start, ps.stop])
+    res["halo"] = np.array([ops.A.plan.n_ghost, ops.B.plan.n_ghost, ops.BT.plan.n_ghost])
+    # distributed SpMV against the global product
+    rng = np.random.default_rng(5)
+    xu, xp = rng.standard_normal(sysm.n_u), rng.standard_normal(sysm.n_p)
+    vu, vp = hipla.Vector.from_numpy(xu[us]), hipla.Vector.from_numpy(xp[ps])
+    y = hipla.Vector(ops.n_u)
+    y.data = ops.A * vu + ops.B.T * vp
+    res["err_AxBTp"] = np.max(np.abs(y.numpy() - (sysm.A @ xu + sysm.B.T @ xp)[us]))
+    q = hipla.Vector(ops.n_p)
+    q.data = ops.B * vu
+    res["err_Bx"] = np.max(np.abs(q.numpy() - (sysm.B @ xu)[ps]))
+    res["dot"] = ops.inner(vu, vu)
+    res["dot_ref"] = float(np.dot(xu, xu))
+
+    # ---- BPCG v2 on distributed operands -------------------------------------------------------
+    sink = io.StringIO()
+    if mode == "cpu":
+        sol = hipla.BlockVector([hipla.Vector(ops.n_u), hipla.Vector(ops.n_p)])
+        with contextlib.redirect_stdout(sink):
+            ses = BpcgSession(Form(ops.A), Form(ops.B), None, hipla.Vector.from_numpy(f[us]),
+                              hipla.Vector.from_numpy(g[ps]), ops.preA, ops.preM, sol=sol, inner=ops.inner)
+            it, conv = ses.protocol_loop(tol, maxsteps, True, True)
+        import re
+        res["hist"] = np.array([float(m) for m in re.findall(r"it =\s+\d+\s+err =\s+(\S+)", sink.getvalue())])
+        res["it"], res["k"], res["err0"] = it, ses.k, ses.err0
+        res["u"], res["p"] = sol[0].numpy(), sol[1].numpy()
+        # ---- MINRES on distributed operands ---------------------------------------------------------
+        K = hipla.BlockMatrix([[ops.A, ops.B.T], [ops.B, None]])
+        Cm = hipla.BlockMatrix([[ops.preA, None], [None, ops.preM]])
+        import hipla.vector as hv
+        saved = hv.InnerProduct
+        import minres as minres_mod
+        minres_mod.InnerProduct = ops.inner
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                um, errs = MinRes(mat=K, pre=Cm, rhs=hipla.BlockVector([hipla.Vector.from_numpy(f[us]),
+                                                                       hipla.Vector.from_numpy(g[ps])]),
+                                  maxsteps=maxsteps, tol=tol, printrates=False)
+        finally:
+            minres_mod.InnerProduct = saved
+        res["minres_errors"] = np.array(errs)
+        res["minres_u"] = um[0].numpy()
+    else:
+        run_ = DistributedBpcg2(sysm, f, g, blocks, dist, eng, comm=comm)
+        it, conv = run_.solve(tol=tol, maxsteps=maxsteps, poll_every=8)
+        res["hist"] = run_.history(it)
+        res["it"], res["k"], res["err0"] = it, run_.k, run_.err0
+        res["u"], res["p"] = run_.sol[0].numpy(), run_.sol[1].numpy()
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), **res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    a = sys.argv[1:]
+    run(int(a[0]), int(a[1]), a[2], a[3], a[4], int(a[5]), int(a[6]), a[7], float(a[8]), int(a[9]))

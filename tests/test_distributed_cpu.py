@@ -1,0 +1,130 @@
+"""N > 1 path on CPU: world_size-2 (and 3) gloo process groups, numpy checker engine.
+Covers the row partition, halo plans, all_to_all halo exchange, all-reduced inner products and
+the protocol-path BPCG v2 / MINRES loops on distributed operands, against the single-rank run."""
+
+import contextlib
+import io
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from staggered_grid import mac_stokes
+
+
+def launch(world, mode, dim, n, pre, tol, maxsteps):
+    tmp = tempfile.mkdtemp(prefix="nssdist_")
+    init = os.path.join(tmp, "rendezvous")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), str(r), str(world), mode,
+                               init, tmp, str(dim), str(n), pre, repr(tol), str(maxsteps)], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(o.decode(errors="replace"))
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+    return [np.load(os.path.join(tmp, "rank%d.npz" % r)) for r in range(world)]
+
+
+def single_rank_reference(dim, n, pre, tol, maxsteps, numpy_engine):
+    import hipla
+    from minres import MinRes
+    from solvers.bramblepasciak_new import BpcgSession
+    s = mac_stokes(dim, n, 0.01)
+    f, g = s.rhs(0)
+    A, B = hipla.SparseMatrix.from_scipy(s.A), hipla.SparseMatrix.from_scipy(s.B)
+    preA = hipla.BlockJacobi(A, s.line_blocks(3)) if pre == "bjac" else hipla.JacobiPreconditioner(A)
+    preM = hipla.DiagonalMatrix(1.0 / s.mass)
+
+    class Form:
+        def __init__(self, mat):
+            self.mat, self.condense = mat, False
+
+    sol = hipla.BlockVector([hipla.Vector(s.n_u), hipla.Vector(s.n_p)])
+    out = io.StringIO()
+    with contextlib.redirect_stdout(out):
+        ses = BpcgSession(Form(A), Form(B), None, hipla.Vector.from_numpy(f), hipla.Vector.from_numpy(g), preA, preM,
+                          sol=sol)
+        it, conv = ses.protocol_loop(tol, maxsteps, True, True)
+    hist = np.array([float(m) for m in re.findall(r"it =\s+\d+\s+err =\s+(\S+)", out.getvalue())])
+    K = hipla.BlockMatrix([[A, B.T], [B, None]])
+    Cm = hipla.BlockMatrix([[preA, None], [None, preM]])
+    with contextlib.redirect_stdout(io.StringIO()):
+        um, errs = MinRes(mat=K, pre=Cm, rhs=hipla.BlockVector([hipla.Vector.from_numpy(f), hipla.Vector.from_numpy(g)]),
+                          maxsteps=maxsteps, tol=tol, printrates=False)
+    return s, dict(it=it, hist=hist, k=ses.k, err0=ses.err0, u=sol[0].numpy(), p=sol[1].numpy(),
+                   minres_errors=np.array(errs), minres_u=um[0].numpy())
+
+
+@pytest.mark.parametrize("world,dim,n,pre", [(2, 3, 8, "bjac"), (3, 2, 20, "jacobi")])
+def test_gloo_row_partitioned_solve_matches_single_rank(numpy_engine, world, dim, n, pre):
+    tol, maxsteps = 1e-8, 3000
+    ranks = launch(world, "cpu", dim, n, pre, tol, maxsteps)
+    s, ref = single_rank_reference(dim, n, pre, tol, maxsteps, numpy_engine)
+    vel, prs = s.partition(world)
+    for r, d in enumerate(ranks):
+        assert list(d["slices"]) == [vel[r], vel[r + 1], prs[r], prs[r + 1]]
+        assert d["err_AxBTp"] < 1e-12 and d["err_Bx"] < 1e-12
+        assert abs(d["dot"] - d["dot_ref"]) < 1e-10 * d["dot_ref"]
+        # neighbour halos only: at most two planes of velocity for A, one plane for B / B^T
+        plane_u = s.velocity_slab_offsets[1] - s.velocity_slab_offsets[0]
+        assert 0 < d["halo"][0] <= 2 * plane_u
+        assert 0 <= d["halo"][1] <= plane_u and 0 <= d["halo"][2] <= s.n ** (dim - 1)
+        # scalars are identical on every rank (all-reduced), histories match the single-rank run
+        assert abs(d["k"] - ref["k"]) < 1e-9 * ref["k"]
+        assert abs(d["err0"] - ref["err0"]) < 1e-10 * ref["err0"]
+        np.testing.assert_array_equal(d["hist"], ranks[0]["hist"])
+        w = min(30, len(ref["hist"]), len(d["hist"]))   # inside the stable window
+        np.testing.assert_allclose(d["hist"][:w], ref["hist"][:w], rtol=1e-8)
+        assert abs(int(d["it"]) - ref["it"]) <= max(3, int(0.03 * ref["it"]))
+        np.testing.assert_allclose(d["minres_errors"][:40], ref["minres_errors"][:40], rtol=1e-8)
+        assert abs(len(d["minres_errors"]) - len(ref["minres_errors"])) <= max(3, int(0.03 * len(ref["minres_errors"])))
+    assert sum(int(d["halo"][1]) for d in ranks) > 0 and sum(int(d["halo"][2]) for d in ranks) > 0
+    u = np.concatenate([d["u"] for d in ranks])
+    p = np.concatenate([d["p"] for d in ranks])
+    assert np.linalg.norm(u - ref["u"]) < 1e-5 * np.linalg.norm(ref["u"])
+    p0, pr = p - p.mean(), ref["p"] - ref["p"].mean()
+    assert np.linalg.norm(p0 - pr) < 1e-4 * np.linalg.norm(pr)
+    um = np.concatenate([d["minres_u"] for d in ranks])
+    assert np.linalg.norm(um - ref["minres_u"]) < 1e-5 * np.linalg.norm(ref["minres_u"])
+
+
+def test_halo_plan_bookkeeping():
+    from distributed import HaloPlan, even_offsets, localize_rows
+    s = mac_stokes(3, 6)
+    vel, prs = s.partition(3)
+    total_recv = total_send = 0
+    plans = []
+    for r in range(3):
+        loc, ghosts = localize_rows(s.A, (vel[r], vel[r + 1]), vel, r)
+        assert loc.shape == (vel[r + 1] - vel[r], vel[r + 1] - vel[r] + ghosts.size)
+        assert np.all((ghosts < vel[r]) | (ghosts >= vel[r + 1]))
+        plans.append(HaloPlan(r, 3, vel[r + 1] - vel[r], ghosts, vel))
+    for r, pl in enumerate(plans):
+        pl.finalize([plans[q].requests()[r] for q in range(3)])
+        assert pl.recv_counts[r] == 0 and pl.send_counts[r] == 0
+        total_recv += pl.recv_counts.sum()
+        total_send += pl.send_counts.sum()
+        assert pl.send_idx.size == pl.send_counts.sum()
+        assert pl.send_idx.min(initial=0) >= 0 and pl.send_idx.max(initial=0) < pl.n_owned
+    assert total_recv == total_send > 0
+    assert plans[0].recv_counts[2] == 0 and plans[2].recv_counts[0] == 0      # slabs: neighbours only
+    # the renumbered local product equals the global one
+    x = np.random.default_rng(0).standard_normal(s.n_u)
+    for r in range(3):
+        loc, ghosts = localize_rows(s.A, (vel[r], vel[r + 1]), vel, r)
+        ext = np.concatenate([x[vel[r]:vel[r + 1]], x[ghosts]])
+        np.testing.assert_allclose(loc @ ext, (s.A @ x)[vel[r]:vel[r + 1]], rtol=1e-14, atol=1e-14)
+    assert list(even_offsets(10, 3)) == [0, 3, 7, 10]

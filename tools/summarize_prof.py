@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 CSV output (kernel stats + FETCH_SIZE / WRITE_SIZE passes) into a small
+markdown summary: per-kernel calls / average duration, and per-kernel average HBM traffic with
+the gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE under-reports wide coalesced reads by
+2x; here calibrated on the STREAM-triad kernel of the same run, whose byte count is known)."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+
+def find(root, pattern):
+    hits = glob.glob(os.path.join(root, "**", pattern), recursive=True)
+    return hits[0] if hits else None
+
+
+def short(name):
+    name = name.replace("nss::", "")
+    return name[:90]
+
+
+def kernel_stats(path):
+    rows = []
+    with open(path) as fh:
+        for r in csv.DictReader(fh):
+            rows.append(r)
+    return rows
+
+
+def pmc_avg(path, counter):
+    acc = defaultdict(lambda: [0.0, 0])
+    with open(path) as fh:
+        for r in csv.DictReader(fh):
+            if r.get("Counter_Name") != counter:
+                continue
+            k = r["Kernel_Name"]
+            acc[k][0] += float(r["Counter_Value"])
+            acc[k][1] += 1
+    return {k: (v[0] / v[1], v[1]) for k, v in acc.items()}
+
+
+def main():
+    root, tag = sys.argv[1], sys.argv[2]
+    out = ["# rocprofv3 summary (%s)" % tag, ""]
+    stats = find(os.path.join(root, tag + "_trace"), "*kernel_stats.csv")
+    if stats:
+        out += ["## kernel-trace --stats", "", "| kernel | calls | avg (us) | total (ms) | % |", "|---|---|---|---|---|"]
+        for r in kernel_stats(stats)[:16]:
+            out.append("| %s | %s | %.2f | %.3f | %s |" % (short(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e3,
+                                                        float(r["TotalDurationNs"]) / 1e6, r["Percentage"]))
+        out.append("")
+    fetch = find(os.path.join(root, tag + "_fetch"), "*counter_collection.csv")
+    write = find(os.path.join(root, tag + "_write"), "*counter_collection.csv")
+    if fetch and write:
+        f = pmc_avg(fetch, "FETCH_SIZE")
+        w = pmc_avg(write, "WRITE_SIZE")
+        tri = [k for k in f if "triad_kernel" in k]
+        cal = None
+        if tri:
+            n = 1 << 26
+            cal = (16.0 * n) / (f[tri[0]][0] * 1024.0)     # known read bytes / reported
+        out += ["## HBM traffic per launch (PMC, separate passes)", "",
+                "FETCH_SIZE / WRITE_SIZE are in KiB.  Read-side calibration factor from the STREAM-triad kernel "
+                "(known 16 B x 2^26 read): %s" % ("%.3f" % cal if cal else "n/a"), "",
+                "| kernel | launches | FETCH raw (MB) | WRITE raw (MB) | corrected read+write (MB) |", "|---|---|---|---|---|"]
+        for k in sorted(f, key=lambda k: -f[k][0])[:14]:
+            fr = f[k][0] * 1024 / 1e6
+            wr = w.get(k, (0.0, 0))[0] * 1024 / 1e6
+            corr = fr * (cal or 1.0) + wr
+            out.append("| %s | %d | %.1f | %.1f | %.1f |" % (short(k), f[k][1], fr, wr, corr))
+        out.append("")
+    print("\n".join(out))
+
+
+if __name__ == "__main__":
+    main()
