@@ -99,19 +99,51 @@ struct EpiK3 {
   }
 };
 
-// local sum of the partials of K2 and K3 (or of K4 when nb == 0) into scal[slot]
-__global__ __launch_bounds__(kBlock) void bpcg2_sum_kernel(const int32_t* __restrict__ ctrl, int na,
-                                                            const double* __restrict__ pa, int nb,
-                                                            const double* __restrict__ pb, double* __restrict__ scal,
-                                                            int slot) {
-  __shared__ double lds[kBlock / kWave];
+// local sum of the partials of K2 and K3 (or of K4 when nb == 0) into scal[slot].  One
+// workgroup of 1024 lanes, four independent accumulators per lane: the ~35 k partials of the
+// 1e7-DoF case are latency-, not bandwidth-bound (a 256-lane serial loop took 32 us).
+constexpr int kSumBlock = 1024;
+__global__ __launch_bounds__(kSumBlock) void bpcg2_sum_kernel(const int32_t* __restrict__ ctrl, int na,
+                                                               const double* __restrict__ pa, int nb,
+                                                               const double* __restrict__ pb,
+                                                               double* __restrict__ scal, int slot) {
+  __shared__ double lds[2 * kSumBlock / kWave];
   if (ctrl[C_DONE] != 0) return;
-  double a = 0.0, b = 0.0;
-  for (int i = threadIdx.x; i < na; i += kBlock) a += pa[i];
-  for (int i = threadIdx.x; i < nb; i += kBlock) b += pb[i];
-  const double sa = block_sum(a, lds);
-  const double sb = block_sum(b, lds);
-  if (threadIdx.x == 0) scal[slot] = sa + sb;
+  const int tid = threadIdx.x;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  int i = tid;
+  for (; i + 3 * kSumBlock < na; i += 4 * kSumBlock) {
+    a0 += pa[i];
+    a1 += pa[i + kSumBlock];
+    a2 += pa[i + 2 * kSumBlock];
+    a3 += pa[i + 3 * kSumBlock];
+  }
+  for (; i < na; i += kSumBlock) a0 += pa[i];
+  double b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
+  i = tid;
+  for (; i + 3 * kSumBlock < nb; i += 4 * kSumBlock) {
+    b0 += pb[i];
+    b1 += pb[i + kSumBlock];
+    b2 += pb[i + 2 * kSumBlock];
+    b3 += pb[i + 3 * kSumBlock];
+  }
+  for (; i < nb; i += kSumBlock) b0 += pb[i];
+  const double sa = wave_sum((a0 + a1) + (a2 + a3));
+  const double sb = wave_sum((b0 + b1) + (b2 + b3));
+  const int lane = tid & (kWave - 1), wave = tid >> 6;
+  if (lane == 0) {
+    lds[wave] = sa;
+    lds[kSumBlock / kWave + wave] = sb;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double ta = 0.0, tb = 0.0;
+    for (int w = 0; w < kSumBlock / kWave; ++w) {
+      ta += lds[w];
+      tb += lds[kSumBlock / kWave + w];
+    }
+    scal[slot] = ta + tb;
+  }
 }
 
 // scalar steps (one lane): which = 1 -> alpha; which = 2 -> beta, history, stop test
@@ -215,7 +247,7 @@ static void phase(const nss_bpcg2_t& s, int which, int it, hipStream_t st) {
       break;
     }
     case NSS_BPCG2_SUM1:
-      hipLaunchKernelGGL(bpcg2_sum_kernel, dim3(1), dim3(kBlock), 0, st, s.ctrl, s.A->nblk, s.partials_a, s.B->nblk,
+      hipLaunchKernelGGL(bpcg2_sum_kernel, dim3(1), dim3(kSumBlock), 0, st, s.ctrl, s.A->grid(), s.partials_a, s.B->grid(),
                          s.partials_b, s.scal, int(S_AS));
       NSS_CHECK_LAUNCH();
       break;
@@ -231,7 +263,7 @@ static void phase(const nss_bpcg2_t& s, int which, int it, hipStream_t st) {
       break;
     }
     case NSS_BPCG2_SUM2:
-      hipLaunchKernelGGL(bpcg2_sum_kernel, dim3(1), dim3(kBlock), 0, st, s.ctrl, k4_grid(s), s.partials_c, 0,
+      hipLaunchKernelGGL(bpcg2_sum_kernel, dim3(1), dim3(kSumBlock), 0, st, s.ctrl, k4_grid(s), s.partials_c, 0,
                          s.partials_c, s.scal, int(S_WDN));
       NSS_CHECK_LAUNCH();
       break;
@@ -258,8 +290,8 @@ extern "C" {
 int nss_bpcg2_workspace(const nss_bpcg2_t* s, int64_t* partials_a, int64_t* partials_b, int64_t* partials_c) {
   return guarded([&] {
     NSS_REQUIRE(s && s->A && s->B, "bpcg2_workspace: NULL state / matrices");
-    if (partials_a) *partials_a = s->A->nblk;
-    if (partials_b) *partials_b = s->B->nblk;
+    if (partials_a) *partials_a = s->A->grid();
+    if (partials_b) *partials_b = s->B->grid();
     if (partials_c) *partials_c = k4_grid(*s);
   });
 }

@@ -13,7 +13,8 @@
 //   epilogue a functor consumes (row, A x) -- plain alpha/beta update or the fused
 //            vector updates + dot partials of the Krylov loops -- so y is written once
 //            and the extra vectors are read while the row is still in registers.
-// Row blocks are precomputed on the host when the matrix is uploaded.  The
+// Row blocks are precomputed on the host when the matrix is uploaded; the default grid has
+// one workgroup per row block (the kernel also accepts a smaller, striding grid).  The
 // blockIdx -> row-block map is XCD-aware: workgroups b and b+8 share an XCD (round-robin
 // dispatch), so XCD i walks its own contiguous eighth of the rows and its private 4 MiB
 // L2 keeps one window of x instead of all eight L2s caching the same window.
@@ -50,6 +51,8 @@ struct nss_csr_s {
   nss::CsrView view() const {
     return nss::CsrView{rowblk, rowptr, col, val, nblk, (nblk + nss::kXcds - 1) / nss::kXcds};
   }
+  // one workgroup per row block (the hardware dispatcher balances the tail better than a
+  // persistent grid did: -8 % on the A SpMV), padded to a multiple of the XCD count
   int grid() const { return ((nblk + nss::kXcds - 1) / nss::kXcds) * nss::kXcds; }
 };
 
@@ -64,55 +67,60 @@ __global__ __launch_bounds__(kBlock) void csr_stream_kernel(CsrView a, const dou
   __shared__ double prod[kChunk];
   __shared__ double red[kBlock / kWave];
   if (epi.skip()) return;
-  const int b = (blockIdx.x & (kXcds - 1)) * a.per_xcd + (blockIdx.x >> 3);
-  if (b >= a.nblk) return;
   const int tid = threadIdx.x;
-  const int r0 = a.rowblk[b];
-  const int r1 = a.rowblk[b + 1];
-  const int p0 = a.rowptr[r0];
-  const int cnt = a.rowptr[r1] - p0;
-
-  if (cnt <= kChunk) {
-    // ---- phase 1: coalesced stream of (col, val), gather x, stage products -----------
-    constexpr int kPer = kChunk / kBlock;
-    int32_t c[kPer];
-    double v[kPer];
+  // XCD-aware walk: workgroups with equal (blockIdx & 7) share an XCD and stride together
+  // through that XCD's contiguous eighth of the row blocks.
+  const int xcd = blockIdx.x & (kXcds - 1);
+  const int b_end = min((xcd + 1) * a.per_xcd, a.nblk);
+  const int b_step = gridDim.x >> 3;   // == per_xcd for the default grid: one row block each
+  for (int b = xcd * a.per_xcd + (blockIdx.x >> 3); b < b_end; b += b_step) {
+    const int r0 = a.rowblk[b];
+    const int r1 = a.rowblk[b + 1];
+    const int p0 = a.rowptr[r0];
+    const int cnt = a.rowptr[r1] - p0;
+    if (cnt <= kChunk) {
+      // ---- phase 1: coalesced stream of (col, val), gather x, stage products ---------
+      constexpr int kPer = kChunk / kBlock;
+      int32_t c[kPer];
+      double v[kPer];
 #pragma unroll
-    for (int k = 0; k < kPer; ++k) {
-      const int i = tid + k * kBlock;
-      const bool live = i < cnt;
-      c[k] = live ? a.col[p0 + i] : 0;
-      v[k] = live ? a.val[p0 + i] : 0.0;
-    }
-    double xv[kPer];
-#pragma unroll
-    for (int k = 0; k < kPer; ++k) xv[k] = (tid + k * kBlock < cnt) ? x[c[k]] : 0.0;
-#pragma unroll
-    for (int k = 0; k < kPer; ++k)
-      if (tid + k * kBlock < cnt) prod[tid + k * kBlock] = v[k] * xv[k];
-    __syncthreads();
-    // ---- phase 2: per-row reduction from LDS -------------------------------------------
-    constexpr int kRowsPerPass = kBlock / RG;
-    const int sub = tid % RG;
-    for (int r = r0 + tid / RG; r < r1; r += kRowsPerPass) {
-      const int s = a.rowptr[r] - p0;
-      const int e = a.rowptr[r + 1] - p0;
-      double sum = 0.0;
-      for (int j = s + sub; j < e; j += RG) sum += prod[j];
-      if (RG > 1) {
-#pragma unroll
-        for (int off = RG / 2; off > 0; off >>= 1) sum += __shfl_xor(sum, off, kWave);
+      for (int k = 0; k < kPer; ++k) {
+        const int i = tid + k * kBlock;
+        const bool live = i < cnt;
+        c[k] = live ? a.col[p0 + i] : 0;
+        v[k] = live ? a.val[p0 + i] : 0.0;
       }
-      if (sub == 0) epi.row(r, sum);
+      double xv[kPer];
+#pragma unroll
+      for (int k = 0; k < kPer; ++k) xv[k] = (tid + k * kBlock < cnt) ? x[c[k]] : 0.0;
+#pragma unroll
+      for (int k = 0; k < kPer; ++k)
+        if (tid + k * kBlock < cnt) prod[tid + k * kBlock] = v[k] * xv[k];
+      __syncthreads();
+      // ---- phase 2: per-row reduction from LDS -----------------------------------------
+      constexpr int kRowsPerPass = kBlock / RG;
+      const int sub = tid % RG;
+      for (int r = r0 + tid / RG; r < r1; r += kRowsPerPass) {
+        const int s = a.rowptr[r] - p0;
+        const int e = a.rowptr[r + 1] - p0;
+        double sum = 0.0;
+        for (int j = s + sub; j < e; j += RG) sum += prod[j];
+        if (RG > 1) {
+#pragma unroll
+          for (int off = RG / 2; off > 0; off >>= 1) sum += __shfl_xor(sum, off, kWave);
+        }
+        if (sub == 0) epi.row(r, sum);
+      }
+      __syncthreads();  // prod is rewritten by the next row block
+    } else {
+      // ---- one row longer than the LDS chunk: the whole workgroup reduces it ----------
+      double acc = 0.0;
+      for (int i = tid; i < cnt; i += kBlock) acc = fma(a.val[p0 + i], x[a.col[p0 + i]], acc);
+      const double sum = block_sum(acc, red);
+      if (tid == 0) epi.row(r0, sum);
     }
-  } else {
-    // ---- one row longer than the LDS chunk: the whole workgroup reduces it ------------
-    double acc = 0.0;
-    for (int i = tid; i < cnt; i += kBlock) acc = fma(a.val[p0 + i], x[a.col[p0 + i]], acc);
-    const double sum = block_sum(acc, red);
-    if (tid == 0) epi.row(r0, sum);
   }
-  epi.finish(b, red);
+  epi.finish(blockIdx.x, red);  // one dot partial per workgroup
 }
 
 template <class Epi>
