@@ -341,3 +341,30 @@ def test_fused_bpcg2_frozen_at_break_and_maxsteps_warning(hip_engine):
         it, _ = BramblePasciakCG(Form(A), Form(B), None, hipla.Vector.from_numpy(f), hipla.Vector.from_numpy(g),
                                  preA, preS, sol, tol=1e-30, maxsteps=9)
     assert it == 8 and "Warning: BPCG did not converge" in out.getvalue()
+
+
+def test_drivers_on_gpu(hip_engine, tmp_path):
+    """Harness / driver shape on the product engine: NavierStokes.SolveInitial takes the fused
+    loop, run.py writes the reference's CSV columns, stokes_hcurldiv's call converges."""
+    import run as harness
+    from discretizations import bdm_hybrid
+    from stokes_hcurldiv import solve_stokes
+    from templates.NavierStokesSIMPLE_iterative import NavierStokes, SyntheticMesh
+    ns = NavierStokes(SyntheticMesh(0.125, dim=3), nu=0.001, inflow="inlet", outflow="outlet", wall="wall|cyl",
+                      uin=None, timestep=0.002, order=1)
+    with contextlib.redirect_stdout(io.StringIO()):
+        ns.SolveInitial(iterative=True, GS=False, tol=1e-8)
+    s = ns.system
+    f, g = s.rhs(0)
+    x = np.concatenate([ns.velocity.numpy(), ns.gfup.numpy()])
+    assert np.linalg.norm(np.concatenate([f, g]) - s.saddle_matrix() @ x) / np.linalg.norm(f) < 1e-5
+    assert ns.stokes_bpcg_iterations > 5 and ns.stokes_bpcg_time > 0
+    methods = {"hybrid_dg": {"solve": harness.solve_hybrid, "discretizations": {"HDG BDM 1": bdm_hybrid(1, 10)}}}
+    with contextlib.redirect_stdout(io.StringIO()):
+        data = harness.run([0.125], methods, harness.solver_factories, str(tmp_path / "errors.csv"), False)
+    assert set(data.solver) == {"bramble pasciak cg", "minres"}
+    for _, grp in data.groupby("solver"):
+        assert grp.error.iloc[0] == 1.0 and grp.error.iloc[-1] < 1e-6
+    with contextlib.redirect_stdout(io.StringIO()):
+        sol, errors, _ = solve_stokes(maxh=0.2, tolerance=1e-8)
+    assert errors[-1] < 1e-8
