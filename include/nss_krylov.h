@@ -159,6 +159,39 @@ NSS_API int nss_bpcg2_iterate(const nss_bpcg2_t* s, int32_t it_begin, int32_t it
 NSS_API int nss_bpcg2_poll(const nss_bpcg2_t* s, int32_t* done, int32_t* it_final, int32_t* last_it,
                            nss_stream_t stream);
 
+/* ---- fused preconditioned MINRES ----------------------------------------------------------
+ * Replaces the loop body of minres.py:96-144 for K = [[A, B^T], [B, 0]], C = diag(preA, preS)
+ * (the operands run.py:45-46 builds).  Vectors are given per block component ([0] velocity, n_u;
+ * [1] pressure, n_p).  The three-vector rotations of minres.py:131-133 are index arithmetic on
+ * the rings: at iteration k (1-based)  v_old = v[(k-1)%3], v = v[k%3], v_new = v[(k+1)%3]
+ * (same for w);  z = z[k%2], z_new = z[(k+1)%2].
+ * scal: double[20] (see csrc/minres.hip); ctrl: int32[4] = { stop, k_stop, reason, last_k } with
+ * reason 1 = relative break (:126), 2 = absolute guard `ResNorm > tol` failed (:96, warns);
+ * hist[k] = ResNorm_k / err0 (:125). */
+typedef struct nss_minres_s {
+  nss_csr_t A, B, BT;
+  const double* pre_diag;      /* point-Jacobi preA (n_u) -- or NULL */
+  nss_bjac_t pre_bjac;         /* block-Jacobi preA       -- or NULL */
+  const double* minv;          /* preS diagonal (n_p)                */
+  double* u[2];
+  double* v[3][2];
+  double* w[3][2];
+  double* z[2][2];
+  double* kz[2];
+  double* scal;
+  int32_t* ctrl;
+  double* hist;
+  double *partials_a, *partials_b, *partials_c; /* sizes: nss_minres_workspace() */
+  int32_t n_u, n_p;
+} nss_minres_t;
+
+NSS_API int nss_minres_workspace(const nss_minres_t* s, int64_t* partials_a, int64_t* partials_b,
+                                 int64_t* partials_c);
+/* enqueue iterations k = k_begin .. k_end-1 (1-based, as the reference counts) */
+NSS_API int nss_minres_iterate(const nss_minres_t* s, int32_t k_begin, int32_t k_end, nss_stream_t stream);
+NSS_API int nss_minres_poll(const nss_minres_t* s, int32_t* stop, int32_t* k_stop, int32_t* reason,
+                            int32_t* last_k, nss_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,8 +15,8 @@ import os
 
 import numpy as np
 
-from .matrix import BlockJacobi, DiagonalMatrix, ScaledMatrix, SparseMatrix
-from .vector import Vector
+from .matrix import BlockJacobi, BlockMatrix, DiagonalMatrix, ScaledMatrix, SparseMatrix
+from .vector import BlockVector, Vector
 
 POLL_EVERY = int(os.environ.get("NSS_POLL_EVERY", "32"))
 ENABLED = True      # tests flip this to force the protocol path on native operands
@@ -173,3 +173,115 @@ class Bpcg2Loop:
                 break
         final = it_final if done else maxsteps - 1
         return final, self.history(final), done
+
+
+class MinresState(C.Structure):
+    """ctypes mirror of ``nss_minres_t`` (include/nss_krylov.h)."""
+    _fields_ = ([(n, C.c_void_p) for n in ("A", "B", "BT", "pre_diag", "pre_bjac", "minv")]
+                + [("u", C.c_void_p * 2), ("v", (C.c_void_p * 2) * 3), ("w", (C.c_void_p * 2) * 3),
+                   ("z", (C.c_void_p * 2) * 2), ("kz", C.c_void_p * 2),
+                   ("scal", C.c_void_p), ("ctrl", C.c_void_p), ("hist", C.c_void_p),
+                   ("partials_a", C.c_void_p), ("partials_b", C.c_void_p), ("partials_c", C.c_void_p),
+                   ("n_u", C.c_int32), ("n_p", C.c_int32)])
+
+
+(M_DELTA, M_GAMMA, M_G2, M_ETA_OLD, M_C_OLD, M_C, M_S_OLD, M_S, M_RES_OLD, M_ERR0, M_TOL) = range(11)
+
+
+def _block2(v, n_u, n_p):
+    return (isinstance(v, BlockVector) and v.nblocks == 2 and _plain(v[0], n_u) and _plain(v[1], n_p))
+
+
+class MinresLoop:
+    """Device-resident iteration of minres.py:96-144 for K = [[A, B^T], [B, None]] and
+    C = [[preA, None], [None, preS]] (the operands run.py:45-46 builds)."""
+
+    @classmethod
+    def try_create(cls, mat, pre, u, v_ring, w_ring, z_ring, kz):
+        if not (isinstance(mat, BlockMatrix) and isinstance(pre, BlockMatrix)):
+            return None
+        if (mat.nrows, mat.ncols) != (2, 2) or (pre.nrows, pre.ncols) != (2, 2):
+            return None
+        A, BT, B, C11 = mat[0, 0], mat[0, 1], mat[1, 0], mat[1, 1]
+        if C11 is not None or pre[0, 1] is not None or pre[1, 0] is not None:
+            return None
+        if not all(isinstance(m, SparseMatrix) for m in (A, BT, B)):
+            return None
+        eng = A.engine
+        if not ENABLED or not _hip(eng) or not hasattr(eng.lib, "nss_minres_iterate"):
+            return None
+        n_u, n_p = A.height, B.height
+        if (A.width, B.width, BT.height, BT.width) != (n_u, n_u, n_u, n_p):
+            return None
+        pa_d, pa_b, ps = native_diag(pre[0, 0]), native_bjac(pre[0, 0]), native_diag(pre[1, 1])
+        if ps is None or (pa_d is None and pa_b is None):
+            return None
+        vecs = [u, kz] + list(v_ring) + list(w_ring) + list(z_ring)
+        if len(v_ring) != 3 or len(w_ring) != 3 or len(z_ring) != 2 or not all(_block2(x, n_u, n_p) for x in vecs):
+            return None
+        return cls(eng, A, B, BT, pa_d, pa_b, ps, u, v_ring, w_ring, z_ring, kz)
+
+    def __init__(self, eng, A, B, BT, pa_d, pa_b, ps, u, v_ring, w_ring, z_ring, kz):
+        torch = eng.torch
+        self.eng, self.lib = eng, eng.lib
+        self.keep = [A, B, BT, pa_d, pa_b, ps, u, v_ring, w_ring, z_ring, kz]
+        st = MinresState()
+        st.A, st.B, st.BT = A.handle.ptr, B.handle.ptr, BT.handle.ptr
+
+        def scaled(pair):
+            scale, op = pair
+            return op.d if scale == 1.0 else op.d * scale
+
+        if pa_d is not None:
+            self.dinv = scaled(pa_d)
+            st.pre_diag, st.pre_bjac = self.dinv.data_ptr(), None
+        else:
+            scale, op = pa_b
+            if scale != 1.0:
+                raise ValueError("scaled block-Jacobi is not supported by the fused MINRES loop")
+            st.pre_diag, st.pre_bjac = None, op.handle.ptr
+        self.minv = scaled(ps)
+        st.minv = self.minv.data_ptr()
+        for c in range(2):
+            st.u[c] = u[c].buf.data_ptr()
+            st.kz[c] = kz[c].buf.data_ptr()
+            for j in range(3):
+                st.v[j][c] = v_ring[j][c].buf.data_ptr()
+                st.w[j][c] = w_ring[j][c].buf.data_ptr()
+            for j in range(2):
+                st.z[j][c] = z_ring[j][c].buf.data_ptr()
+        st.n_u, st.n_p = A.height, B.height
+        na, nb, nc = C.c_int64(), C.c_int64(), C.c_int64()
+        eng._check(self.lib.nss_minres_workspace(C.byref(st), C.byref(na), C.byref(nb), C.byref(nc)))
+        self.partials = [eng.zeros(max(1, x.value)) for x in (na, nb, nc)]
+        st.partials_a, st.partials_b, st.partials_c = (p.data_ptr() for p in self.partials)
+        self.scal = eng.zeros(20)
+        self.ctrl = torch.zeros(4, dtype=torch.int32, device=eng.device)
+        st.scal, st.ctrl = self.scal.data_ptr(), self.ctrl.data_ptr()
+        self.state = st
+        self.hist = None
+
+    def run(self, gamma, tol, maxsteps, poll_every=None):
+        """Iterations k = 1.. as the reference's while loop.  Returns (errors, hit_relative_tol)."""
+        eng, st = self.eng, self.state
+        poll_every = poll_every or POLL_EVERY
+        self.hist = eng.zeros(maxsteps + 2)
+        st.hist = self.hist.data_ptr()
+        scal = np.zeros(20)
+        scal[M_GAMMA], scal[M_ETA_OLD], scal[M_C_OLD], scal[M_C] = gamma, gamma, 1.0, 1.0
+        scal[M_RES_OLD], scal[M_ERR0], scal[M_TOL] = gamma, gamma, tol
+        eng.upload(scal, self.scal)
+        self.ctrl.zero_()
+        stop, k_stop, reason, last = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        k = 1
+        while k < maxsteps + 1:
+            end = min(maxsteps + 1, k + poll_every)
+            eng._check(self.lib.nss_minres_iterate(C.byref(st), k, end, eng.stream))
+            k = end
+            eng._check(self.lib.nss_minres_poll(C.byref(st), C.byref(stop), C.byref(k_stop), C.byref(reason),
+                                                C.byref(last), eng.stream))
+            if stop.value:
+                break
+        last_k = k_stop.value if stop.value else maxsteps
+        errors = [1.0] + [float(x) for x in eng.to_host(self.hist)[1: last_k + 1]]
+        return errors, bool(stop.value and reason.value == 1)

@@ -17,6 +17,7 @@ Recurrences follow Kolmbauer's formulation used by the reference (minres.py:9)."
 from math import sqrt
 
 from hipla import InnerProduct
+from hipla.fused import MinresLoop
 
 __all__ = ["MinRes"]
 
@@ -67,6 +68,17 @@ def MinRes(mat, rhs, pre=None, sol=None, maxsteps=100, printrates=True, initiali
     errors = [1.0]                                   # minres.py:95
     k = 1
     hit_relative_tol = False
+    fused_loop = None
+    if pre and maxsteps >= 1 and res > tol:
+        # ring layout expected by nss_minres_iterate at k = 1: old = [0], current = [1], new = [2]
+        fused_loop = MinresLoop.try_create(mat, pre, u, (v_prev, v_cur, v_next), (w_prev, w_cur, w_next),
+                                           (z_next, z_cur), kz)
+    if fused_loop is not None:
+        errors, hit_relative_tol = fused_loop.run(gamma, tol, maxsteps)
+        if printrates:
+            for i, e in enumerate(errors[1:], 1):
+                _report(i, e * err0, err0, True)
+        maxsteps = 0                                 # the protocol loop below is skipped
     while k < maxsteps + 1 and res > tol:            # absolute guard, minres.py:96
         kz.data = mat * z_cur                        # :97
         delta = InnerProduct(kz, z_cur)              # :98

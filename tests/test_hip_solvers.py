@@ -368,3 +368,46 @@ def test_drivers_on_gpu(hip_engine, tmp_path):
     with contextlib.redirect_stdout(io.StringIO()):
         sol, errors, _ = solve_stokes(maxh=0.2, tolerance=1e-8)
     assert errors[-1] < 1e-8
+
+
+def test_fused_minres_is_selected_and_agrees_with_protocol_path(hip_engine):
+    import hipla
+    from hipla import fused
+    from minres import MinRes
+    for case in ("stokes3d_n10_bjac_minres", "stokes2d_n24_jacobi_minres"):
+        d = np.load(golden_path(case))
+        s, f, g, A, B, preA, preS = operands(d)
+        K = hipla.BlockMatrix([[A, B.T], [B, None]])
+        Cm = hipla.BlockMatrix([[preA, None], [None, preS]])
+        res = {}
+        for mode in ("fused", "protocol"):
+            fused.ENABLED = mode == "fused"
+            try:
+                made = []
+                orig = fused.MinresLoop.try_create.__func__
+
+                def spy(cls, *a, **kw):
+                    out = orig(cls, *a, **kw)
+                    made.append(out is not None)
+                    return out
+
+                fused.MinresLoop.try_create = classmethod(spy)
+                try:
+                    out = io.StringIO()
+                    with contextlib.redirect_stdout(out):
+                        u, errors = MinRes(mat=K, pre=Cm, rhs=hipla.BlockVector([hipla.Vector.from_numpy(f),
+                                                                                 hipla.Vector.from_numpy(g)]),
+                                           maxsteps=int(d["maxsteps"]), tol=float(d["tol"]), printrates=False)
+                finally:
+                    fused.MinresLoop.try_create = classmethod(orig)
+                assert made == [mode == "fused"]
+                res[mode] = (np.array(errors), u.numpy(), "Warning" in out.getvalue())
+            finally:
+                fused.ENABLED = True
+        w = int(d["window"])
+        np.testing.assert_allclose(res["fused"][0][:w], res["protocol"][0][:w], rtol=1e-8)
+        check_history(res["fused"][0], d["errors"], d["window"])
+        check_iterations(len(res["fused"][0]) - 1, d["iterations"], d)
+        assert res["fused"][2] == res["protocol"][2] == bool(d["warned"])
+        assert np.linalg.norm(res["fused"][1] - res["protocol"][1]) <= 1e-6 * np.linalg.norm(res["protocol"][1])
+        check_solution(res["fused"][1], s, f, g, d)
