@@ -192,6 +192,34 @@ NSS_API int nss_minres_iterate(const nss_minres_t* s, int32_t k_begin, int32_t k
 NSS_API int nss_minres_poll(const nss_minres_t* s, int32_t* stop, int32_t* k_stop, int32_t* reason,
                             int32_t* last_k, nss_stream_t stream);
 
+/* ---- fused Bramble-Pasciak CG, textbook form ------------------------------------------------
+ * Replaces the loop body of bramble_pasciak_cg.py:110-143 (6 SpMV per iteration) for
+ * C = None, pre_a Jacobi / block-Jacobi, pre_schur diagonal.  Block vectors per component
+ * ([0] velocity n_u, [1] pressure n_p): x = solution, r = residuum, d =
+ * full_preconditioned_residuum, a = a_preconditioned_residuum, t1 / t2 = temp_1 / temp_2.
+ * scal: double[8] = { rho, <d,t1>, rho_new, alpha, beta, err0, tolerance, - };
+ * ctrl: int32[4] = { stop, it_stop, last_it, - };  hist[it] = err_it / err_0 (:118), written
+ * before the stop test of iteration `it` (:119). */
+typedef struct nss_bpcg1_s {
+  nss_csr_t A, B, BT;
+  const double* pre_diag;
+  nss_bjac_t pre_bjac;
+  const double* minv;
+  double *x[2], *r[2], *d[2], *a[2], *t1[2], *t2[2];
+  double* scal;
+  int32_t* ctrl;
+  double* hist;
+  double *partials_a, *partials_b, *partials_c;
+  double k;
+  int32_t n_u, n_p;
+} nss_bpcg1_t;
+
+NSS_API int nss_bpcg1_workspace(const nss_bpcg1_t* s, int64_t* partials_a, int64_t* partials_b,
+                                int64_t* partials_c);
+NSS_API int nss_bpcg1_iterate(const nss_bpcg1_t* s, int32_t it_begin, int32_t it_end, nss_stream_t stream);
+NSS_API int nss_bpcg1_poll(const nss_bpcg1_t* s, int32_t* stop, int32_t* it_stop, int32_t* last_it,
+                           nss_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

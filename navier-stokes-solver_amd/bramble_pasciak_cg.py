@@ -13,6 +13,7 @@ statement for statement -- 6 SpMV, 1 pre_a, 1 pre_s, 2 inner products per iterat
 from math import sqrt
 
 from hipla import BaseMatrix, BlockMatrix, BlockVector, IdentityMatrix, InnerProduct, Vector
+from hipla.fused import Bpcg1Loop
 from hipla.la import EigenValues_Preconditioner
 from hipla.ngstd import Timer
 
@@ -121,6 +122,18 @@ def bramble_pasciak_cg(a_matrix, b_matrix, c_matrix, pre_a, pre_schur_complement
     rho = InnerProduct(t1, r)                             # :105
     err0 = sqrt(abs(rho))
     errors = []
+
+    fused_loop = Bpcg1Loop.try_create(a_matrix, b_matrix, c_matrix, pre_a, pre_schur_complement, k,
+                                      dict(x=solution, r=r, d=d, a=ar, t1=t1, t2=t2))
+    if fused_loop is not None:
+        errors, converged = fused_loop.run(rho, err0, tolerance, max_steps)
+        if print_rates:
+            for i, e in enumerate(errors):
+                print("\rit =", i, "rel err =", e, "abs err =", e * err0, " " * 20, end="")
+        if not converged:
+            print("\nWarning: CG did not converge to TOL")
+        print("")
+        return (solution, errors)
 
     for iteration in range(max_steps):
         it_timer = Timer("Bramble Pasciak CG Iteration " + str(iteration))

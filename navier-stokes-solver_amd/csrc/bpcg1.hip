@@ -1,0 +1,266 @@
+// Fused, device-resident iteration of the textbook Bramble-Pasciak CG (reference loop:
+// bramble_pasciak_cg.py:110-143; 6 SpMV per iteration as the reference).
+//
+//   S0   one lane : hist[it] = err/err0 (:115-118), stop test at the loop top (:119)
+//   V1a  rows of A   : t1u = A du                                                     (:125)
+//   V1b  rows of B^T : ku = t1u + B^T dp;  t1u = -ku;  Jacobi: t2u = k dinv ku        (:125-126)
+//   [J]  block-Jacobi: t2u = -k J t1u                                                 (:126)
+//   V1c  rows of B   : kp = B du;  t1p = -kp;  t2p = kp                               (:125-126)
+//   V3a  rows of A   : t1u += A t2u, partial <du, t1u>                                (:127,130)
+//   V3b  rows of B   : t1p += B t2u, partial <dp, t1p>                                (:127,130)
+//   R1   alpha = rho / sum                                                            (:129)
+//   V4   element-wise: x += a d, r -= a t1, a_res -= a t2, partial <a_res_u, r_u>     (:131-133,137)
+//   V5   rows of B   : t1p = minv (B a_res_u - a_res_p), partial <t1p, r_p>           (:135,137)
+//   R2   rho_new, beta = rho_new / rho                                                (:137-138)
+//   V6   element-wise: du = b du + a_res_u, dp = b dp + t1p                           (:140-141)
+#include "bpcg2.h"
+
+#include <algorithm>
+
+namespace nss {
+
+enum { P_RHO = 0, P_DSUM = 1, P_RHON = 2, P_ALPHA = 3, P_BETA = 4, P_ERR0 = 5, P_TOL = 6 };
+enum { PC_STOP = 0, PC_ITSTOP = 1, PC_LAST = 2 };
+
+struct EpiStore1 {
+  const int32_t* __restrict__ ctrl;
+  double* __restrict__ y;
+  __device__ bool skip() const { return ctrl[PC_STOP] != 0; }
+  __device__ void row(int r, double ax) const { y[r] = ax; }
+  __device__ void finish(int, double*) const {}
+};
+
+struct EpiV1b {
+  const int32_t* __restrict__ ctrl;
+  double* __restrict__ t1u;
+  double* __restrict__ t2u;
+  const double* __restrict__ dinv;
+  double k;
+  __device__ bool skip() const { return ctrl[PC_STOP] != 0; }
+  __device__ void row(int r, double btp) const {
+    const double ku = t1u[r] + btp;
+    t1u[r] = -ku;
+    if (dinv) t2u[r] = k * (dinv[r] * ku);
+  }
+  __device__ void finish(int, double*) const {}
+};
+
+struct EpiV1c {
+  const int32_t* __restrict__ ctrl;
+  double* __restrict__ t1p;
+  double* __restrict__ t2p;
+  __device__ bool skip() const { return ctrl[PC_STOP] != 0; }
+  __device__ void row(int r, double kp) const {
+    t1p[r] = -kp;
+    t2p[r] = kp;
+  }
+  __device__ void finish(int, double*) const {}
+};
+
+struct EpiV3 {  // y += A x ; partial <d, y>
+  const int32_t* __restrict__ ctrl;
+  double* __restrict__ y;
+  const double* __restrict__ d;
+  double* __restrict__ partials;
+  double acc = 0.0;
+  __device__ bool skip() const { return ctrl[PC_STOP] != 0; }
+  __device__ void row(int r, double ax) {
+    const double t = y[r] + ax;
+    y[r] = t;
+    acc = fma(d[r], t, acc);
+  }
+  __device__ void finish(int b, double* lds) {
+    const double s = block_sum(acc, lds);
+    if (threadIdx.x == 0) partials[b] = s;
+  }
+};
+
+struct EpiV5 {
+  const int32_t* __restrict__ ctrl;
+  const double* __restrict__ ap;
+  const double* __restrict__ minv;
+  const double* __restrict__ rp;
+  double* __restrict__ t1p;
+  double* __restrict__ partials;
+  double acc = 0.0;
+  __device__ bool skip() const { return ctrl[PC_STOP] != 0; }
+  __device__ void row(int r, double bau) {
+    const double t = minv[r] * (bau - ap[r]);
+    t1p[r] = t;
+    acc = fma(t, rp[r], acc);
+  }
+  __device__ void finish(int b, double* lds) {
+    const double s = block_sum(acc, lds);
+    if (threadIdx.x == 0) partials[b] = s;
+  }
+};
+
+constexpr int kPSum = 1024;
+// which = 0: loop-top bookkeeping; 1: alpha from sum(pa)+sum(pb); 2: rho_new, beta
+__global__ __launch_bounds__(kPSum) void bpcg1_scalar_kernel(int32_t* __restrict__ ctrl, double* __restrict__ s,
+                                                              double* __restrict__ hist, int which, int it, int na,
+                                                              const double* __restrict__ pa, int nb,
+                                                              const double* __restrict__ pb) {
+  __shared__ double lds[2 * kPSum / kWave];
+  if (ctrl[PC_STOP] != 0) return;
+  const int tid = threadIdx.x;
+  if (which == 0) {
+    if (tid == 0) {
+      const double err = sqrt(fabs(s[P_RHO]));
+      hist[it] = err / s[P_ERR0];
+      ctrl[PC_LAST] = it;
+      if (err < s[P_TOL] * s[P_ERR0]) {
+        ctrl[PC_ITSTOP] = it;
+        ctrl[PC_STOP] = 1;
+      }
+    }
+    return;
+  }
+  double a = 0.0, b = 0.0;
+  for (int i = tid; i < na; i += kPSum) a += pa[i];
+  for (int i = tid; i < nb; i += kPSum) b += pb[i];
+  const double sa = wave_sum(a), sb = wave_sum(b);
+  const int lane = tid & (kWave - 1), wave = tid >> 6;
+  if (lane == 0) {
+    lds[wave] = sa;
+    lds[kPSum / kWave + wave] = sb;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double ta = 0.0, tb = 0.0;
+    for (int w = 0; w < kPSum / kWave; ++w) {
+      ta += lds[w];
+      tb += lds[kPSum / kWave + w];
+    }
+    const double total = ta + tb;
+    if (which == 1) {
+      s[P_DSUM] = total;
+      s[P_ALPHA] = s[P_RHO] / total;
+    } else {
+      s[P_RHON] = total;
+      s[P_BETA] = total / s[P_RHO];
+      s[P_RHO] = total;
+    }
+  }
+}
+
+struct V4Args {
+  const int32_t* ctrl;
+  const double* scal;
+  int32_t n_u, n_p;
+  double *xu, *xp, *ru, *rp, *au, *ap;
+  const double *du, *dp, *t1u, *t1p, *t2u, *t2p;
+  double* partials;
+};
+
+__global__ __launch_bounds__(kBlock) void bpcg1_v4_kernel(V4Args a) {
+  __shared__ double lds[kBlock / kWave];
+  if (a.ctrl[PC_STOP] != 0) return;
+  const double alpha = a.scal[P_ALPHA];
+  const int stride = gridDim.x * kBlock;
+  double acc = 0.0;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < a.n_u; i += stride) {
+    a.xu[i] = fma(alpha, a.du[i], a.xu[i]);
+    const double rn = fma(-alpha, a.t1u[i], a.ru[i]);
+    const double an = fma(-alpha, a.t2u[i], a.au[i]);
+    a.ru[i] = rn;
+    a.au[i] = an;
+    acc = fma(an, rn, acc);
+  }
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < a.n_p; i += stride) {
+    a.xp[i] = fma(alpha, a.dp[i], a.xp[i]);
+    a.rp[i] = fma(-alpha, a.t1p[i], a.rp[i]);
+    a.ap[i] = fma(-alpha, a.t2p[i], a.ap[i]);
+  }
+  const double s = block_sum(acc, lds);
+  if (threadIdx.x == 0) a.partials[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(kBlock) void bpcg1_v6_kernel(const int32_t* __restrict__ ctrl,
+                                                           const double* __restrict__ scal, int32_t n_u, int32_t n_p,
+                                                           double* __restrict__ du, double* __restrict__ dp,
+                                                           const double* __restrict__ au,
+                                                           const double* __restrict__ t1p) {
+  if (ctrl[PC_STOP] != 0) return;
+  const double beta = scal[P_BETA];
+  const int stride = gridDim.x * kBlock;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n_u; i += stride) du[i] = fma(beta, du[i], au[i]);
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n_p; i += stride) dp[i] = fma(beta, dp[i], t1p[i]);
+}
+
+static int p_grid(const nss_bpcg1_t& s) { return stream_grid(int64_t(s.n_u) + s.n_p, kBlock * 4); }
+
+static void bpcg1_check(const nss_bpcg1_t* s) {
+  NSS_REQUIRE(s != nullptr, "bpcg1: NULL state");
+  NSS_REQUIRE(s->A && s->B && s->BT, "bpcg1: NULL matrix handle");
+  NSS_REQUIRE(s->A->m == s->n_u && s->BT->m == s->n_u && s->B->m == s->n_p, "bpcg1: matrix rows do not match n_u/n_p");
+  NSS_REQUIRE(s->A->n == s->n_u && s->B->n == s->n_u && s->BT->n == s->n_p, "bpcg1: matrix columns do not match");
+  NSS_REQUIRE((s->pre_diag != nullptr) != (s->pre_bjac != nullptr), "bpcg1: exactly one of pre_diag / pre_bjac");
+  NSS_REQUIRE(!s->pre_bjac || s->pre_bjac->n == s->n_u, "bpcg1: block-Jacobi size mismatch");
+  NSS_REQUIRE(s->minv && s->scal && s->ctrl && s->hist && s->partials_a && s->partials_b && s->partials_c,
+              "bpcg1: NULL work buffer");
+  for (int c = 0; c < 2; ++c)
+    NSS_REQUIRE(s->x[c] && s->r[c] && s->d[c] && s->a[c] && s->t1[c] && s->t2[c], "bpcg1: NULL vector");
+}
+
+static void bpcg1_iteration(const nss_bpcg1_t& s, int it, hipStream_t st) {
+  hipLaunchKernelGGL(bpcg1_scalar_kernel, dim3(1), dim3(kWave), 0, st, s.ctrl, s.scal, s.hist, 0, it, 0,
+                     s.partials_a, 0, s.partials_b);
+  NSS_CHECK_LAUNCH();
+  launch_csr_stream(*s.A, s.d[0], EpiStore1{s.ctrl, s.t1[0]}, st);
+  launch_csr_stream(*s.BT, s.d[1], EpiV1b{s.ctrl, s.t1[0], s.t2[0], s.pre_diag, s.k}, st);
+  if (s.pre_bjac) bjac_apply(*s.pre_bjac, -s.k, s.t1[0], 0.0, s.t2[0], s.ctrl, st);
+  launch_csr_stream(*s.B, s.d[0], EpiV1c{s.ctrl, s.t1[1], s.t2[1]}, st);
+  launch_csr_stream(*s.A, s.t2[0], EpiV3{s.ctrl, s.t1[0], s.d[0], s.partials_a}, st);
+  launch_csr_stream(*s.B, s.t2[0], EpiV3{s.ctrl, s.t1[1], s.d[1], s.partials_b}, st);
+  hipLaunchKernelGGL(bpcg1_scalar_kernel, dim3(1), dim3(kPSum), 0, st, s.ctrl, s.scal, s.hist, 1, it, s.A->grid(),
+                     s.partials_a, s.B->grid(), s.partials_b);
+  NSS_CHECK_LAUNCH();
+  V4Args a4{s.ctrl, s.scal, s.n_u, s.n_p, s.x[0], s.x[1], s.r[0], s.r[1], s.a[0], s.a[1],
+            s.d[0], s.d[1], s.t1[0], s.t1[1], s.t2[0], s.t2[1], s.partials_c};
+  hipLaunchKernelGGL(bpcg1_v4_kernel, dim3(p_grid(s)), dim3(kBlock), 0, st, a4);
+  NSS_CHECK_LAUNCH();
+  launch_csr_stream(*s.B, s.a[0], EpiV5{s.ctrl, s.a[1], s.minv, s.r[1], s.t1[1], s.partials_b}, st);
+  hipLaunchKernelGGL(bpcg1_scalar_kernel, dim3(1), dim3(kPSum), 0, st, s.ctrl, s.scal, s.hist, 2, it, p_grid(s),
+                     s.partials_c, s.B->grid(), s.partials_b);
+  NSS_CHECK_LAUNCH();
+  hipLaunchKernelGGL(bpcg1_v6_kernel, dim3(p_grid(s)), dim3(kBlock), 0, st, s.ctrl, s.scal, s.n_u, s.n_p, s.d[0],
+                     s.d[1], s.a[0], s.t1[1]);
+  NSS_CHECK_LAUNCH();
+}
+
+}  // namespace nss
+
+using namespace nss;
+
+extern "C" {
+
+int nss_bpcg1_workspace(const nss_bpcg1_t* s, int64_t* partials_a, int64_t* partials_b, int64_t* partials_c) {
+  return guarded([&] {
+    NSS_REQUIRE(s && s->A && s->B, "bpcg1_workspace: NULL state / matrices");
+    if (partials_a) *partials_a = s->A->grid();
+    if (partials_b) *partials_b = s->B->grid();
+    if (partials_c) *partials_c = p_grid(*s);
+  });
+}
+
+int nss_bpcg1_iterate(const nss_bpcg1_t* s, int32_t it_begin, int32_t it_end, nss_stream_t stream) {
+  return guarded([&] {
+    bpcg1_check(s);
+    for (int it = it_begin; it < it_end; ++it) bpcg1_iteration(*s, it, as_stream(stream));
+  });
+}
+
+int nss_bpcg1_poll(const nss_bpcg1_t* s, int32_t* stop, int32_t* it_stop, int32_t* last_it, nss_stream_t stream) {
+  return guarded([&] {
+    NSS_REQUIRE(s && s->ctrl, "bpcg1_poll: NULL state");
+    int32_t h[4] = {0, 0, 0, 0};
+    NSS_HIP(hipMemcpyAsync(h, s->ctrl, sizeof h, hipMemcpyDeviceToHost, as_stream(stream)));
+    NSS_HIP(hipStreamSynchronize(as_stream(stream)));
+    if (stop) *stop = h[PC_STOP];
+    if (it_stop) *it_stop = h[PC_ITSTOP];
+    if (last_it) *last_it = h[PC_LAST];
+  });
+}
+
+}  // extern "C"

@@ -285,3 +285,87 @@ class MinresLoop:
         last_k = k_stop.value if stop.value else maxsteps
         errors = [1.0] + [float(x) for x in eng.to_host(self.hist)[1: last_k + 1]]
         return errors, bool(stop.value and reason.value == 1)
+
+
+class Bpcg1State(C.Structure):
+    """ctypes mirror of ``nss_bpcg1_t`` (include/nss_krylov.h)."""
+    _fields_ = ([(n, C.c_void_p) for n in ("A", "B", "BT", "pre_diag", "pre_bjac", "minv")]
+                + [(n, C.c_void_p * 2) for n in ("x", "r", "d", "a", "t1", "t2")]
+                + [("scal", C.c_void_p), ("ctrl", C.c_void_p), ("hist", C.c_void_p),
+                   ("partials_a", C.c_void_p), ("partials_b", C.c_void_p), ("partials_c", C.c_void_p),
+                   ("k", C.c_double), ("n_u", C.c_int32), ("n_p", C.c_int32)])
+
+
+class Bpcg1Loop:
+    """Device-resident iteration of bramble_pasciak_cg.py:110-143."""
+
+    @classmethod
+    def try_create(cls, a_matrix, b_matrix, c_matrix, pre_a, pre_s, k, vecs):
+        if c_matrix is not None or not (isinstance(a_matrix, SparseMatrix) and isinstance(b_matrix, SparseMatrix)):
+            return None
+        eng = a_matrix.engine
+        if not ENABLED or not _hip(eng) or not hasattr(eng.lib, "nss_bpcg1_iterate"):
+            return None
+        n_u, n_p = a_matrix.height, b_matrix.height
+        if a_matrix.width != n_u or b_matrix.width != n_u:
+            return None
+        pa_d, pa_b, ps = native_diag(pre_a), native_bjac(pre_a), native_diag(pre_s)
+        if ps is None or (pa_d is None and pa_b is None):
+            return None
+        if any(not _block2(vecs.get(name), n_u, n_p) for name in ("x", "r", "d", "a", "t1", "t2")):
+            return None
+        return cls(eng, a_matrix, b_matrix, pa_d, pa_b, ps, k, vecs)
+
+    def __init__(self, eng, A, B, pa_d, pa_b, ps, k, vecs):
+        torch = eng.torch
+        self.eng, self.lib = eng, eng.lib
+        BT = B.CreateTranspose()
+        self.keep = [A, B, BT, pa_d, pa_b, ps, vecs]
+        st = Bpcg1State()
+        st.A, st.B, st.BT = A.handle.ptr, B.handle.ptr, BT.handle.ptr
+        if pa_d is not None:
+            scale, op = pa_d
+            st.pre_diag, st.pre_bjac = op.d.data_ptr(), None
+        else:
+            scale, op = pa_b
+            st.pre_diag, st.pre_bjac = None, op.handle.ptr
+        st.k = float(k) * scale
+        mscale, mop = ps
+        self.minv = mop.d if mscale == 1.0 else mop.d * mscale
+        st.minv = self.minv.data_ptr()
+        for name in ("x", "r", "d", "a", "t1", "t2"):
+            arr = getattr(st, name)
+            for c in range(2):
+                arr[c] = vecs[name][c].buf.data_ptr()
+        st.n_u, st.n_p = A.height, B.height
+        na, nb, nc = C.c_int64(), C.c_int64(), C.c_int64()
+        eng._check(self.lib.nss_bpcg1_workspace(C.byref(st), C.byref(na), C.byref(nb), C.byref(nc)))
+        self.partials = [eng.zeros(max(1, x.value)) for x in (na, nb, nc)]
+        st.partials_a, st.partials_b, st.partials_c = (p.data_ptr() for p in self.partials)
+        self.scal = eng.zeros(8)
+        self.ctrl = torch.zeros(4, dtype=torch.int32, device=eng.device)
+        st.scal, st.ctrl = self.scal.data_ptr(), self.ctrl.data_ptr()
+        self.state = st
+        self.hist = None
+
+    def run(self, rho, err0, tolerance, max_steps, poll_every=None):
+        """Returns (errors, converged): errors[i] = err_i/err_0 as appended at :118."""
+        eng, st = self.eng, self.state
+        poll_every = poll_every or POLL_EVERY
+        self.hist = eng.zeros(max(1, max_steps))
+        st.hist = self.hist.data_ptr()
+        scal = np.zeros(8)
+        scal[0], scal[5], scal[6] = rho, err0, tolerance
+        eng.upload(scal, self.scal)
+        self.ctrl.zero_()
+        stop, it_stop, last = C.c_int32(), C.c_int32(), C.c_int32()
+        it = 0
+        while it < max_steps:
+            end = min(max_steps, it + poll_every)
+            eng._check(self.lib.nss_bpcg1_iterate(C.byref(st), it, end, eng.stream))
+            it = end
+            eng._check(self.lib.nss_bpcg1_poll(C.byref(st), C.byref(stop), C.byref(it_stop), C.byref(last), eng.stream))
+            if stop.value:
+                break
+        count = it_stop.value + 1 if stop.value else max_steps
+        return [float(x) for x in eng.to_host(self.hist)[:count]], bool(stop.value)

@@ -55,6 +55,9 @@ def _signatures():
         "nss_bpcg2_phases": (C.c_int, [vp, i32, i32, i32, vp]),
         "nss_bpcg2_iterate": (C.c_int, [vp, i32, i32, vp]),
         "nss_bpcg2_poll": (C.c_int, [vp, c_i32_p, c_i32_p, c_i32_p, vp]),
+        "nss_bpcg1_workspace": (C.c_int, [vp, c_i64_p, c_i64_p, c_i64_p]),
+        "nss_bpcg1_iterate": (C.c_int, [vp, i32, i32, vp]),
+        "nss_bpcg1_poll": (C.c_int, [vp, c_i32_p, c_i32_p, c_i32_p, vp]),
         "nss_minres_workspace": (C.c_int, [vp, c_i64_p, c_i64_p, c_i64_p]),
         "nss_minres_iterate": (C.c_int, [vp, i32, i32, vp]),
         "nss_minres_poll": (C.c_int, [vp, c_i32_p, c_i32_p, c_i32_p, c_i32_p, vp]),

@@ -411,3 +411,40 @@ def test_fused_minres_is_selected_and_agrees_with_protocol_path(hip_engine):
         assert res["fused"][2] == res["protocol"][2] == bool(d["warned"])
         assert np.linalg.norm(res["fused"][1] - res["protocol"][1]) <= 1e-6 * np.linalg.norm(res["protocol"][1])
         check_solution(res["fused"][1], s, f, g, d)
+
+
+def test_fused_bpcg1_is_selected_and_agrees_with_protocol_path(hip_engine):
+    import hipla
+    from hipla import fused
+    from bramble_pasciak_cg import bramble_pasciak_cg
+    for case in ("stokes3d_n10_bjac_bpcg1", "stokes2d_n24_jacobi_bpcg1"):
+        d = np.load(golden_path(case))
+        s, f, g, A, B, preA, preS = operands(d)
+        res = {}
+        for mode in ("fused", "protocol"):
+            fused.ENABLED = mode == "fused"
+            made = []
+            orig = fused.Bpcg1Loop.try_create.__func__
+
+            def spy(cls, *a, **kw):
+                out = orig(cls, *a, **kw)
+                made.append(out is not None)
+                return out
+
+            fused.Bpcg1Loop.try_create = classmethod(spy)
+            try:
+                with contextlib.redirect_stdout(io.StringIO()):
+                    x, errors = bramble_pasciak_cg(A, B, None, preA, preS, hipla.Vector.from_numpy(f),
+                                                   hipla.Vector.from_numpy(g), tolerance=float(d["tol"]),
+                                                   max_steps=int(d["maxsteps"]), print_rates=False)
+            finally:
+                fused.Bpcg1Loop.try_create = classmethod(orig)
+                fused.ENABLED = True
+            assert made == [mode == "fused"]
+            res[mode] = (np.array(errors), x.numpy())
+        w = int(d["window"])
+        np.testing.assert_allclose(res["fused"][0][:w], res["protocol"][0][:w], rtol=1e-8)
+        check_history(res["fused"][0], d["errors"], d["window"])
+        check_iterations(len(res["fused"][0]) - 1, d["iterations"], d)
+        assert np.linalg.norm(res["fused"][1] - res["protocol"][1]) <= 1e-6 * np.linalg.norm(res["protocol"][1])
+        check_solution(res["fused"][1], s, f, g, d)
