@@ -100,8 +100,24 @@ def main():
     t_asm = time.perf_counter() - t_asm
 
     if world > 1:
-        from distributed import DistributedBpcg2
-        run = DistributedBpcg2(sysm, f, g, blocks, dist, eng)
+        from distributed import DistributedBpcg2, TorchComm
+        comm, comm_kind = None, "torch.distributed/" + backend
+        if backend == "nccl" and os.environ.get("NSS_COMM", "rccl") == "rccl":
+            try:                                   # RCCL straight through ctypes on the compute stream
+                from rccl_comm import RcclComm
+                comm = RcclComm(dist, eng)
+                comm.self_test(torch)
+                comm_kind = "rccl-ctypes"
+            except Exception as exc:               # any doubt -> the torch.distributed data path
+                print("rank %d: RCCL ctypes communicator unavailable (%s); using torch.distributed" % (rank, exc),
+                      file=sys.stderr)
+                comm = None
+        flag = torch.tensor([1.0 if comm is not None else 0.0], dtype=torch.float64, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)      # all ranks must agree on the data path
+        if flag.item() == 0.0:
+            comm, comm_kind = TorchComm(dist, eng), "torch.distributed/" + backend
+        with quiet:
+            run = DistributedBpcg2(sysm, f, g, blocks, dist, eng, comm=comm)
         run.start(tol=0.0, maxsteps=total_its)
         run.iterate(0, W)
         torch.cuda.synchronize()
@@ -129,7 +145,7 @@ def main():
                                        "%d DoF, BPCG v2, %s preA, row-partitioned over %d GPUs"
                                        % (args.n, sysm.ndof, args.pre, world),
                            "n_u": sysm.n_u, "n_p": sysm.n_p, "nnz_A": int(sysm.A.nnz), "nnz_B": int(sysm.B.nnz)},
-                "valid": ok, "halo_doubles_per_rank": run.halo_summary(),
+                "valid": ok, "halo_doubles_per_rank": run.halo_summary(), "comm": comm_kind,
             }
             print(json.dumps(out))
         dist.destroy_process_group()

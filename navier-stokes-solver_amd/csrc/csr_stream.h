@@ -24,6 +24,13 @@
 
 namespace nss {
 
+// Non-temporal loads for the col/val streams: they are read exactly once, and keeping them
+// out of the 4-MiB XCD L2s leaves room for the gathered x window.  Measured on the 1e7-DoF
+// case (interleaved A/B, one box): plain A SpMV 0.173 -> 0.163 ms, BPCG iteration +4 %.
+#ifndef NSS_STREAM_NT
+#define NSS_STREAM_NT 1
+#endif
+
 constexpr int kChunk = 2048;            // products staged per workgroup: 16 KiB of LDS
 constexpr int kMaxRowsPerBlock = 2048;  // bound for blocks of empty / very short rows
 constexpr int kXcds = 8;
@@ -87,8 +94,13 @@ __global__ __launch_bounds__(kBlock) void csr_stream_kernel(CsrView a, const dou
       for (int k = 0; k < kPer; ++k) {
         const int i = tid + k * kBlock;
         const bool live = i < cnt;
+#if NSS_STREAM_NT
+        c[k] = live ? __builtin_nontemporal_load(&a.col[p0 + i]) : 0;
+        v[k] = live ? __builtin_nontemporal_load(&a.val[p0 + i]) : 0.0;
+#else
         c[k] = live ? a.col[p0 + i] : 0;
         v[k] = live ? a.val[p0 + i] : 0.0;
+#endif
       }
       double xv[kPer];
 #pragma unroll

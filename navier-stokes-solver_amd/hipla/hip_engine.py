@@ -18,7 +18,7 @@ from .engine import EngineUnavailable
 
 _LIB_NAME = "libnsskrylov.so"
 _PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG_DIR, _LIB_NAME)
+LIB_PATH = os.environ.get("NSS_LIB_PATH") or os.path.join(_PKG_DIR, _LIB_NAME)   # override: kernel A/B builds
 
 c_double_p = C.POINTER(C.c_double)
 c_i32_p = C.POINTER(C.c_int32)

@@ -57,3 +57,25 @@ def test_fused_distributed_loop_matches_single_gpu(hip_engine, world, dim, n, pr
     assert np.linalg.norm(u - ref["u"]) < 1e-5 * np.linalg.norm(ref["u"])
     p0, pr = p - p.mean(), ref["p"] - ref["p"].mean()
     assert np.linalg.norm(p0 - pr) < 1e-4 * np.linalg.norm(pr)
+
+
+def test_rccl_ctypes_communicator_single_rank(hip_engine, tmp_path):
+    """librccl binds through ctypes in the process that already holds torch's copy; a 1-rank
+    communicator initialises, all-reduces in place and accepts an empty halo exchange.  (Two ranks
+    on one device are refused by RCCL, so multi-rank traffic is covered by the gloo tests.)"""
+    import torch
+    import torch.distributed as dist
+    from rccl_comm import RcclComm
+    dist.init_process_group("gloo", init_method="file://" + str(tmp_path / "rdv"), rank=0, world_size=1)
+    try:
+        comm = RcclComm(dist, hip_engine)
+        comm.size = 2                      # force the RCCL calls (1-rank communicator underneath)
+        x = torch.arange(5, dtype=torch.float64, device=hip_engine.device)
+        comm.allreduce_sum(x)
+        torch.cuda.synchronize()
+        assert x.tolist() == [0.0, 1.0, 2.0, 3.0, 4.0]
+        comm.size = 1
+        comm.self_test(torch)
+        comm.close()
+    finally:
+        dist.destroy_process_group()
