@@ -1,0 +1,152 @@
+"""BASELINE.json configurations at their full sizes on the GPU, checked through size-independent
+properties (the oracle cannot finish these in seconds): adjointness <A x, y> = <x, A y>,
+<B x, p> = <x, B^T p>, linearity, symmetry / positivity of the preconditioners, true residual of
+the solve computed on the host with scipy, monotone MINRES residual estimates -- plus a short
+oracle window at cfg4 (a dozen CPU iterations on the identical matrices)."""
+
+import contextlib
+import io
+import os
+import re
+
+import numpy as np
+import pytest
+
+from staggered_grid import mac_stokes
+
+pytestmark = pytest.mark.gpu
+
+
+class Form:
+    def __init__(self, mat):
+        self.mat, self.condense = mat, False
+
+
+def upload(s, pre="bjac"):
+    import hipla
+    A, B = hipla.SparseMatrix.from_scipy(s.A), hipla.SparseMatrix.from_scipy(s.B)
+    preA = hipla.BlockJacobi(A, s.line_blocks(3)) if pre == "bjac" else hipla.JacobiPreconditioner(A)
+    return A, B, preA, hipla.DiagonalMatrix(1.0 / s.mass)
+
+
+def operator_properties(s, A, B, preA, seed=0):
+    import hipla
+    rng = np.random.default_rng(seed)
+    x, y = (hipla.Vector.from_numpy(rng.standard_normal(s.n_u)) for _ in range(2))
+    p = hipla.Vector.from_numpy(rng.standard_normal(s.n_p))
+    ax, ay, btp, bx, jx = x.CreateVector(), x.CreateVector(), x.CreateVector(), p.CreateVector(), x.CreateVector()
+    ax.data = A * x
+    ay.data = A * y
+    bx.data = B * x
+    btp.data = B.T * p
+    jx.data = preA * x
+    ip = hipla.InnerProduct
+    nx, ny, npp = hipla.Norm(x), hipla.Norm(y), hipla.Norm(p)
+    assert abs(ip(ax, y) - ip(x, ay)) <= 1e-12 * hipla.Norm(ax) * ny            # A symmetric
+    assert abs(ip(bx, p) - ip(x, btp)) <= 1e-12 * hipla.Norm(bx) * npp           # explicit B^T is the adjoint
+    assert ip(ax, x) > 0 and ip(jx, x) > 0                                       # SPD operator / preconditioner
+    z = x.CreateVector()
+    z.data = 2.0 * x - 3.0 * y
+    az = x.CreateVector()
+    az.data = A * z
+    lin = x.CreateVector()
+    lin.data = 2.0 * ax - 3.0 * ay
+    lin.data -= az
+    assert hipla.Norm(lin) <= 1e-12 * (hipla.Norm(ax) + hipla.Norm(ay))           # linearity
+    ones = hipla.Vector(s.n_p)
+    ones[:] = 1.0
+    btp.data = B.T * ones
+    assert hipla.Norm(btp) <= 1e-12 * s.n_p ** 0.5 * abs(s.B).max()              # enclosed flow: B^T 1 = 0
+
+
+def test_cfg2_minres_1e5_dof(hip_engine):
+    """BASELINE config 2: 2-D, n=183, N=100 101, MINRES (fused loop)."""
+    import hipla
+    from minres import MinRes
+    s = mac_stokes(2, 183, 0.01)
+    assert (s.n_u, s.n_p) == (66612, 33489)
+    A, B, preA, preS = upload(s)
+    operator_properties(s, A, B, preA)
+    f, g = s.rhs(0)
+    K = hipla.BlockMatrix([[A, B.T], [B, None]])
+    Cm = hipla.BlockMatrix([[preA, None], [None, preS]])
+    out = io.StringIO()
+    with contextlib.redirect_stdout(out):
+        u, errors = MinRes(mat=K, pre=Cm, rhs=hipla.BlockVector([hipla.Vector.from_numpy(f), hipla.Vector.from_numpy(g)]),
+                           maxsteps=60000, tol=1e-7, printrates=False)
+    errors = np.array(errors)
+    assert "Warning" not in out.getvalue() and errors[-1] < 1e-7
+    assert np.all(np.diff(errors) <= 1e-12)                       # MINRES residual estimates are monotone
+    x = u.numpy()
+    b = np.concatenate([f, g])
+    assert np.linalg.norm(b - s.saddle_matrix() @ x) <= 1e-4 * np.linalg.norm(b)
+
+
+def test_cfg3_bpcg_1e6_dof(hip_engine):
+    """BASELINE config 3: 2-D, n=577, N=997 633, Bramble-Pasciak CG v2 (fused loop)."""
+    import hipla
+    from solvers.bramblepasciak_new import BramblePasciakCG
+    s = mac_stokes(2, 577, 0.01)
+    assert (s.n_u, s.n_p) == (664704, 332929)
+    A, B, preA, preS = upload(s)
+    operator_properties(s, A, B, preA)
+    f, g = s.rhs(0)
+    sol = hipla.BlockVector([hipla.Vector(s.n_u), hipla.Vector(s.n_p)])
+    out = io.StringIO()
+    with contextlib.redirect_stdout(out):
+        it, seconds = BramblePasciakCG(Form(A), Form(B), None, hipla.Vector.from_numpy(f), hipla.Vector.from_numpy(g),
+                                       preA, preS, sol, tol=1e-8, maxsteps=100000, printrates=False)
+    assert "Warning" not in out.getvalue() and it > 100
+    x = sol.numpy()
+    b = np.concatenate([f, g])
+    assert np.linalg.norm(b - s.saddle_matrix() @ x) <= 1e-4 * np.linalg.norm(b)
+    print("cfg3: %d iterations, %.3f s, %.0f it/s" % (it, seconds, it / seconds))
+
+
+def test_cfg4_bpcg_1e7_dof_window_against_oracle(hip_engine):
+    """BASELINE config 4 (the bench workload): 3-D, n=136, N=10 006 336.  Operator properties
+    at full size and the first iterations of the fused loop against the CPU oracle."""
+    import hipla
+    from oracle import krylov_ref as kr
+    from solvers.bramblepasciak_new import BpcgSession
+    s = mac_stokes(3, 136, 0.01)
+    assert (s.n_u, s.n_p) == (7490880, 2515456)
+    A, B, preA, preS = upload(s)
+    operator_properties(s, A, B, preA)
+    f, g = s.rhs(0)
+    sol = hipla.BlockVector([hipla.Vector(s.n_u), hipla.Vector(s.n_p)])
+    with contextlib.redirect_stdout(io.StringIO()):
+        ses = BpcgSession(Form(A), Form(B), None, hipla.Vector.from_numpy(f), hipla.Vector.from_numpy(g), preA, preS,
+                          sol=sol)
+    ses.first_direction()
+    nit = 12
+    it, hist, conv = ses.fused.run(ses.wdn, ses.err0, 0.0, True, nit)
+    assert it == nit - 1 and not conv
+    it_c, u_c, p_c, hist_c, err0_c = kr.bpcg_v2(s.A, s.B, kr.block_jacobi(s.A, s.line_blocks(3)),
+                                               kr.diag_inverse(s.mass), f, g, ses.k, tol=0.0, maxsteps=nit)
+    assert abs(ses.err0 - err0_c) <= 1e-10 * err0_c
+    np.testing.assert_allclose(hist, hist_c, rtol=1e-8)
+    x = sol.numpy()
+    xc = np.concatenate([u_c, p_c])
+    assert np.linalg.norm(x - xc) <= 1e-9 * np.linalg.norm(xc)
+
+
+@pytest.mark.skipif(os.environ.get("NSS_SKIP_HUGE") == "1", reason="NSS_SKIP_HUGE=1")
+def test_cfg5_5e7_dof_operators_and_iterations(hip_engine):
+    """BASELINE config 5: 3-D, n=232, N=49 787 200 (11.5 GB on the device).  Operator properties
+    and 20 finite, decreasing-on-average iterations of the fused loop for Re = 100, 400, 1000
+    (the viscosity only rescales A)."""
+    import hipla
+    from solvers.bramblepasciak_new import BpcgSession
+    s = mac_stokes(3, 232, 0.01)
+    assert (s.n_u, s.n_p) == (37300032, 12487168)
+    A, B, preA, preS = upload(s, pre="jacobi")
+    operator_properties(s, A, B, preA)
+    f, g = s.rhs(0)
+    fv, gv = hipla.Vector.from_numpy(f), hipla.Vector.from_numpy(g)
+    sol = hipla.BlockVector([hipla.Vector(s.n_u), hipla.Vector(s.n_p)])
+    with contextlib.redirect_stdout(io.StringIO()):
+        ses = BpcgSession(Form(A), Form(B), None, fv, gv, preA, preS, sol=sol)
+    ses.first_direction()
+    it, hist, conv = ses.fused.run(ses.wdn, ses.err0, 0.0, True, 20)
+    assert np.all(np.isfinite(hist)) and hist[-1] < hist[0]
