@@ -46,6 +46,27 @@ class Form:
         self.mat, self.condense = mat, False
 
 
+def pmc_traffic(kernel_substring, workload_args):
+    """HBM bytes per launch of the dominant kernel from the latest committed rocprofv3 PMC
+    passes (profiles/*_traffic.json, written by tools/profile_bench.sh on this same command;
+    FETCH_SIZE corrected x2 as MI355X_MICROARCH.md prescribes, calibrated on the triad kernel).
+    None when no profile of this workload is committed."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json"))):
+        try:
+            with open(path) as fh:
+                doc = json.load(fh)
+        except (OSError, ValueError):
+            continue
+        if doc.get("workload") and doc["workload"] != workload_args:
+            continue
+        for name, rec in doc.get("kernels", {}).items():
+            if kernel_substring in name:
+                best = {"bytes": rec["hbm_bytes_per_launch"], "source": os.path.relpath(path, ROOT)}
+    return best
+
+
 def event_time_ms(torch, fn, reps):
     """Average duration of `fn` (one kernel launch on the current stream) from HIP events."""
     start = torch.cuda.Event(enable_timing=True)
@@ -227,6 +248,7 @@ def main():
                   "history_max_rel_diff": float(np.max(np.abs(hist[:m] - hist_c[:m]) / np.abs(hist_c[:m]))),
                   "err0_rel_diff": abs(ses.err0 - err0_c) / err0_c}
 
+    traffic = pmc_traffic("EpiK2", "grid=%d dim=%d pre=%s" % (args.n, args.dim, args.pre))
     out = {
         "metric": "Krylov iters/sec, 3D SIMPLE Stokes solve (BPCG)", "value": K / elapsed, "unit": "iters/s",
         "n_gpus": 1, "steps": K, "warmup": W, "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True,
@@ -238,7 +260,9 @@ def main():
                    "scale_factor_k": ses.k, "device": info["arch"], "cu_count": info["cu_count"]},
         "roofline": {"bound": "hbm", "kernel": "csr_stream_kernel<1, EpiK2> (A SpMV + fused t4 / <s0,v0>)",
                      "achieved": k2_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k2_gbs / HBM_PEAK_GBS,
-                     "traffic": None, "algorithmic_bytes_per_launch": k2_bytes, "avg_launch_ms": k2_ms,
+                     "traffic": traffic["bytes"] if traffic else None,
+                     "traffic_source": traffic["source"] if traffic else None,
+                     "algorithmic_bytes_per_launch": k2_bytes, "avg_launch_ms": k2_ms,
                      "frac_of_stream_triad": k2_gbs / triad_gbs},
         "cpu_baseline": cpu,
         "valid": valid,

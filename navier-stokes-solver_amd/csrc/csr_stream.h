@@ -13,8 +13,8 @@
 //   epilogue a functor consumes (row, A x) -- plain alpha/beta update or the fused
 //            vector updates + dot partials of the Krylov loops -- so y is written once
 //            and the extra vectors are read while the row is still in registers.
-// Row blocks are precomputed on the host when the matrix is uploaded; the default grid has
-// one workgroup per row block (the kernel also accepts a smaller, striding grid).  The
+// Row blocks are precomputed on the host when the matrix is uploaded; one workgroup per row
+// block.  The
 // blockIdx -> row-block map is XCD-aware: workgroups b and b+8 share an XCD (round-robin
 // dispatch), so XCD i walks its own contiguous eighth of the rows and its private 4 MiB
 // L2 keeps one window of x instead of all eight L2s caching the same window.
@@ -58,8 +58,7 @@ struct nss_csr_s {
   nss::CsrView view() const {
     return nss::CsrView{rowblk, rowptr, col, val, nblk, (nblk + nss::kXcds - 1) / nss::kXcds};
   }
-  // one workgroup per row block (the hardware dispatcher balances the tail better than a
-  // persistent grid did: -8 % on the A SpMV), padded to a multiple of the XCD count
+  // one workgroup per row block, padded to a multiple of the XCD count
   int grid() const { return ((nblk + nss::kXcds - 1) / nss::kXcds) * nss::kXcds; }
 };
 
@@ -75,12 +74,12 @@ __global__ __launch_bounds__(kBlock) void csr_stream_kernel(CsrView a, const dou
   __shared__ double red[kBlock / kWave];
   if (epi.skip()) return;
   const int tid = threadIdx.x;
-  // XCD-aware walk: workgroups with equal (blockIdx & 7) share an XCD and stride together
-  // through that XCD's contiguous eighth of the row blocks.
-  const int xcd = blockIdx.x & (kXcds - 1);
-  const int b_end = min((xcd + 1) * a.per_xcd, a.nblk);
-  const int b_step = gridDim.x >> 3;   // == per_xcd for the default grid: one row block each
-  for (int b = xcd * a.per_xcd + (blockIdx.x >> 3); b < b_end; b += b_step) {
+  // XCD-aware map: workgroups with equal (blockIdx & 7) share an XCD; XCD i owns the i-th
+  // contiguous eighth of the row blocks.  One row block per workgroup: a striding
+  // (persistent) loop around this body measured 9 % slower on the A SpMV (extra barrier, and
+  // the hardware dispatcher balances the tail better).
+  const int b = (blockIdx.x & (kXcds - 1)) * a.per_xcd + (blockIdx.x >> 3);
+  if (b < a.nblk) {
     const int r0 = a.rowblk[b];
     const int r1 = a.rowblk[b + 1];
     const int p0 = a.rowptr[r0];
@@ -123,7 +122,6 @@ __global__ __launch_bounds__(kBlock) void csr_stream_kernel(CsrView a, const dou
         }
         if (sub == 0) epi.row(r, sum);
       }
-      __syncthreads();  // prod is rewritten by the next row block
     } else {
       // ---- one row longer than the LDS chunk: the whole workgroup reduces it ----------
       double acc = 0.0;

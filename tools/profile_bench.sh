@@ -12,5 +12,5 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -o ${T
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_fetch -o ${TAG} -- python3 $REPO/bench.py $ARGS > $OUT/${TAG}_fetch.json 2> $OUT/${TAG}_fetch.err || exit 1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_write -o ${TAG} -- python3 $REPO/bench.py $ARGS > $OUT/${TAG}_write.json 2> $OUT/${TAG}_write.err || exit 1
 find $OUT -name "*.csv" | head -50
-python3 $REPO/tools/summarize_prof.py $OUT $TAG > $OUT/${TAG}_summary.md
+python3 $REPO/tools/summarize_prof.py $OUT $TAG $OUT/${TAG}_traffic.json "$ARGS" > $OUT/${TAG}_summary.md
 cat $OUT/${TAG}_summary.md

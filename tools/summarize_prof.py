@@ -70,6 +70,23 @@ def main():
             corr = fr * (cal or 1.0) + wr
             out.append("| %s | %d | %.1f | %.1f | %.1f |" % (short(k), f[k][1], fr, wr, corr))
         out.append("")
+    if fetch and write and len(sys.argv) > 3:
+        import json
+        traffic = {}
+        for k in f:
+            fr = f[k][0] * 1024.0
+            wr = w.get(k, (0.0, 0))[0] * 1024.0
+            traffic[k] = {"launches": f[k][1], "fetch_size_bytes_raw": fr, "write_size_bytes": wr,
+                          "read_correction": cal or 1.0, "hbm_bytes_per_launch": fr * (cal or 1.0) + wr}
+        with open(sys.argv[3], "w") as fh:
+            import re
+            args = sys.argv[4] if len(sys.argv) > 4 else ""
+            grid = re.search(r"--grid\s+(\d+)", args)
+            dim = re.search(r"--dim\s+(\d+)", args)
+            pre = re.search(r"--pre\s+(\w+)", args)
+            workload = "grid=%s dim=%s pre=%s" % (grid.group(1) if grid else "136", dim.group(1) if dim else "3",
+                                                  pre.group(1) if pre else "bjac3")
+            json.dump({"tag": tag, "bench_args": args, "workload": workload, "kernels": traffic}, fh, indent=1)
     print("\n".join(out))
 
 
