@@ -136,9 +136,34 @@ def main():
         flag = torch.tensor([1.0 if comm is not None else 0.0], dtype=torch.float64, device="cuda")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)      # all ranks must agree on the data path
         if flag.item() == 0.0:
-            comm, comm_kind = TorchComm(dist, eng), "torch.distributed/" + backend
+            comm = None
+        torch_comm = TorchComm(dist, eng)
+        if comm is not None:
+            # cross-check: a few iterations of the native loop (RCCL + halo overlap issued from C)
+            # against the same iterations over torch.distributed collectives, from the same state
+            probe_its = 6
+            hists = []
+            for c in (comm, torch_comm):
+                with quiet:
+                    probe = DistributedBpcg2(sysm, f, g, blocks, dist, eng, comm=c)
+                probe.start(tol=0.0, maxsteps=probe_its)
+                probe.iterate(0, probe_its)
+                torch.cuda.synchronize()
+                hists.append(probe.history(probe_its - 1))
+                del probe
+            same = bool(np.all(np.isfinite(hists[0])) and np.allclose(hists[0], hists[1], rtol=1e-9, atol=0.0))
+            flag = torch.tensor([1.0 if same else 0.0], dtype=torch.float64, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if flag.item() == 0.0:
+                print("rank %d: native partitioned loop disagrees with the torch.distributed path; "
+                      "falling back" % rank, file=sys.stderr)
+                comm = None
+        if comm is None:
+            comm, comm_kind = torch_comm, "torch.distributed/" + backend
         with quiet:
             run = DistributedBpcg2(sysm, f, g, blocks, dist, eng, comm=comm)
+        if run.native is not None:
+            comm_kind += " + native loop (interior/boundary overlap)"
         run.start(tol=0.0, maxsteps=total_its)
         run.iterate(0, W)
         torch.cuda.synchronize()

@@ -87,6 +87,8 @@ NSS_API int nss_csr_spmv_f64(nss_csr_t a, double alpha, const double* x, double 
 NSS_API int nss_csr_info(nss_csr_t a, int32_t* nrows, int32_t* ncols, int64_t* nnz,
                          int32_t* nblocks, int32_t* lanes_per_row, int64_t* algorithmic_bytes);
 NSS_API int nss_csr_diagonal(nss_csr_t a, double* diag_dev, nss_stream_t stream);
+/* copy the launch plan to the host: h_out receives nblocks+1 first-row indices (cap = capacity) */
+NSS_API int nss_csr_row_blocks(nss_csr_t a, int32_t* h_out, int64_t cap);
 
 /* ---- preconditioner applies -------------------------------------------------------------
  * point Jacobi / lumped-mass inverse `Preconditioner(m,'local')`
@@ -158,6 +160,42 @@ NSS_API int nss_bpcg2_iterate(const nss_bpcg2_t* s, int32_t it_begin, int32_t it
  * iteration whose history entry was written */
 NSS_API int nss_bpcg2_poll(const nss_bpcg2_t* s, int32_t* done, int32_t* it_final, int32_t* last_it,
                            nss_stream_t stream);
+
+/* ---- row-partitioned BPCG iteration with RCCL issued natively --------------------------------
+ * (multi-GPU; the reference is single-process, so no counterpart.)
+ * One nss_halo_t per SpMV operand of the loop (s1 for B^T, t1 for A, t4 for B): the owned
+ * entries other ranks need are packed (send_idx -> sendbuf), exchanged with grouped
+ * ncclSend / ncclRecv between slab neighbours, and land behind the owned entries of `ext`.
+ * [int_begin, int_end) are the row blocks of the consuming matrix that touch no ghost column:
+ * with overlap != 0 they run while the exchange is in flight on a second stream, the remaining
+ * (boundary) row blocks after it.  Inner products are all-reduced in place in `scal`. */
+typedef struct nss_halo_s {
+  const int32_t* send_idx;     /* DEVICE int32[n_pack]: owned indices to pack                    */
+  double* sendbuf;             /* DEVICE double[n_pack]                                          */
+  double* ext;                 /* DEVICE operand buffer [owned | ghosts]                         */
+  const int32_t* h_send_peer;  /* HOST  int32[n_send]                                            */
+  const int64_t* h_send_off;   /* HOST  int64[n_send]: offsets into sendbuf                      */
+  const int64_t* h_send_cnt;   /* HOST  int64[n_send]                                            */
+  const int32_t* h_recv_peer;  /* HOST  int32[n_recv]                                            */
+  const int64_t* h_recv_off;   /* HOST  int64[n_recv]: offsets into ext (>= n_owned)             */
+  const int64_t* h_recv_cnt;   /* HOST  int64[n_recv]                                            */
+  int32_t n_pack, n_send, n_recv;
+  int32_t int_begin, int_end;  /* interior row blocks of the consuming matrix                   */
+} nss_halo_t;
+
+typedef struct nss_dist_s* nss_dist_t;
+/* `nccl_comm` is an initialised ncclComm_t (created by the host, e.g. through ctypes on librccl);
+ * the library resolves ncclAllReduce / ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd from
+ * the librccl already loaded in the process and creates its communication stream and events. */
+NSS_API int nss_dist_create(void* nccl_comm, int32_t nranks, int32_t rank, nss_dist_t* out);
+NSS_API int nss_dist_destroy(nss_dist_t d);
+/* iterations [it_begin, it_end) of the partitioned loop: per iteration 3 halo exchanges, the
+ * phases of nss_bpcg2_phase split into interior / boundary row blocks, 2 all-reduces.
+ * overlap: 0 = exchange then multiply on `stream`; 1 = interior rows overlap the exchange;
+ * 2 = as 1 but also when this rank has no neighbour (exercises the split path in tests). */
+NSS_API int nss_bpcg2_iterate_dist(const nss_bpcg2_t* s, nss_dist_t d, const nss_halo_t* halo_s1,
+                                   const nss_halo_t* halo_t1, const nss_halo_t* halo_t4, int32_t overlap,
+                                   int32_t it_begin, int32_t it_end, nss_stream_t stream);
 
 /* ---- fused preconditioned MINRES ----------------------------------------------------------
  * Replaces the loop body of minres.py:96-144 for K = [[A, B^T], [B, 0]], C = diag(preA, preS)

@@ -141,6 +141,12 @@ __global__ __launch_bounds__(kBlock) void gather_kernel(int64_t n, const int32_t
   for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride) dst[i] = src[idx[i]];
 }
 
+void gather_launch(int64_t n, const int32_t* idx, const double* src, double* dst, hipStream_t st) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(gather_kernel, dim3(stream_grid(n, kBlock)), dim3(kBlock), 0, st, n, idx, src, dst);
+  NSS_CHECK_LAUNCH();
+}
+
 // ---- dot: stage 1 = per-workgroup partial sums of up to 4 vector pairs ----------------
 struct DotArgs {
   const double* x[4];

@@ -71,7 +71,7 @@ struct EpiV3 {  // y += A x ; partial <d, y>
   }
   __device__ void finish(int b, double* lds) {
     const double s = block_sum(acc, lds);
-    if (threadIdx.x == 0) partials[b] = s;
+    if (threadIdx.x == 0 && b >= 0) partials[b] = s;
   }
 };
 
@@ -91,7 +91,7 @@ struct EpiV5 {
   }
   __device__ void finish(int b, double* lds) {
     const double s = block_sum(acc, lds);
-    if (threadIdx.x == 0) partials[b] = s;
+    if (threadIdx.x == 0 && b >= 0) partials[b] = s;
   }
 };
 
@@ -213,8 +213,8 @@ static void bpcg1_iteration(const nss_bpcg1_t& s, int it, hipStream_t st) {
   launch_csr_stream(*s.B, s.d[0], EpiV1c{s.ctrl, s.t1[1], s.t2[1]}, st);
   launch_csr_stream(*s.A, s.t2[0], EpiV3{s.ctrl, s.t1[0], s.d[0], s.partials_a}, st);
   launch_csr_stream(*s.B, s.t2[0], EpiV3{s.ctrl, s.t1[1], s.d[1], s.partials_b}, st);
-  hipLaunchKernelGGL(bpcg1_scalar_kernel, dim3(1), dim3(kPSum), 0, st, s.ctrl, s.scal, s.hist, 1, it, s.A->grid(),
-                     s.partials_a, s.B->grid(), s.partials_b);
+  hipLaunchKernelGGL(bpcg1_scalar_kernel, dim3(1), dim3(kPSum), 0, st, s.ctrl, s.scal, s.hist, 1, it, s.A->nblk,
+                     s.partials_a, s.B->nblk, s.partials_b);
   NSS_CHECK_LAUNCH();
   V4Args a4{s.ctrl, s.scal, s.n_u, s.n_p, s.x[0], s.x[1], s.r[0], s.r[1], s.a[0], s.a[1],
             s.d[0], s.d[1], s.t1[0], s.t1[1], s.t2[0], s.t2[1], s.partials_c};
@@ -222,7 +222,7 @@ static void bpcg1_iteration(const nss_bpcg1_t& s, int it, hipStream_t st) {
   NSS_CHECK_LAUNCH();
   launch_csr_stream(*s.B, s.a[0], EpiV5{s.ctrl, s.a[1], s.minv, s.r[1], s.t1[1], s.partials_b}, st);
   hipLaunchKernelGGL(bpcg1_scalar_kernel, dim3(1), dim3(kPSum), 0, st, s.ctrl, s.scal, s.hist, 2, it, p_grid(s),
-                     s.partials_c, s.B->grid(), s.partials_b);
+                     s.partials_c, s.B->nblk, s.partials_b);
   NSS_CHECK_LAUNCH();
   hipLaunchKernelGGL(bpcg1_v6_kernel, dim3(p_grid(s)), dim3(kBlock), 0, st, s.ctrl, s.scal, s.n_u, s.n_p, s.d[0],
                      s.d[1], s.a[0], s.t1[1]);
@@ -238,8 +238,8 @@ extern "C" {
 int nss_bpcg1_workspace(const nss_bpcg1_t* s, int64_t* partials_a, int64_t* partials_b, int64_t* partials_c) {
   return guarded([&] {
     NSS_REQUIRE(s && s->A && s->B, "bpcg1_workspace: NULL state / matrices");
-    if (partials_a) *partials_a = s->A->grid();
-    if (partials_b) *partials_b = s->B->grid();
+    if (partials_a) *partials_a = s->A->nblk;
+    if (partials_b) *partials_b = s->B->nblk;
     if (partials_c) *partials_c = p_grid(*s);
   });
 }

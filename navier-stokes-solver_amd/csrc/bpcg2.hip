@@ -78,7 +78,7 @@ struct EpiK2 {
   }
   __device__ void finish(int b, double* lds) {
     const double s = block_sum(acc, lds);
-    if (threadIdx.x == 0) partials[b] = s;
+    if (threadIdx.x == 0 && b >= 0) partials[b] = s;
   }
 };
 
@@ -95,7 +95,7 @@ struct EpiK3 {
   }
   __device__ void finish(int b, double* lds) {
     const double s = block_sum(acc, lds);
-    if (threadIdx.x == 0) partials[b] = s;
+    if (threadIdx.x == 0 && b >= 0) partials[b] = s;
   }
 };
 
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(kBlock) void bpcg2_k5_kernel(const int32_t* __restr
 
 static int k4_grid(const nss_bpcg2_t& s) { return stream_grid(int64_t(s.n_u) + s.n_p, kBlock * 4); }
 
-static void check_state(const nss_bpcg2_t* s) {
+void bpcg2_check_state(const nss_bpcg2_t* s) {
   NSS_REQUIRE(s != nullptr, "bpcg2: NULL state");
   NSS_REQUIRE(s->A && s->B && s->BT, "bpcg2: NULL matrix handle");
   NSS_REQUIRE(s->A->m == s->n_u && s->BT->m == s->n_u && s->B->m == s->n_p, "bpcg2: matrix row counts do not match n_u/n_p");
@@ -228,26 +228,46 @@ static void check_state(const nss_bpcg2_t* s) {
               "bpcg2: NULL vector");
 }
 
-static void phase(const nss_bpcg2_t& s, int which, int it, hipStream_t st) {
+// SpMV phases over the row blocks [b0, b1) of their matrix (b1 < 0: all).  The block-Jacobi
+// apply that completes K1 is a separate step (`bpcg2_k1_finish`) because it needs all of t0.
+void bpcg2_spmv_phase(const nss_bpcg2_t& s, int which, int it, hipStream_t st, int b0, int b1) {
   switch (which) {
     case NSS_BPCG2_K1: {
       EpiK1 e{s.ctrl, s.scal, s.q, s.z0, s.t2, s.s0, s.w0, s.t0, s.t1, s.pre_diag, s.k, it == 0 ? 1 : 0};
-      launch_csr_stream(*s.BT, s.s1, e, st);
-      if (s.pre_bjac) bjac_apply_guarded(*s.pre_bjac, s.k, s.t0, s.t1, s.ctrl, st);
+      launch_csr_stream(*s.BT, s.s1, e, st, b0, b1);
       break;
     }
     case NSS_BPCG2_K2: {
       EpiK2 e{s.ctrl, s.t0, s.t1, s.s0, s.t2, s.t4, s.partials_a};
-      launch_csr_stream(*s.A, s.t1, e, st);
+      launch_csr_stream(*s.A, s.t1, e, st, b0, b1);
       break;
     }
     case NSS_BPCG2_K3: {
       EpiK3 e{s.ctrl, s.s1, s.t3, s.partials_b};
-      launch_csr_stream(*s.B, s.t4, e, st);
+      launch_csr_stream(*s.B, s.t4, e, st, b0, b1);
       break;
     }
+    default:
+      throw Error("bpcg2: not an SpMV phase");
+  }
+}
+
+void bpcg2_k1_finish(const nss_bpcg2_t& s, hipStream_t st) {
+  if (s.pre_bjac) bjac_apply_guarded(*s.pre_bjac, s.k, s.t0, s.t1, s.ctrl, st);
+}
+
+void bpcg2_phase(const nss_bpcg2_t& s, int which, int it, hipStream_t st) {
+  switch (which) {
+    case NSS_BPCG2_K1:
+      bpcg2_spmv_phase(s, which, it, st, 0, -1);
+      bpcg2_k1_finish(s, st);
+      break;
+    case NSS_BPCG2_K2:
+    case NSS_BPCG2_K3:
+      bpcg2_spmv_phase(s, which, it, st, 0, -1);
+      break;
     case NSS_BPCG2_SUM1:
-      hipLaunchKernelGGL(bpcg2_sum_kernel, dim3(1), dim3(kSumBlock), 0, st, s.ctrl, s.A->grid(), s.partials_a, s.B->grid(),
+      hipLaunchKernelGGL(bpcg2_sum_kernel, dim3(1), dim3(kSumBlock), 0, st, s.ctrl, s.A->nblk, s.partials_a, s.B->nblk,
                          s.partials_b, s.scal, int(S_AS));
       NSS_CHECK_LAUNCH();
       break;
@@ -290,33 +310,33 @@ extern "C" {
 int nss_bpcg2_workspace(const nss_bpcg2_t* s, int64_t* partials_a, int64_t* partials_b, int64_t* partials_c) {
   return guarded([&] {
     NSS_REQUIRE(s && s->A && s->B, "bpcg2_workspace: NULL state / matrices");
-    if (partials_a) *partials_a = s->A->grid();
-    if (partials_b) *partials_b = s->B->grid();
+    if (partials_a) *partials_a = s->A->nblk;
+    if (partials_b) *partials_b = s->B->nblk;
     if (partials_c) *partials_c = k4_grid(*s);
   });
 }
 
 int nss_bpcg2_phase(const nss_bpcg2_t* s, int32_t which, int32_t it, nss_stream_t stream) {
   return guarded([&] {
-    check_state(s);
-    phase(*s, which, it, as_stream(stream));
+    bpcg2_check_state(s);
+    bpcg2_phase(*s, which, it, as_stream(stream));
   });
 }
 
 int nss_bpcg2_phases(const nss_bpcg2_t* s, int32_t first, int32_t last, int32_t it, nss_stream_t stream) {
   return guarded([&] {
-    check_state(s);
+    bpcg2_check_state(s);
     NSS_REQUIRE(first >= NSS_BPCG2_K1 && last <= NSS_BPCG2_K5 && first <= last, "bpcg2_phases: bad phase range");
-    for (int ph = first; ph <= last; ++ph) phase(*s, ph, it, as_stream(stream));
+    for (int ph = first; ph <= last; ++ph) bpcg2_phase(*s, ph, it, as_stream(stream));
   });
 }
 
 int nss_bpcg2_iterate(const nss_bpcg2_t* s, int32_t it_begin, int32_t it_end, nss_stream_t stream) {
   return guarded([&] {
-    check_state(s);
+    bpcg2_check_state(s);
     hipStream_t st = as_stream(stream);
     for (int it = it_begin; it < it_end; ++it)
-      for (int ph = NSS_BPCG2_K1; ph <= NSS_BPCG2_K5; ++ph) phase(*s, ph, it, st);
+      for (int ph = NSS_BPCG2_K1; ph <= NSS_BPCG2_K5; ++ph) bpcg2_phase(*s, ph, it, st);
   });
 }
 

@@ -40,7 +40,8 @@ struct CsrView {
   const int32_t* __restrict__ rowptr;
   const int32_t* __restrict__ col;
   const double* __restrict__ val;
-  int32_t nblk;
+  int32_t blk0;     // first row block of this launch (sub-range launches: interior / boundary)
+  int32_t nblk;     // row blocks in this launch
   int32_t per_xcd;  // ceil(nblk / 8)
 };
 
@@ -55,18 +56,21 @@ struct nss_csr_s {
   int32_t* rowblk = nullptr;
   int32_t nblk = 0;
   int32_t rg = 1;
-  nss::CsrView view() const {
-    return nss::CsrView{rowblk, rowptr, col, val, nblk, (nblk + nss::kXcds - 1) / nss::kXcds};
+  // launch view of the row blocks [b0, b1)
+  nss::CsrView view(int b0, int b1) const {
+    return nss::CsrView{rowblk, rowptr, col, val, b0, b1 - b0, (b1 - b0 + nss::kXcds - 1) / nss::kXcds};
   }
   // one workgroup per row block, padded to a multiple of the XCD count
-  int grid() const { return ((nblk + nss::kXcds - 1) / nss::kXcds) * nss::kXcds; }
+  static int grid(int count) { return ((count + nss::kXcds - 1) / nss::kXcds) * nss::kXcds; }
 };
 
 namespace nss {
 
 // Epi interface:
 //   __device__ void row(int r, double ax);          // called once per row by one lane
-//   __device__ void finish(int block, double* lds); // called by all threads at the end
+//   __device__ void finish(int b, double* lds);     // called by all threads at the end; b = row
+//                                                   // block of this workgroup (-1: padding), the
+//                                                   // slot of its dot partial
 //   __device__ bool skip() const;                   // e.g. solver already converged
 template <int RG, class Epi>
 __global__ __launch_bounds__(kBlock) void csr_stream_kernel(CsrView a, const double* __restrict__ x, Epi epi) {
@@ -78,8 +82,9 @@ __global__ __launch_bounds__(kBlock) void csr_stream_kernel(CsrView a, const dou
   // contiguous eighth of the row blocks.  One row block per workgroup: a striding
   // (persistent) loop around this body measured 9 % slower on the A SpMV (extra barrier, and
   // the hardware dispatcher balances the tail better).
-  const int b = (blockIdx.x & (kXcds - 1)) * a.per_xcd + (blockIdx.x >> 3);
-  if (b < a.nblk) {
+  const int lb = (blockIdx.x & (kXcds - 1)) * a.per_xcd + (blockIdx.x >> 3);
+  const int b = lb < a.nblk ? a.blk0 + lb : -1;
+  if (b >= 0) {
     const int r0 = a.rowblk[b];
     const int r1 = a.rowblk[b + 1];
     const int p0 = a.rowptr[r0];
@@ -130,14 +135,17 @@ __global__ __launch_bounds__(kBlock) void csr_stream_kernel(CsrView a, const dou
       if (tid == 0) epi.row(r0, sum);
     }
   }
-  epi.finish(blockIdx.x, red);  // one dot partial per workgroup
+  epi.finish(b, red);  // one dot partial per row block
 }
 
+// rows of the row blocks [b0, b1) (default: all)
 template <class Epi>
-inline void launch_csr_stream(const nss_csr_s& A, const double* x, const Epi& epi, hipStream_t st) {
-  if (A.m == 0) return;
-  const CsrView v = A.view();
-  const dim3 grid(A.grid()), block(kBlock);
+inline void launch_csr_stream(const nss_csr_s& A, const double* x, const Epi& epi, hipStream_t st, int b0 = 0,
+                              int b1 = -1) {
+  if (b1 < 0) b1 = A.nblk;
+  if (A.m == 0 || b1 <= b0) return;
+  const CsrView v = A.view(b0, b1);
+  const dim3 grid(nss_csr_s::grid(b1 - b0)), block(kBlock);
   switch (A.rg) {
     case 1: hipLaunchKernelGGL((csr_stream_kernel<1, Epi>), grid, block, 0, st, v, x, epi); break;
     case 4: hipLaunchKernelGGL((csr_stream_kernel<4, Epi>), grid, block, 0, st, v, x, epi); break;

@@ -56,7 +56,7 @@ struct EpiMAccDot {  // y (+)= A x ; partial <y, z>
   }
   __device__ void finish(int b, double* lds) {
     const double s = block_sum(acc, lds);
-    if (threadIdx.x == 0) partials[b] = s;
+    if (threadIdx.x == 0 && b >= 0) partials[b] = s;
   }
 };
 
@@ -243,8 +243,8 @@ static void minres_iteration(const nss_minres_t& s, int k, hipStream_t st) {
   launch_csr_stream(*s.A, s.z[zc][0], EpiMStore{s.ctrl, k, s.kz[0]}, st);
   launch_csr_stream(*s.BT, s.z[zc][1], EpiMAccDot{s.ctrl, k, 1, s.kz[0], s.z[zc][0], s.partials_a}, st);
   launch_csr_stream(*s.B, s.z[zc][0], EpiMAccDot{s.ctrl, k, 0, s.kz[1], s.z[zc][1], s.partials_b}, st);
-  hipLaunchKernelGGL(minres_sum_kernel, dim3(1), dim3(kMSum), 0, st, s.ctrl, k, s.BT->grid(), s.partials_a,
-                     s.B->grid(), s.partials_b, s.scal, int(M_DELTA));
+  hipLaunchKernelGGL(minres_sum_kernel, dim3(1), dim3(kMSum), 0, st, s.ctrl, k, s.BT->nblk, s.partials_a,
+                     s.B->nblk, s.partials_b, s.scal, int(M_DELTA));
   NSS_CHECK_LAUNCH();
   MK4Args a4{s.ctrl, s.scal, s.n_u, s.n_p, k, s.kz[0], s.kz[1], s.v[ic][0], s.v[ic][1], s.v[io][0], s.v[io][1],
              s.v[in][0], s.v[in][1], s.z[zn][0], s.z[zn][1], s.pre_diag, s.minv, s.partials_c};
@@ -279,8 +279,8 @@ int nss_minres_workspace(const nss_minres_t* s, int64_t* partials_a, int64_t* pa
   return guarded([&] {
     NSS_REQUIRE(s && s->A && s->B && s->BT, "minres_workspace: NULL state / matrices");
     const int64_t dotg = m_dot_grid(*s);
-    if (partials_a) *partials_a = std::max<int64_t>(s->BT->grid(), dotg);
-    if (partials_b) *partials_b = s->B->grid();
+    if (partials_a) *partials_a = std::max<int64_t>(s->BT->nblk, dotg);
+    if (partials_b) *partials_b = s->B->nblk;
     if (partials_c) *partials_c = m_grid(*s);
   });
 }

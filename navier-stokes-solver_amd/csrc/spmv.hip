@@ -123,6 +123,14 @@ int nss_csr_info(nss_csr_t a, int32_t* nrows, int32_t* ncols, int64_t* nnz, int3
   });
 }
 
+int nss_csr_row_blocks(nss_csr_t a, int32_t* h_out, int64_t cap) {
+  return guarded([&] {
+    NSS_REQUIRE(a != nullptr && h_out != nullptr, "csr_row_blocks: NULL argument");
+    NSS_REQUIRE(cap >= int64_t(a->nblk) + 1, "csr_row_blocks: output too small");
+    NSS_HIP(hipMemcpy(h_out, a->rowblk, sizeof(int32_t) * (size_t(a->nblk) + 1), hipMemcpyDeviceToHost));
+  });
+}
+
 int nss_csr_diagonal(nss_csr_t a, double* diag_dev, nss_stream_t stream) {
   return guarded([&] {
     NSS_REQUIRE(a != nullptr, "csr_diagonal: NULL matrix");

@@ -225,6 +225,54 @@ class DistSparseMatrix(BaseMatrix):
             return
         self.comm.exchange(self.plan, self.pack(hv), hv.ext)
 
+    def interior_row_blocks(self):
+        """[begin, end) of the longest run of row blocks (launch plan of the local CSR) whose rows
+        reference no ghost column: these can be multiplied while the halo is in flight."""
+        rb = self.local.handle.row_blocks().astype(np.int64)
+        loc = self.local_scipy
+        nb = rb.size - 1
+        if nb == 0:
+            return 0, 0
+        ghost_rows = np.zeros(loc.shape[0] + 1, dtype=np.int64)
+        rows_with_ghost = np.unique(np.repeat(np.arange(loc.shape[0]), np.diff(loc.indptr))[loc.indices >= self.n_cols_owned])
+        ghost_rows[rows_with_ghost + 1] = 1
+        csum = np.cumsum(ghost_rows)
+        boundary = (csum[rb[1:]] - csum[rb[:-1]]) > 0
+        best, cur, best_range = 0, 0, (0, 0)
+        for b in range(nb):
+            cur = 0 if boundary[b] else cur + 1
+            if cur > best:
+                best, best_range = cur, (b - cur + 1, b + 1)
+        return best_range
+
+    def native_halo(self, hv, interior=None):
+        """ctypes `nss_halo_t` for operand `hv` of this matrix (keeps its host arrays alive)."""
+        from hipla.fused import HaloStruct
+        plan = self.plan
+        h = HaloStruct()
+        keep = {}
+        sp, so, sc, off = [], [], [], 0
+        for q, c in enumerate(plan.send_counts):
+            if c:
+                sp.append(q), so.append(off), sc.append(int(c))
+            off += int(c)
+        rp, ro, rc, off = [], [], [], plan.n_owned
+        for q, c in enumerate(plan.recv_counts):
+            if c:
+                rp.append(q), ro.append(off), rc.append(int(c))
+            off += int(c)
+        for name, vals, dt in (("h_send_peer", sp, np.int32), ("h_send_off", so, np.int64), ("h_send_cnt", sc, np.int64),
+                               ("h_recv_peer", rp, np.int32), ("h_recv_off", ro, np.int64), ("h_recv_cnt", rc, np.int64)):
+            arr = keep[name] = np.ascontiguousarray(vals, dtype=dt)
+            setattr(h, name, arr.ctypes.data if arr.size else None)
+        h.n_pack, h.n_send, h.n_recv = int(plan.send_idx.size), len(sp), len(rp)
+        h.send_idx = self._send_idx.data_ptr() if plan.send_idx.size else None
+        h.sendbuf = self._sendbuf.data_ptr() if plan.send_idx.size else None
+        h.ext = hv.ext.data_ptr()
+        h.int_begin, h.int_end = interior if interior is not None else self.interior_row_blocks()
+        h._keep = (keep, hv, self)
+        return h
+
     def _operand_for(self, x):
         if isinstance(x, HaloVector) and x.plan is self.plan:
             return x
@@ -384,12 +432,33 @@ class DistributedBpcg2:
         if self.loop is None:
             raise RuntimeError("fused distributed BPCG loop needs the HIP engine and native operands")
         self.halo = {"s1": (ops.BT, self.s1), "t1": (ops.A, self.t1), "t4": (ops.B, self.t4)}
+        self.native = None
+        self.overlap = True
+        comm_handle = getattr(self.comm, "comm", None)         # RcclComm: an ncclComm_t
+        if comm_handle is not None and hasattr(self.loop.lib, "nss_bpcg2_iterate_dist"):
+            self.enable_native(comm_handle)
+
+    def enable_native(self, comm_handle, interior=None):
+        """Issue the partitioned iterations from C (nss_bpcg2_iterate_dist): RCCL calls, halo
+        packs, events and the interior/boundary split without Python in the loop."""
+        import ctypes as C
+        handle = C.c_void_p()
+        eng = self.engine
+        eng._check(eng.lib.nss_dist_create(comm_handle, self.comm.size, self.comm.rank, C.byref(handle)))
+        ops = self.ops
+        interior = interior or {}
+        halos = (ops.BT.native_halo(self.s1, interior.get("s1")), ops.A.native_halo(self.t1, interior.get("t1")),
+                 ops.B.native_halo(self.t4, interior.get("t4")))
+        self.native = (handle, halos)
 
     def start(self, tol, maxsteps, rel_err=True):
         self.first_direction()
         self.loop.start(self.wdn, self.err0, tol, rel_err, maxsteps)
 
     def iterate(self, it_begin, it_end):
+        if self.native is not None:
+            self.loop.enqueue_dist(self.native[0], self.native[1], self.overlap, it_begin, it_end)
+            return
         loop, comm = self.loop, self.comm
         for it in range(it_begin, it_end):
             for kind, what in self.SCHEDULE:

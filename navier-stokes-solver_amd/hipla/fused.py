@@ -32,6 +32,15 @@ class Bpcg2State(C.Structure):
                    ("k", C.c_double), ("n_u", C.c_int32), ("n_p", C.c_int32)])
 
 
+class HaloStruct(C.Structure):
+    """ctypes mirror of ``nss_halo_t`` (include/nss_krylov.h)."""
+    _fields_ = [("send_idx", C.c_void_p), ("sendbuf", C.c_void_p), ("ext", C.c_void_p),
+                ("h_send_peer", C.c_void_p), ("h_send_off", C.c_void_p), ("h_send_cnt", C.c_void_p),
+                ("h_recv_peer", C.c_void_p), ("h_recv_off", C.c_void_p), ("h_recv_cnt", C.c_void_p),
+                ("n_pack", C.c_int32), ("n_send", C.c_int32), ("n_recv", C.c_int32),
+                ("int_begin", C.c_int32), ("int_end", C.c_int32)]
+
+
 PHASE = {"K1": 1, "K2": 2, "K3": 3, "SUM1": 4, "ALPHA": 5, "K4": 6, "SUM2": 7, "BETA": 8, "K5": 9}
 S_WD, S_AS, S_WDN, S_ALPHA, S_BETA, S_ERR0, S_TOL, S_REL = range(8)
 
@@ -147,6 +156,12 @@ class Bpcg2Loop:
     def phases(self, first, last, it):
         self.eng._check(self.lib.nss_bpcg2_phases(C.byref(self.state), PHASE[first], PHASE[last], int(it),
                                                   self.eng.stream))
+
+    def enqueue_dist(self, dist_handle, halos, overlap, it_begin, it_end):
+        """Row-partitioned iterations issued natively (nss_bpcg2_iterate_dist)."""
+        self.eng._check(self.lib.nss_bpcg2_iterate_dist(C.byref(self.state), dist_handle, C.byref(halos[0]),
+                                                        C.byref(halos[1]), C.byref(halos[2]), int(overlap),
+                                                        int(it_begin), int(it_end), self.eng.stream))
 
     def poll(self):
         """Drain the stream; returns (done, it_final, last_it)."""

@@ -45,6 +45,10 @@ def _signatures():
         "nss_csr_spmv_f64": (C.c_int, [vp, dbl, vp, dbl, vp, vp]),
         "nss_csr_info": (C.c_int, [vp, c_i32_p, c_i32_p, c_i64_p, c_i32_p, c_i32_p, c_i64_p]),
         "nss_csr_diagonal": (C.c_int, [vp, vp, vp]),
+        "nss_csr_row_blocks": (C.c_int, [vp, vp, i64]),
+        "nss_dist_create": (C.c_int, [vp, i32, i32, C.POINTER(vp)]),
+        "nss_dist_destroy": (C.c_int, [vp]),
+        "nss_bpcg2_iterate_dist": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, vp]),
         "nss_diag_apply_f64": (C.c_int, [i64, vp, dbl, vp, dbl, vp, vp]),
         "nss_bjac_create": (C.c_int, [vp, i32, i32, vp, C.POINTER(vp)]),
         "nss_bjac_destroy": (C.c_int, [vp]),
@@ -91,6 +95,13 @@ class NssError(RuntimeError):
 class _CsrHandle:
     def __init__(self, engine, ptr, m, n, nnz):
         self.engine, self.ptr, self.m, self.n, self.nnz = engine, ptr, m, n, nnz
+
+    def row_blocks(self):
+        """First row of every row block of the launch plan (host array, length nblocks + 1)."""
+        nb = self.info()["row_blocks"]
+        out = np.zeros(nb + 1, dtype=np.int32)
+        self.engine._check(self.engine.lib.nss_csr_row_blocks(self.ptr, out.ctypes.data, out.size))
+        return out
 
     def info(self):
         lib = self.engine.lib

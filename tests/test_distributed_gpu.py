@@ -79,3 +79,69 @@ def test_rccl_ctypes_communicator_single_rank(hip_engine, tmp_path):
         comm.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_native_partitioned_loop_split_and_streams_single_rank(hip_engine, tmp_path):
+    """nss_bpcg2_iterate_dist on a 1-rank RCCL communicator: in-place all-reduces, and (mode 2) the
+    interior / boundary split with the second stream and events.  Partial sums are per row block and
+    added in a fixed order, so every variant must reproduce the single-GPU loop bit for bit."""
+    import torch
+    import torch.distributed as dist
+    from distributed import DistributedBpcg2
+    from rccl_comm import RcclComm
+    dim, n, pre, tol, maxsteps = 3, 12, "bjac", 1e-8, 4000
+    s, ref = single_gpu(dim, n, pre, tol, maxsteps)
+    f, g = s.rhs(0)
+    dist.init_process_group("gloo", init_method="file://" + str(tmp_path / "rdv"), rank=0, world_size=1)
+    try:
+        comm = RcclComm(dist, hip_engine)
+        for overlap, interior in [(0, None), (1, None), (2, None), (2, "middle"), (2, "empty")]:
+            run = DistributedBpcg2(s, f, g, s.line_blocks(3), dist, hip_engine, comm=comm)
+            assert run.native is not None
+            if interior is not None:
+                nbs = {k: m.local.handle.info()["row_blocks"] for k, m in (("s1", run.ops.BT), ("t1", run.ops.A),
+                                                                            ("t4", run.ops.B))}
+                assert min(nbs.values()) >= 3
+                if interior == "middle":      # prefix and suffix boundary blocks around an interior run
+                    interior = {k: (max(1, nb // 4), nb - max(1, nb // 4)) for k, nb in nbs.items()}
+                else:                         # everything is "boundary"
+                    interior = {k: (nb // 2, nb // 2) for k, nb in nbs.items()}
+                run.enable_native(comm.comm, interior)
+            else:
+                nb = run.ops.A.local.handle.info()["row_blocks"]
+                assert run.native[1][1].int_begin == 0 and run.native[1][1].int_end == nb      # no ghosts: all interior
+            run.overlap = overlap
+            it, conv = run.solve(tol=tol, maxsteps=maxsteps, poll_every=16)
+            assert conv and it == ref["it"]
+            np.testing.assert_array_equal(run.history(it), ref["hist"])
+            np.testing.assert_array_equal(run.sol[0].numpy(), ref["u"])
+            np.testing.assert_array_equal(run.sol[1].numpy(), ref["p"])
+        comm.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_interior_row_blocks_of_a_partitioned_matrix(hip_engine):
+    """Row blocks flagged interior must not reference ghost columns; boundary blocks sit at the
+    slab ends (checked on rank 1 of 3 without any communication)."""
+    from distributed import DistSparseMatrix
+    s = mac_stokes(3, 20, 0.01)
+    vel, prs = s.partition(3)
+
+    class FakeComm:
+        rank, size = 1, 3
+
+        def gather_requests(self, mine, compute):
+            return [compute(q) for q in range(3)]
+
+    for mat, rows, cols in ((s.A, vel, vel), (s.B, prs, vel), (s.B.T.tocsr(), vel, prs)):
+        dm = DistSparseMatrix(mat, rows, cols, FakeComm(), hip_engine)
+        b0, b1 = dm.interior_row_blocks()
+        rb = dm.local.handle.row_blocks()
+        loc = dm.local_scipy
+        assert 0 <= b0 < b1 <= rb.size - 1
+        inner = loc[rb[b0]:rb[b1]]
+        assert inner.indices.max() < dm.n_cols_owned                      # interior: owned columns only
+        assert dm.plan.n_ghost > 0 and (b1 - b0) > 0.5 * (rb.size - 1)    # most of the slab is interior
+        h = dm.native_halo(dm.operand())
+        assert (h.int_begin, h.int_end) == (b0, b1) and h.n_recv >= 1 and h.n_send >= 1
