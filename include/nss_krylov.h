@@ -118,7 +118,7 @@ NSS_API int nss_bjac_info(nss_bjac_t j, int32_t* bs, int32_t* nblocks, int64_t* 
  * have A's / B's column count (n_u plus halo entries in a row-partitioned run); n_p for
  * u1,d1,w1,t3 ; s1 is the operand of B^T (B^T's column count).
  * scal: double[8] = { wd, as_s, wdn, alpha, beta, err0, tol, rel_err(0/1) };
- * ctrl: int32[4]  = { done, it_final, last_it, - };  hist: double[maxsteps]. */
+ * ctrl: int32[4]  = { done, it_final, last_it, breakdown };  hist: double[maxsteps]. */
 typedef struct nss_bpcg2_s {
   nss_csr_t A, B, BT;          /* A: n_u rows; B: n_p rows; BT: n_u rows (explicit transpose, :198) */
   const double* pre_diag;      /* point-Jacobi preA (inverse diagonal, n_u)  -- or NULL          */
@@ -156,8 +156,9 @@ NSS_API int nss_bpcg2_phases(const nss_bpcg2_t* s, int32_t first, int32_t last, 
                              nss_stream_t stream);
 /* enqueue iterations [it_begin, it_end) back to back (single GPU): no host synchronisation */
 NSS_API int nss_bpcg2_iterate(const nss_bpcg2_t* s, int32_t it_begin, int32_t it_end, nss_stream_t stream);
-/* wait for the stream and read ctrl: done flag, iteration at which the stop test fired, last
- * iteration whose history entry was written */
+/* wait for the stream and read ctrl: done (0 running, 1 stop test fired, 2 breakdown
+ * <s, K s> == 0 where the reference raises ZeroDivisionError, :226), iteration at which it
+ * happened, last iteration whose history entry was written */
 NSS_API int nss_bpcg2_poll(const nss_bpcg2_t* s, int32_t* done, int32_t* it_final, int32_t* last_it,
                            nss_stream_t stream);
 

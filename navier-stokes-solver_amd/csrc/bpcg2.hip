@@ -27,7 +27,7 @@
 namespace nss {
 
 enum { S_WD = 0, S_AS = 1, S_WDN = 2, S_ALPHA = 3, S_BETA = 4, S_ERR0 = 5, S_TOL = 6, S_REL = 7 };
-enum { C_DONE = 0, C_IT_FINAL = 1, C_LAST_IT = 2 };
+enum { C_DONE = 0, C_IT_FINAL = 1, C_LAST_IT = 2, C_BREAKDOWN = 3 };
 
 struct EpiK1 {
   const int32_t* __restrict__ ctrl;
@@ -151,6 +151,14 @@ __global__ void bpcg2_scalar_kernel(int32_t* __restrict__ ctrl, double* __restri
                                     int which, int it) {
   if (threadIdx.x != 0 || ctrl[C_DONE] != 0) return;
   if (which == 1) {
+    // <s, K^ s> == 0: the reference's `alpha = wd / as_s` (:226) raises ZeroDivisionError in Python;
+    // freeze the state and report it (ctrl[3]) so that the host can raise the same error
+    if (scal[S_AS] == 0.0) {
+      ctrl[C_BREAKDOWN] = 1;
+      ctrl[C_IT_FINAL] = it;
+      ctrl[C_DONE] = 1;
+      return;
+    }
     scal[S_ALPHA] = scal[S_WD] / scal[S_AS];
   } else {
     const double wd = scal[S_WD], wdn = scal[S_WDN];
@@ -344,9 +352,9 @@ int nss_bpcg2_poll(const nss_bpcg2_t* s, int32_t* done, int32_t* it_final, int32
   return guarded([&] {
     NSS_REQUIRE(s && s->ctrl, "bpcg2_poll: NULL state");
     int32_t h[4] = {0, 0, 0, 0};
-    NSS_HIP(hipMemcpyAsync(h, s->ctrl, sizeof(int32_t) * 3, hipMemcpyDeviceToHost, as_stream(stream)));
+    NSS_HIP(hipMemcpyAsync(h, s->ctrl, sizeof(int32_t) * 4, hipMemcpyDeviceToHost, as_stream(stream)));
     NSS_HIP(hipStreamSynchronize(as_stream(stream)));
-    if (done) *done = h[C_DONE];
+    if (done) *done = h[C_DONE] ? (h[C_BREAKDOWN] ? 2 : 1) : 0;   // 2: alpha = wd / 0 breakdown
     if (it_final) *it_final = h[C_IT_FINAL];
     if (last_it) *last_it = h[C_LAST_IT];
   });

@@ -168,6 +168,9 @@ class Bpcg2Loop:
         done, it_final, last = C.c_int32(), C.c_int32(), C.c_int32()
         self.eng._check(self.lib.nss_bpcg2_poll(C.byref(self.state), C.byref(done), C.byref(it_final),
                                                 C.byref(last), self.eng.stream))
+        if done.value == 2:      # the reference's `alpha = wd / as_s` with as_s == 0 (:226)
+            raise ZeroDivisionError("float division by zero (BPCG breakdown <s, K s> = 0 at iteration %d)"
+                                    % it_final.value)
         return bool(done.value), it_final.value, last.value
 
     def history(self, upto):

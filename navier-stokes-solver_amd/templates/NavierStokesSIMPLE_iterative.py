@@ -18,7 +18,23 @@ from hipla import BlockVector
 from discretizations import AssembledForm, SyntheticMesh, assemble, bdm_hybrid
 from solvers.bramblepasciak_new import BramblePasciakCG
 
-__all__ = ["NavierStokes", "SyntheticMesh"]
+__all__ = ["NavierStokes", "SyntheticMesh", "MypreA"]
+
+
+class MypreA(hipla.BlockJacobi):
+    """``MypreA(space, a, jacblocks, GS)`` of the reference
+    (templates/NavierStokesSIMPLE_iterative.py:364-391) restricted to the hot-path part:
+    ``GS=False`` -> additive ``y = J x`` with ``J = a.mat.CreateBlockSmoother(jacblocks)`` (:373,383).
+    The auxiliary-space term ``transform @ preAh1 @ transform.T`` (:380,383) needs the AMG
+    hierarchy (scope row N3) and is absent; ``GS=True`` (:376-381) is scope row N1.
+    Being a `BlockJacobi`, it is recognised by the fused device-resident loops."""
+
+    def __init__(self, space, a, jacblocks, GS):
+        if GS:
+            raise NotImplementedError("multiplicative block Gauss-Seidel sweep: SURVEY.md section 8f row N1")
+        super().__init__(a.mat, jacblocks)
+        self.space, self.GS = space, GS
+        self.temp = a.mat.CreateColVector()
 
 
 class NavierStokes:
@@ -53,7 +69,7 @@ class NavierStokes:
         blfA = AssembledForm(self.a.mat)
         blfB = AssembledForm(self.b.mat)
         preM = hipla.Preconditioner(self.mp, "local")
-        preA = hipla.Preconditioner(blfA, "blockjacobi", blocks=self.system.facet_blocks())
+        preA = MypreA(self.V, blfA, self.system.facet_blocks(), GS=GS)
         sol = BlockVector([self.gfu, self.gfup])       # aliases the grid-function storage (:206)
         out = BramblePasciakCG(blfA, blfB, None, self.f.vec, self.g.vec, preA, preM, sol, initialize=False,
                                tol=tol, maxsteps=maxsteps, rel_err=True, printrates=printrates)

@@ -448,3 +448,22 @@ def test_fused_bpcg1_is_selected_and_agrees_with_protocol_path(hip_engine):
         check_iterations(len(res["fused"][0]) - 1, d["iterations"], d)
         assert np.linalg.norm(res["fused"][1] - res["protocol"][1]) <= 1e-6 * np.linalg.norm(res["protocol"][1])
         check_solution(res["fused"][1], s, f, g, d)
+
+
+def test_fused_bpcg2_breakdown_raises_like_the_reference(hip_engine):
+    """<s, K^ s> == 0 makes the reference's `alpha = wd / as_s` raise ZeroDivisionError
+    (solvers/bramblepasciak_new.py:226); the fused loop freezes and the host raises the same."""
+    import hipla
+    from solvers.bramblepasciak_new import BpcgSession
+    d = np.load(golden_path("stokes2d_n12_jacobi_bpcg2"))
+    s, f, g, A, B, preA, preS = operands(d)
+    sol = hipla.BlockVector([hipla.Vector(s.n_u), hipla.Vector(s.n_p)])
+    with contextlib.redirect_stdout(io.StringIO()):
+        ses = BpcgSession(Form(A), Form(B), None, hipla.Vector.from_numpy(f), hipla.Vector.from_numpy(g), preA, preS,
+                          sol=sol)
+    ses.s[0][:] = 0.0                 # direction s = 0  ->  <s, K^ s> = 0 in the first iteration
+    ses.s[1][:] = 0.0
+    ses.first_direction()
+    with pytest.raises(ZeroDivisionError):
+        ses.fused.run(ses.wdn, ses.err0, 1e-8, True, 50)
+    assert np.all(sol.numpy() == 0.0)           # state frozen before any update
