@@ -107,6 +107,19 @@ NSS_API int nss_bjac_destroy(nss_bjac_t j);
 NSS_API int nss_bjac_apply_f64(nss_bjac_t j, double alpha, const double* x, double beta, double* y,
                                nss_stream_t stream);
 NSS_API int nss_bjac_info(nss_bjac_t j, int32_t* bs, int32_t* nblocks, int64_t* n, int64_t* algorithmic_bytes);
+/* multiplicative block Gauss-Seidel sweeps `jacobi.Smooth(y, x)` / `jacobi.SmoothBack(y, x)`
+ * (templates/NavierStokesSIMPLE_iterative.py:376-381) over a
+ * MULTICOLOUR block ordering: the handle's blocks [h_color_ptr[c], h_color_ptr[c+1]) carry colour
+ * c and must not be coupled to each other through `a` (the host colours the block graph and
+ * creates the handle with its blocks in colour-major order).  All blocks of a colour update in
+ * parallel: y_b += A_bb^-1 (xscale * x_b - (a y)_b). */
+NSS_API int nss_bjac_set_colors(nss_bjac_t j, nss_csr_t a, int32_t ncolors, const int32_t* h_color_ptr);
+/* one sweep: colours ascending (backward == 0) or descending */
+NSS_API int nss_bjac_smooth_f64(nss_bjac_t j, double xscale, const double* x, double* y, int32_t backward,
+                                nss_stream_t stream);
+/* symmetric sweep as an operator: y = 0; forward sweep; backward sweep */
+NSS_API int nss_bjac_symgs_apply_f64(nss_bjac_t j, double xscale, const double* x, double* y,
+                                     nss_stream_t stream);
 
 /* ---- fused Bramble-Pasciak CG, recurrence-optimised form ---------------------------------
  * Replaces the loop body of solvers/bramblepasciak_new.py:200-249 (the solver the SIMPLE

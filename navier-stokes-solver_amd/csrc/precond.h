@@ -3,6 +3,8 @@
 
 #include "csr_stream.h"
 
+#include <vector>
+
 struct nss_bjac_s {
   int32_t bs = 0, nblocks = 0;
   int64_t n = 0;
@@ -10,6 +12,9 @@ struct nss_bjac_s {
   double* inv = nullptr;       // [bs*bs][nblocks]
   int32_t* covered = nullptr;  // dofs that belong to no block (count: n_uncovered)
   int32_t n_uncovered = 0;
+  // multicolour Gauss-Seidel mode (nss_bjac_set_colors): blocks are stored colour-major
+  const nss_csr_s* gs_mat = nullptr;
+  std::vector<int32_t> color_ptr;  // ncolors + 1 block offsets (host)
 };
 
 namespace nss {
@@ -20,5 +25,12 @@ constexpr int kMaxBs = 16;
 // `done` (device int, may be NULL) is non-zero.
 void bjac_apply(const nss_bjac_s& j, double alpha, const double* x, double beta, double* y, const int32_t* done,
                 hipStream_t st);
+
+
+// one multicolour block Gauss-Seidel sweep / the symmetric pair as an operator (y = 0 first)
+void bjac_smooth(const nss_bjac_s& j, double xscale, const double* x, double* y, bool backward, const int32_t* done,
+                 hipStream_t st);
+void bjac_symgs_apply(const nss_bjac_s& j, double xscale, const double* x, double* y, const int32_t* done,
+                      hipStream_t st);
 
 }  // namespace nss

@@ -109,6 +109,78 @@ __global__ __launch_bounds__(kBlock) void bjac_uncovered_kernel(int32_t count, c
   y[d] = beta == 0.0 ? 0.0 : beta * y[d];
 }
 
+// One colour of a multicolour block Gauss-Seidel sweep: one lane per block of the colour.
+// Residual rows first (CSR row walks over the current y), then the dense block solve; blocks
+// of one colour are uncoupled, so no lane reads what another lane of this launch writes.
+template <int BS>
+__global__ __launch_bounds__(kBlock) void bgs_color_kernel(int32_t b0, int32_t b1, int32_t nb,
+                                                            const int32_t* __restrict__ idx,
+                                                            const double* __restrict__ inv,
+                                                            const int32_t* __restrict__ rowptr,
+                                                            const int32_t* __restrict__ col,
+                                                            const double* __restrict__ val, double xscale,
+                                                            const double* __restrict__ x, double* y,
+                                                            const int32_t* __restrict__ done) {
+  if (done && done[0] != 0) return;
+  const int b = b0 + blockIdx.x * kBlock + threadIdx.x;
+  if (b >= b1) return;
+  int32_t dof[BS];
+  double res[BS];
+#pragma unroll
+  for (int r = 0; r < BS; ++r) dof[r] = idx[size_t(r) * nb + b];
+#pragma unroll
+  for (int r = 0; r < BS; ++r) {
+    double acc = 0.0;
+    if (dof[r] >= 0) {
+      acc = xscale * x[dof[r]];
+      for (int p = rowptr[dof[r]]; p < rowptr[dof[r] + 1]; ++p) acc = fma(-val[p], y[col[p]], acc);
+    }
+    res[r] = acc;
+  }
+#pragma unroll
+  for (int r = 0; r < BS; ++r) {
+    if (dof[r] < 0) continue;
+    double s = 0.0;
+#pragma unroll
+    for (int c = 0; c < BS; ++c) s = fma(inv[(size_t(r) * BS + c) * nb + b], res[c], s);
+    y[dof[r]] += s;
+  }
+}
+
+template <int BS>
+static void launch_bgs_color(const nss_bjac_s& j, int c, double xscale, const double* x, double* y,
+                             const int32_t* done, hipStream_t st) {
+  const int b0 = j.color_ptr[c], b1 = j.color_ptr[c + 1];
+  if (b1 <= b0) return;
+  const nss_csr_s& a = *j.gs_mat;
+  hipLaunchKernelGGL((bgs_color_kernel<BS>), dim3((b1 - b0 + kBlock - 1) / kBlock), dim3(kBlock), 0, st, b0, b1,
+                     j.nblocks, j.idx, j.inv, a.rowptr, a.col, a.val, xscale, x, y, done);
+}
+
+void bjac_smooth(const nss_bjac_s& j, double xscale, const double* x, double* y, bool backward, const int32_t* done,
+                 hipStream_t st) {
+  if (!j.gs_mat) throw Error("bjac_smooth: colours not set (nss_bjac_set_colors)");
+  const int nc = int(j.color_ptr.size()) - 1;
+  for (int k = 0; k < nc; ++k) {
+    const int c = backward ? nc - 1 - k : k;
+    switch (j.bs) {
+#define NSS_GS(N) case N: launch_bgs_color<N>(j, c, xscale, x, y, done, st); break;
+      NSS_GS(1) NSS_GS(2) NSS_GS(3) NSS_GS(4) NSS_GS(5) NSS_GS(6) NSS_GS(7) NSS_GS(8)
+      NSS_GS(9) NSS_GS(10) NSS_GS(11) NSS_GS(12) NSS_GS(13) NSS_GS(14) NSS_GS(15) NSS_GS(16)
+#undef NSS_GS
+      default: throw Error("bjac_smooth: unsupported block size");
+    }
+    NSS_CHECK_LAUNCH();
+  }
+}
+
+void bjac_symgs_apply(const nss_bjac_s& j, double xscale, const double* x, double* y, const int32_t* done,
+                      hipStream_t st) {
+  NSS_HIP(hipMemsetAsync(y, 0, sizeof(double) * size_t(j.n), st));   // y[:] = 0 (:377)
+  bjac_smooth(j, xscale, x, y, false, done, st);                     // jacobi.Smooth(y, x)      (:378)
+  bjac_smooth(j, xscale, x, y, true, done, st);                      // jacobi.SmoothBack(y, x)  (:381)
+}
+
 template <int BS>
 static void launch_bjac(const nss_bjac_s& j, double alpha, const double* x, double beta, double* y,
                         const int32_t* done, hipStream_t st) {
@@ -119,6 +191,11 @@ static void launch_bjac(const nss_bjac_s& j, double alpha, const double* x, doub
 
 void bjac_apply(const nss_bjac_s& j, double alpha, const double* x, double beta, double* y, const int32_t* done,
                 hipStream_t st) {
+  if (j.gs_mat) {  // a handle in Gauss-Seidel mode is the symmetric sweep operator
+    if (beta != 0.0) throw Error("bjac_apply: Gauss-Seidel mode supports beta == 0 only");
+    bjac_symgs_apply(j, alpha, x, y, done, st);
+    return;
+  }
   switch (j.bs) {
 #define NSS_BJ(N) case N: launch_bjac<N>(j, alpha, x, beta, y, done, st); break;
     NSS_BJ(1) NSS_BJ(2) NSS_BJ(3) NSS_BJ(4) NSS_BJ(5) NSS_BJ(6) NSS_BJ(7) NSS_BJ(8)
@@ -206,6 +283,36 @@ int nss_bjac_apply_f64(nss_bjac_t j, double alpha, const double* x, double beta,
     NSS_REQUIRE(j != nullptr, "bjac_apply: NULL handle");
     NSS_REQUIRE(x != y, "bjac_apply: x must not alias y");
     bjac_apply(*j, alpha, x, beta, y, nullptr, as_stream(stream));
+  });
+}
+
+int nss_bjac_set_colors(nss_bjac_t j, nss_csr_t a, int32_t ncolors, const int32_t* h_color_ptr) {
+  return guarded([&] {
+    NSS_REQUIRE(j != nullptr && a != nullptr && h_color_ptr != nullptr, "bjac_set_colors: NULL argument");
+    NSS_REQUIRE(a->m == a->n && a->m == j->n, "bjac_set_colors: matrix does not match the blocks");
+    NSS_REQUIRE(ncolors >= 1, "bjac_set_colors: need at least one colour");
+    NSS_REQUIRE(h_color_ptr[0] == 0 && h_color_ptr[ncolors] == j->nblocks, "bjac_set_colors: colour offsets must span the blocks");
+    for (int c = 0; c < ncolors; ++c)
+      NSS_REQUIRE(h_color_ptr[c + 1] >= h_color_ptr[c], "bjac_set_colors: colour offsets not monotone");
+    j->gs_mat = a;
+    j->color_ptr.assign(h_color_ptr, h_color_ptr + ncolors + 1);
+  });
+}
+
+int nss_bjac_smooth_f64(nss_bjac_t j, double xscale, const double* x, double* y, int32_t backward,
+                        nss_stream_t stream) {
+  return guarded([&] {
+    NSS_REQUIRE(j != nullptr, "bjac_smooth: NULL handle");
+    NSS_REQUIRE(x != y, "bjac_smooth: x must not alias y");
+    bjac_smooth(*j, xscale, x, y, backward != 0, nullptr, as_stream(stream));
+  });
+}
+
+int nss_bjac_symgs_apply_f64(nss_bjac_t j, double xscale, const double* x, double* y, nss_stream_t stream) {
+  return guarded([&] {
+    NSS_REQUIRE(j != nullptr, "bjac_symgs_apply: NULL handle");
+    NSS_REQUIRE(x != y, "bjac_symgs_apply: x must not alias y");
+    bjac_symgs_apply(*j, xscale, x, y, nullptr, as_stream(stream));
   });
 }
 

@@ -1,0 +1,73 @@
+"""Multicolour ordering of block-Jacobi blocks for the parallel block Gauss-Seidel sweep
+(SURVEY.md section 8f row N1).
+
+Two blocks are *coupled* when the matrix has an entry between their dofs; blocks of one colour
+must be pairwise uncoupled so that a whole colour can be updated in one kernel launch.  The
+colouring is a sequence of maximal independent sets (Luby's algorithm with fixed pseudo-random
+priorities), fully vectorised with scipy/numpy so that millions of blocks colour in seconds.
+Host-side set-up code, deterministic for a given seed."""
+
+import numpy as np
+import scipy.sparse as sp
+
+
+def block_graph(csr, idx):
+    """Adjacency (nblocks x nblocks, CSR, no diagonal) of the blocks `idx` (bs, nblocks; -1 pad)
+    induced by the sparsity of `csr`."""
+    n = csr.shape[0]
+    bs, nb = idx.shape
+    live = idx >= 0
+    dofs = idx[live]
+    blocks = np.broadcast_to(np.arange(nb, dtype=np.int64), idx.shape)[live]
+    member = sp.csr_matrix((np.ones(dofs.size, dtype=np.float64), (dofs, blocks)), shape=(n, nb))
+    pattern = sp.csr_matrix((np.ones(csr.nnz), csr.indices, csr.indptr), shape=csr.shape)
+    g = (member.T @ pattern @ member).tocsr()
+    g = g + g.T
+    g.setdiag(0)
+    g.eliminate_zeros()
+    g.sort_indices()
+    return g
+
+
+def _neighbour_max(g, values, fill):
+    """max over graph neighbours of `values` (fill for isolated nodes)."""
+    out = np.full(g.shape[0], fill, dtype=values.dtype)
+    deg = np.diff(g.indptr)
+    has = deg > 0
+    if g.nnz:
+        red = np.maximum.reduceat(values[g.indices], g.indptr[:-1][has])
+        out[has] = red
+    return out
+
+
+def color_blocks(g, seed=0):
+    """Colours (int32 per block), each colour a maximal independent set of the remaining graph."""
+    nb = g.shape[0]
+    rng = np.random.default_rng(seed)
+    priority = rng.permutation(nb).astype(np.int64) + 1          # distinct, > 0
+    colors = -np.ones(nb, dtype=np.int32)
+    c = 0
+    while np.any(colors < 0):
+        cand = colors < 0
+        chosen = np.zeros(nb, dtype=bool)
+        while cand.any():
+            pri = np.where(cand, priority, 0)
+            winners = cand & (pri > _neighbour_max(g, pri, 0))
+            chosen |= winners
+            hit = _neighbour_max(g, winners.astype(np.int64), 0) > 0
+            cand &= ~winners & ~hit
+        colors[chosen] = c
+        c += 1
+    return colors
+
+
+def colour_major_order(colors):
+    """Permutation that sorts blocks by colour (stable) and the colour offsets."""
+    order = np.argsort(colors, kind="stable")
+    ptr = np.concatenate([[0], np.cumsum(np.bincount(colors, minlength=int(colors.max()) + 1))]).astype(np.int32)
+    return order, ptr
+
+
+def check_coloring(g, colors):
+    coo = g.tocoo()
+    return not np.any(colors[coo.row] == colors[coo.col])

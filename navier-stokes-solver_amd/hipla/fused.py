@@ -15,7 +15,7 @@ import os
 
 import numpy as np
 
-from .matrix import BlockJacobi, BlockMatrix, DiagonalMatrix, ScaledMatrix, SparseMatrix
+from .matrix import BlockGaussSeidel, BlockJacobi, BlockMatrix, DiagonalMatrix, ScaledMatrix, SparseMatrix
 from .vector import BlockVector, Vector
 
 POLL_EVERY = int(os.environ.get("NSS_POLL_EVERY", "32"))
@@ -60,10 +60,12 @@ def native_diag(op):
 
 
 def native_bjac(op):
+    """(scale, op) for a (scaled) block-Jacobi or symmetric block Gauss-Seidel preconditioner: both
+    own an ``nss_bjac_t`` handle (the latter in Gauss-Seidel mode), which the fused loops apply."""
     scale = 1.0
     if isinstance(op, ScaledMatrix):
         scale, op = op.scale, op.mat
-    if isinstance(op, BlockJacobi):
+    if isinstance(op, (BlockJacobi, BlockGaussSeidel)):
         return scale, op
     return None
 

@@ -54,6 +54,9 @@ def _signatures():
         "nss_bjac_destroy": (C.c_int, [vp]),
         "nss_bjac_apply_f64": (C.c_int, [vp, dbl, vp, dbl, vp, vp]),
         "nss_bjac_info": (C.c_int, [vp, c_i32_p, c_i32_p, c_i64_p, c_i64_p]),
+        "nss_bjac_set_colors": (C.c_int, [vp, vp, i32, vp]),
+        "nss_bjac_smooth_f64": (C.c_int, [vp, dbl, vp, vp, i32, vp]),
+        "nss_bjac_symgs_apply_f64": (C.c_int, [vp, dbl, vp, vp, vp]),
         "nss_bpcg2_workspace": (C.c_int, [vp, c_i64_p, c_i64_p, c_i64_p]),
         "nss_bpcg2_phase": (C.c_int, [vp, i32, i32, vp]),
         "nss_bpcg2_phases": (C.c_int, [vp, i32, i32, i32, vp]),
@@ -278,6 +281,17 @@ class HipEngine:
         out = C.c_void_p()
         self._check(self.lib.nss_bjac_create(csr_handle.ptr, bs, nb, idx.ctypes.data, C.byref(out)))
         return _BjacHandle(self, out, bs, nb, csr_handle.m)
+
+    def bjac_set_colors(self, h, csr_handle, color_ptr):
+        color_ptr = np.ascontiguousarray(color_ptr, dtype=np.int32)
+        self._check(self.lib.nss_bjac_set_colors(h.ptr, csr_handle.ptr, color_ptr.size - 1, color_ptr.ctypes.data))
+        h.keep_matrix = csr_handle          # the sweeps walk the CSR rows: keep it alive
+
+    def bjac_smooth(self, h, xscale, x, y, backward):
+        if x.shape[0] != h.n or y.shape[0] != h.n:
+            raise ValueError("bjac_smooth shape mismatch")
+        self._check(self.lib.nss_bjac_smooth_f64(h.ptr, xscale, x.data_ptr(), y.data_ptr(), int(bool(backward)),
+                                                 self.stream))
 
     def bjac_apply(self, h, alpha, x, beta, y):
         if x.shape[0] != h.n or y.shape[0] != h.n:

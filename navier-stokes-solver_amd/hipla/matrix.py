@@ -540,18 +540,8 @@ class BlockJacobi(BaseMatrix):
         self.engine = mat.engine
         self.mat = mat
         self.n = mat.height
-        if isinstance(blocks, np.ndarray) and blocks.ndim == 2:
-            # prebuilt table (bs, nblocks), -1 = padding (staggered_grid.facet_blocks)
-            idx = np.ascontiguousarray(blocks, dtype=np.int32)
-            self.bs, self.nblocks = idx.shape
-        else:
-            blocks = [np.asarray(b, dtype=np.int64).ravel() for b in blocks]
-            blocks = [b for b in blocks if b.size]
-            self.nblocks = len(blocks)
-            self.bs = max(b.size for b in blocks) if blocks else 0
-            idx = -np.ones((self.bs, self.nblocks), dtype=np.int32)
-            for k, b in enumerate(blocks):
-                idx[: b.size, k] = b
+        idx = self._as_table(blocks)
+        self.bs, self.nblocks = idx.shape
         if self.nblocks == 0:
             raise ValueError("BlockJacobi needs at least one non-empty block")
         if self.bs > 16:
@@ -561,6 +551,20 @@ class BlockJacobi(BaseMatrix):
             raise ValueError("BlockJacobi blocks must be disjoint and in range")
         self.idx_host = idx
         self.handle = self.engine.bjac_create(mat.handle, idx)
+
+    @staticmethod
+    def _as_table(blocks):
+        """(bs, nblocks) int32 table, -1 = padding, from a list of dof lists or a prebuilt table
+        (staggered_grid.facet_blocks / line_blocks)."""
+        if isinstance(blocks, np.ndarray) and blocks.ndim == 2:
+            return np.ascontiguousarray(blocks, dtype=np.int32)
+        blocks = [np.asarray(b, dtype=np.int64).ravel() for b in blocks]
+        blocks = [b for b in blocks if b.size]
+        bs = max(b.size for b in blocks) if blocks else 0
+        idx = -np.ones((bs, len(blocks)), dtype=np.int32)
+        for k, b in enumerate(blocks):
+            idx[: b.size, k] = b
+        return idx
 
     def Height(self):
         return self.n
@@ -581,10 +585,70 @@ class BlockJacobi(BaseMatrix):
     def T(self):
         return self
 
-    def Smooth(self, y, x):
-        raise NotImplementedError("multiplicative block Gauss-Seidel sweep: SURVEY.md section 8f row N1")
+    # ---- multiplicative sweeps (templates/NavierStokesSIMPLE_iterative.py:376-381) -----------
+    def gauss_seidel(self):
+        """The companion handle in Gauss-Seidel mode: same blocks in a multicolour ordering
+        (hipla/coloring.py), built on first use."""
+        if getattr(self, "_gs", None) is None:
+            self._gs = BlockGaussSeidel(self.mat, self.idx_host)
+        return self._gs
 
-    SmoothBack = Smooth
+    def Smooth(self, y, x):
+        """Forward block Gauss-Seidel sweep for ``mat * y = x`` starting from the given y."""
+        self.gauss_seidel().Smooth(y, x)
+
+    def SmoothBack(self, y, x):
+        self.gauss_seidel().SmoothBack(y, x)
+
+
+class BlockGaussSeidel(BaseMatrix):
+    """Symmetric multiplicative block Gauss-Seidel as an operator: ``y = 0; Smooth(y, x);
+    SmoothBack(y, x)`` -- the reference's ``MypreA`` with ``GS=True``
+    (templates/NavierStokesSIMPLE_iterative.py:376-381) without its auxiliary-space AMG term
+    (scope row N3).  SURVEY.md section 8f row N1: the sweep runs over a *multicolour* block
+    ordering so that all blocks of a colour update in one kernel launch
+    (``nss_bjac_smooth_f64``); the ordering differs from NGSolve's mesh-facet order (upstream,
+    not visible), so iteration counts are pinned against the build's own CPU oracle only."""
+
+    def __init__(self, mat, blocks, seed=0):
+        super().__init__()
+        from . import coloring
+        self.engine = mat.engine
+        self.mat = mat
+        self.n = mat.height
+        base = BlockJacobi._as_table(blocks)
+        graph = coloring.block_graph(mat.to_scipy(), base)
+        colors = coloring.color_blocks(graph, seed)
+        if not coloring.check_coloring(graph, colors):
+            raise RuntimeError("block colouring is not proper")
+        order, ptr = coloring.colour_major_order(colors)
+        self.idx_host = np.ascontiguousarray(base[:, order])
+        self.color_ptr = ptr
+        self.ncolors = int(ptr.size - 1)
+        self.bs, self.nblocks = self.idx_host.shape
+        self.handle = self.engine.bjac_create(mat.handle, self.idx_host)
+        self.engine.bjac_set_colors(self.handle, mat.handle, ptr)
+
+    def Height(self):
+        return self.n
+
+    def Width(self):
+        return self.n
+
+    def Smooth(self, y, x):
+        self.engine.bjac_smooth(self.handle, 1.0, x.buf, y.buf, False)
+
+    def SmoothBack(self, y, x):
+        self.engine.bjac_smooth(self.handle, 1.0, x.buf, y.buf, True)
+
+    def Mult(self, x, y):
+        self.engine.bjac_apply(self.handle, 1.0, x.buf, 0.0, y.buf)      # GS-mode handle: symmetric sweep
+
+    MultTrans = Mult          # forward then backward sweep: symmetric operator
+
+    @property
+    def T(self):
+        return self
 
 
 class Projector(BaseMatrix):

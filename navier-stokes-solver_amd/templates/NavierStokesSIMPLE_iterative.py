@@ -8,10 +8,13 @@ drivers exercise: the *iterative Stokes initial solve*, i.e. the hand-off
 with ``preA`` = facet-block Jacobi (``MypreA`` with ``GS=False`` minus the AMG term, :364-391) and
 ``preM`` = ``Preconditioner(mass, 'local')`` (:197-200).
 
+``GS=True`` (the reference's default) selects the symmetric multiplicative block Gauss-Seidel
+sweep (:376-381) over a multicolour block ordering, ``GS=False`` the additive block Jacobi.
+
 Out of scope (SURVEY.md sections 2 and 8f): the MCS/HDG assembly, the auxiliary-space AMG
-correction (N3), the multiplicative block Gauss-Seidel sweep ``GS=True`` (N1), static
-condensation (N2), the IMEX time stepping ``DoTimeStep`` / ``Project`` (N4) and the sparse
-direct branch ``iterative=False``.  Those raise ``NotImplementedError`` naming the row."""
+correction (N3), static condensation (N2), the IMEX time stepping ``DoTimeStep`` / ``Project``
+(N4) and the sparse direct branch ``iterative=False``.  Those raise ``NotImplementedError``
+naming the row."""
 
 import hipla
 from hipla import BlockVector
@@ -21,20 +24,19 @@ from solvers.bramblepasciak_new import BramblePasciakCG
 __all__ = ["NavierStokes", "SyntheticMesh", "MypreA"]
 
 
-class MypreA(hipla.BlockJacobi):
+def MypreA(space, a, jacblocks, GS):
     """``MypreA(space, a, jacblocks, GS)`` of the reference
-    (templates/NavierStokesSIMPLE_iterative.py:364-391) restricted to the hot-path part:
-    ``GS=False`` -> additive ``y = J x`` with ``J = a.mat.CreateBlockSmoother(jacblocks)`` (:373,383).
-    The auxiliary-space term ``transform @ preAh1 @ transform.T`` (:380,383) needs the AMG
-    hierarchy (scope row N3) and is absent; ``GS=True`` (:376-381) is scope row N1.
-    Being a `BlockJacobi`, it is recognised by the fused device-resident loops."""
+    (templates/NavierStokesSIMPLE_iterative.py:364-391) without its auxiliary-space term
+    ``transform @ preAh1 @ transform.T`` (:380,383; needs the AMG hierarchy, scope row N3):
 
-    def __init__(self, space, a, jacblocks, GS):
-        if GS:
-            raise NotImplementedError("multiplicative block Gauss-Seidel sweep: SURVEY.md section 8f row N1")
-        super().__init__(a.mat, jacblocks)
-        self.space, self.GS = space, GS
-        self.temp = a.mat.CreateColVector()
+    * ``GS=False`` -> additive ``y = J x`` with ``J = a.mat.CreateBlockSmoother(jacblocks)`` (:383);
+    * ``GS=True``  -> ``y = 0; J.Smooth(y, x); J.SmoothBack(y, x)`` (:376-381), the symmetric
+      multiplicative sweep over a multicolour block ordering (scope row N1).
+
+    Both are native operators, so the fused device-resident loops take them."""
+    op = hipla.BlockGaussSeidel(a.mat, jacblocks) if GS else hipla.BlockJacobi(a.mat, jacblocks)
+    op.space, op.GS = space, GS
+    return op
 
 
 class NavierStokes:
@@ -63,9 +65,6 @@ class NavierStokes:
             raise NotImplementedError("projection time stepping: SURVEY.md section 8f row N4")
         if not iterative:
             raise NotImplementedError("sparse direct initial solve is not on the Krylov path")
-        if GS:
-            raise NotImplementedError("multiplicative block Gauss-Seidel sweep: SURVEY.md section 8f row N1 "
-                                      "(call SolveInitial(GS=False) for the additive block-Jacobi preconditioner)")
         blfA = AssembledForm(self.a.mat)
         blfB = AssembledForm(self.b.mat)
         preM = hipla.Preconditioner(self.mp, "local")

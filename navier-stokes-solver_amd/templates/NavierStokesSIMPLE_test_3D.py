@@ -16,7 +16,7 @@ def main(maxh=0.1, order=2, tol=1e-10):
     with TaskManager():
         navstokes = NavierStokes(mesh, nu=0.001, order=order, timestep=timestep, inflow="inlet", outflow="outlet",
                                  wall="wall|cyl", uin=None)
-    navstokes.SolveInitial(iterative=True, GS=False, tol=tol)
+    navstokes.SolveInitial(iterative=True, tol=tol)
     print("iterations", navstokes.stokes_bpcg_iterations, "time", navstokes.stokes_bpcg_time)
     return navstokes
 

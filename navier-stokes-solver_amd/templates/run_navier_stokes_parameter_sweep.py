@@ -1,7 +1,6 @@
 """Parameter sweep with the reference's CSV schema
 (templates/run_navier_stokes_parameter_sweep.py:44-70): mesh size x order x gauss_seidel ->
-``iterations``, ``time`` (= `BramblePasciakCG`'s return, i.e. the iteration loop only).
-``gauss_seidel_enabled=True`` rows are skipped: the multiplicative sweep is scope row N1."""
+``iterations``, ``time`` (= `BramblePasciakCG`'s return, i.e. the iteration loop only)."""
 import sys
 import os
 
@@ -20,19 +19,17 @@ def create_nav_stokes(mesh, order, nu=0.001):
                         wall="cyl|wall", uin=None)
 
 
-def sweep(mesh_sizes, orders, gauss_seidel_enabled=(False,), out="data.csv", dim=2, tol=1e-10, maxsteps=100000):
+def sweep(mesh_sizes, orders, gauss_seidel_enabled=(True, False), out="data.csv", dim=2, tol=1e-10, maxsteps=100000):
     frames = []
     for mesh_size in mesh_sizes:
         mesh = create_mesh(mesh_size, dim)
         for order in orders:
             navstokes = create_nav_stokes(mesh, order)
             for gauss_seidel in gauss_seidel_enabled:
-                if gauss_seidel:
-                    print("skipping GS=True for h = %g, p = %d (SURVEY.md section 8f row N1)" % (mesh_size, order))
-                    continue
                 navstokes.gfu[:] = 0.0
                 navstokes.gfup[:] = 0.0
-                navstokes.SolveInitial(iterative=True, GS=False, tol=tol, maxsteps=maxsteps)
+                print("solving h = %g, p = %d, GS = %s" % (mesh_size, order, gauss_seidel))
+                navstokes.SolveInitial(iterative=True, GS=gauss_seidel, tol=tol, maxsteps=maxsteps)
                 frames.append(pd.DataFrame({'mesh_size': mesh_size, 'order': order,
                                             'iterations': navstokes.stokes_bpcg_iterations,
                                             'time': navstokes.stokes_bpcg_time,

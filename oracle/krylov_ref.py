@@ -64,6 +64,32 @@ def block_jacobi(A, idx):
     return apply
 
 
+def block_gauss_seidel_sweep(A, idx, x, y, backward=False):
+    """One *sequential* block Gauss-Seidel sweep for A y = x over the blocks of `idx` in the given
+    order (reversed if `backward`): y_b += A_bb^-1 (x_b - (A y)_b), one block after the other --
+    `jacobi.Smooth` / `jacobi.SmoothBack` of templates/NavierStokesSIMPLE_iterative.py:378,381.
+    Plain Python loop: small cases only.  The multicolour GPU sweep must agree with this when
+    handed its colour-major block order (same-colour blocks are uncoupled)."""
+    A = sp.csr_matrix(A)
+    y = np.array(y, dtype=np.float64)
+    nb = idx.shape[1]
+    order = range(nb - 1, -1, -1) if backward else range(nb)
+    for b in order:
+        dofs = idx[:, b]
+        dofs = dofs[dofs >= 0]
+        res = x[dofs] - A[dofs] @ y
+        y[dofs] += np.linalg.solve(A[dofs][:, dofs].toarray(), res)
+    return y
+
+
+def symmetric_block_gauss_seidel(A, idx):
+    """y = 0; forward sweep; backward sweep (MypreA with GS=True minus the AMG term, :376-381)."""
+    def apply(x):
+        y = block_gauss_seidel_sweep(A, idx, x, np.zeros(A.shape[0]), backward=False)
+        return block_gauss_seidel_sweep(A, idx, x, y, backward=True)
+    return apply
+
+
 # --------------------------------------------------------------------------
 # eigenvalue estimate -> scale factor k
 # --------------------------------------------------------------------------

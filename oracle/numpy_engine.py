@@ -122,7 +122,35 @@ class NumpyEngine:
         inv = np.linalg.inv(blocks)
         return _Bjac(idx.copy(), inv)
 
+    def bjac_set_colors(self, h, csr_handle, color_ptr):
+        h.mat = csr_handle.mat.tocsr()
+        h.color_ptr = np.array(color_ptr, dtype=np.int64)
+
+    def bjac_smooth(self, h, xscale, x, y, backward):
+        """One multicolour block Gauss-Seidel sweep (colour by colour, vectorised per colour)."""
+        idx, inv, a = h.idx, h.inv, h.mat
+        nc = h.color_ptr.size - 1
+        for k in range(nc):
+            c = nc - 1 - k if backward else k
+            b0, b1 = int(h.color_ptr[c]), int(h.color_ptr[c + 1])
+            if b1 <= b0:
+                continue
+            sub = idx[:, b0:b1]
+            live = sub >= 0
+            safe = np.where(live, sub, 0)
+            r = xscale * x - a @ y
+            res = np.where(live, r[safe], 0.0)
+            upd = np.einsum("krc,ck->rk", inv[b0:b1], res)
+            y[sub[live]] += upd[live]
+
     def bjac_apply(self, h, alpha, x, beta, y):
+        if getattr(h, "color_ptr", None) is not None:      # Gauss-Seidel mode: symmetric sweep operator
+            if beta != 0.0:
+                raise ValueError("Gauss-Seidel mode supports beta == 0 only")
+            y[:] = 0.0
+            self.bjac_smooth(h, alpha, x, y, False)
+            self.bjac_smooth(h, alpha, x, y, True)
+            return
         idx, inv = h.idx, h.inv
         safe = np.where(idx >= 0, idx, 0)
         xb = np.where(idx >= 0, x[safe], 0.0)          # (bs, nb)

@@ -64,12 +64,16 @@ def test_navier_stokes_class_and_sweep(numpy_engine, tmp_path):
     ns = NavierStokes(SyntheticMesh(0.2, dim=2), nu=0.001, inflow="inlet", outflow="outlet", wall="wall|cyl", uin=None,
                       timestep=0.001, order=2)
     with pytest.raises(NotImplementedError):
-        ns.SolveInitial(iterative=True)                      # reference default GS=True: scope row N1
-    with pytest.raises(NotImplementedError):
         ns.DoTimeStep()
     with contextlib.redirect_stdout(io.StringIO()):
         ns.SolveInitial(iterative=True, GS=False, tol=1e-8)
-    assert ns.stokes_bpcg_iterations > 5 and ns.stokes_bpcg_time > 0
+    its_jacobi = ns.stokes_bpcg_iterations
+    assert its_jacobi > 5 and ns.stokes_bpcg_time > 0
+    ns.gfu[:] = 0.0
+    ns.gfup[:] = 0.0
+    with contextlib.redirect_stdout(io.StringIO()):
+        ns.SolveInitial(iterative=True, tol=1e-8)            # reference default GS=True
+    assert 3 < ns.stokes_bpcg_iterations < its_jacobi        # the multiplicative sweep is the stronger smoother
     s = ns.system
     f, g = s.rhs(0)
     x = np.concatenate([ns.velocity.numpy(), ns.gfup.numpy()])
@@ -79,7 +83,10 @@ def test_navier_stokes_class_and_sweep(numpy_engine, tmp_path):
     with contextlib.redirect_stdout(io.StringIO()):
         data = sweep([0.25, 0.2], [2, 1], (True, False), out=str(tmp_path / "data.csv"), tol=1e-6)
     assert list(data.columns) == ['mesh_size', 'order', 'iterations', 'time', 'gauss_seidel_enabled']
-    assert len(data) == 4 and (data.iterations > 0).all() and not data.gauss_seidel_enabled.any()
+    assert len(data) == 8 and (data.iterations > 0).all() and data.gauss_seidel_enabled.sum() == 4
+    for _, grp in data.groupby(["mesh_size", "order"]):
+        gs = grp[grp.gauss_seidel_enabled].iterations.iloc[0]
+        assert gs < grp[~grp.gauss_seidel_enabled].iterations.iloc[0]
 
 
 def test_stokes_hcurldiv_driver(numpy_engine):
@@ -87,3 +94,63 @@ def test_stokes_hcurldiv_driver(numpy_engine):
     with contextlib.redirect_stdout(io.StringIO()):
         sol, errors, (a, b, f, g) = solve_stokes(maxh=0.2, tolerance=1e-8, max_steps=10000)
     assert errors[0] == 1.0 and errors[-1] < 1e-8 and len(sol) == a.mat.height + b.mat.height
+
+
+def test_multicolour_block_gauss_seidel_against_sequential_oracle(numpy_engine):
+    """Scope row N1: colouring is proper, the colour-parallel sweep equals the sequential sweep
+    over the same (colour-major) block order, the symmetric pair is a symmetric positive operator
+    and BPCG with it matches the oracle loop driven by the sequential sweep."""
+    import hipla
+    from hipla import coloring
+    from oracle import krylov_ref as kr
+    from solvers.bramblepasciak_new import BramblePasciakCG
+    from staggered_grid import mac_stokes
+    for s, blocks in ((mac_stokes(2, 10, 0.01), "line"), (mac_stokes(3, 5, 0.01).inflate(2), "facet")):
+        idx = s.line_blocks(3) if blocks == "line" else s.facet_blocks()
+        A = hipla.SparseMatrix.from_scipy(s.A)
+        g = coloring.block_graph(s.A, idx)
+        colors = coloring.color_blocks(g)
+        assert coloring.check_coloring(g, colors) and colors.min() == 0
+        G = hipla.BlockGaussSeidel(A, idx)
+        assert G.ncolors == colors.max() + 1 and sorted(G.idx_host[G.idx_host >= 0]) == list(range(s.n_u))
+        rng = np.random.default_rng(0)
+        x, y0 = rng.standard_normal(s.n_u), rng.standard_normal(s.n_u)
+        y = hipla.Vector.from_numpy(y0)
+        G.Smooth(y, hipla.Vector.from_numpy(x))
+        ref = kr.block_gauss_seidel_sweep(s.A, G.idx_host, x, y0)
+        np.testing.assert_allclose(y.numpy(), ref, rtol=0, atol=1e-12 * np.abs(ref).max())
+        G.SmoothBack(y, hipla.Vector.from_numpy(x))
+        ref = kr.block_gauss_seidel_sweep(s.A, G.idx_host, x, ref, backward=True)
+        np.testing.assert_allclose(y.numpy(), ref, rtol=0, atol=1e-12 * np.abs(ref).max())
+        out, z = hipla.Vector(s.n_u), rng.standard_normal(s.n_u)
+        out.data = G * hipla.Vector.from_numpy(x)
+        gz = hipla.Vector(s.n_u)
+        gz.data = G * hipla.Vector.from_numpy(z)
+        assert abs(np.dot(out.numpy(), z) - np.dot(x, gz.numpy())) < 1e-10 * np.linalg.norm(x) * np.linalg.norm(gz.numpy())
+        assert np.dot(out.numpy(), x) > 0
+        # J.Smooth on a BlockJacobi goes through the same companion handle
+        J = hipla.BlockJacobi(A, idx)
+        y2 = hipla.Vector(s.n_u)
+        J.Smooth(y2, hipla.Vector.from_numpy(x))
+        np.testing.assert_allclose(y2.numpy(), kr.block_gauss_seidel_sweep(s.A, J.gauss_seidel().idx_host, x,
+                                                                           np.zeros(s.n_u)), atol=1e-12)
+    # BPCG v2 with the symmetric sweep as preA: protocol loop vs the oracle loop
+    s = mac_stokes(2, 10, 0.01)
+    f, gg = s.rhs(0)
+    A, B = hipla.SparseMatrix.from_scipy(s.A), hipla.SparseMatrix.from_scipy(s.B)
+    G = hipla.BlockGaussSeidel(A, s.line_blocks(3))
+
+    class Form:
+        def __init__(self, mat):
+            self.mat, self.condense = mat, False
+
+    sol = hipla.BlockVector([hipla.Vector(s.n_u), hipla.Vector(s.n_p)])
+    out = io.StringIO()
+    with contextlib.redirect_stdout(out):
+        it, _ = BramblePasciakCG(Form(A), Form(B), None, hipla.Vector.from_numpy(f), hipla.Vector.from_numpy(gg), G,
+                                 hipla.DiagonalMatrix(1.0 / s.mass), sol, tol=1e-8, maxsteps=500)
+    pa = kr.symmetric_block_gauss_seidel(s.A, G.idx_host)
+    k = kr.scale_factor(kr.lanczos_ritz(s.A, pa, tol=1e-3))
+    it_ref, u, p, hist, err0 = kr.bpcg_v2(s.A, s.B, pa, kr.diag_inverse(s.mass), f, gg, k, tol=1e-8, maxsteps=500)
+    assert abs(it - it_ref) <= 2
+    assert np.linalg.norm(sol.numpy() - np.concatenate([u, p])) < 1e-6 * np.linalg.norm(u)

@@ -253,3 +253,45 @@ def test_lanczos_scale_factor_matches_oracle(hip_engine):
     assert abs(min(lams) - ref.min()) <= 1e-9 * ref.min()
     d = np.load(__import__("conftest").golden_path("stokes3d_n10_bjac_bpcg2"))
     assert abs(1.0 / min(lams) + 1e-3 - float(d["k"])) <= 1e-8 * float(d["k"])
+
+
+@pytest.mark.parametrize("case", ["line3_2d", "facet_3d_inflated", "ragged_lists"])
+def test_multicolour_block_gauss_seidel_sweeps(hip_engine, case):
+    """nss_bjac_smooth_f64 (one launch per colour) against the sequential block Gauss-Seidel of
+    the oracle over the same colour-major block order; symmetric pair as an operator."""
+    import hipla
+    from oracle import krylov_ref as kr
+    if case == "line3_2d":
+        s = mac_stokes(2, 24)
+        blocks = s.line_blocks(3)
+    elif case == "facet_3d_inflated":
+        s = mac_stokes(3, 5).inflate(4)
+        blocks = s.facet_blocks()
+    else:
+        s = mac_stokes(2, 9)
+        rng = np.random.default_rng(3)
+        perm = rng.permutation(s.n_u)
+        cuts = np.sort(rng.choice(np.arange(1, s.n_u), size=s.n_u // 3, replace=False))
+        blocks = [list(b) for b in np.split(perm, cuts) if 0 < len(b) <= 16]
+    A = hipla.SparseMatrix.from_scipy(s.A)
+    G = hipla.BlockGaussSeidel(A, blocks)
+    assert G.ncolors >= 2
+    rng = np.random.default_rng(1)
+    x, y0 = rng.standard_normal(s.n_u), rng.standard_normal(s.n_u)
+    X, Y = hipla.Vector.from_numpy(x), hipla.Vector.from_numpy(y0)
+    G.Smooth(Y, X)
+    ref = kr.block_gauss_seidel_sweep(s.A, G.idx_host, x, y0)
+    assert relerr(Y.numpy(), ref) < 1e-12
+    G.SmoothBack(Y, X)
+    ref = kr.block_gauss_seidel_sweep(s.A, G.idx_host, x, ref, backward=True)
+    assert relerr(Y.numpy(), ref) < 1e-12
+    out = hipla.Vector(s.n_u)
+    out[:] = 5.0
+    out.data = G * X
+    assert relerr(out.numpy(), kr.symmetric_block_gauss_seidel(s.A, G.idx_host)(x)) < 1e-12
+    z = rng.standard_normal(s.n_u)
+    gz = hipla.Vector(s.n_u)
+    gz.data = G * hipla.Vector.from_numpy(z)
+    assert abs(np.dot(out.numpy(), z) - np.dot(x, gz.numpy())) < 1e-10 * np.linalg.norm(x) * np.linalg.norm(gz.numpy())
+    out.data = 2.5 * G * X                       # scaled operator (preA = k * preA_unscaled)
+    assert relerr(out.numpy(), 2.5 * kr.symmetric_block_gauss_seidel(s.A, G.idx_host)(x)) < 1e-12

@@ -467,3 +467,65 @@ def test_fused_bpcg2_breakdown_raises_like_the_reference(hip_engine):
     with pytest.raises(ZeroDivisionError):
         ses.fused.run(ses.wdn, ses.err0, 1e-8, True, 50)
     assert np.all(sol.numpy() == 0.0)           # state frozen before any update
+
+
+def test_fused_loops_with_block_gauss_seidel_preconditioner(hip_engine):
+    """Scope row N1 on the hot path: the symmetric multicolour block Gauss-Seidel sweep as preA in
+    the three fused loops, against the oracle loops driven by the *sequential* sweep over the
+    same block order; and the reference's default `SolveInitial()` (GS=True) end to end."""
+    import hipla
+    from bramble_pasciak_cg import bramble_pasciak_cg
+    from minres import MinRes
+    from oracle import krylov_ref as kr
+    from solvers.bramblepasciak_new import BpcgSession, BramblePasciakCG
+    s = mac_stokes(3, 6, 0.01)
+    f, g = s.rhs(0)
+    A, B = hipla.SparseMatrix.from_scipy(s.A), hipla.SparseMatrix.from_scipy(s.B)
+    G = hipla.BlockGaussSeidel(A, s.line_blocks(3))
+    preS = hipla.DiagonalMatrix(1.0 / s.mass)
+    pa, ps = kr.symmetric_block_gauss_seidel(s.A, G.idx_host), kr.diag_inverse(s.mass)
+    fv, gv = hipla.Vector.from_numpy(f), hipla.Vector.from_numpy(g)
+    b = np.concatenate([f, g])
+    K = s.saddle_matrix()
+
+    sol = hipla.BlockVector([hipla.Vector(s.n_u), hipla.Vector(s.n_p)])
+    with contextlib.redirect_stdout(io.StringIO()):
+        ses = BpcgSession(Form(A), Form(B), None, fv, gv, G, preS, sol=sol)
+    assert ses.fused is not None
+    out = io.StringIO()
+    sol = hipla.BlockVector([hipla.Vector(s.n_u), hipla.Vector(s.n_p)])
+    with contextlib.redirect_stdout(out):
+        it, _ = BramblePasciakCG(Form(A), Form(B), None, fv, gv, G, preS, sol, tol=1e-9, maxsteps=2000)
+    hist = np.array([float(m) for m in re.findall(r"it =\s+\d+\s+err =\s+(\S+)", out.getvalue())])
+    k = kr.scale_factor(kr.lanczos_ritz(s.A, pa, tol=1e-3))
+    assert abs(k - ses.k) < 1e-8 * k
+    it_ref, u, p, hist_ref, err0 = kr.bpcg_v2(s.A, s.B, pa, ps, f, g, k, tol=1e-9, maxsteps=2000)
+    np.testing.assert_allclose(hist[:25], hist_ref[:25], rtol=1e-8)
+    assert abs(it - it_ref) <= max(3, int(0.03 * it_ref))
+    assert np.linalg.norm(b - K @ sol.numpy()) < 1e-6 * np.linalg.norm(b)
+
+    with contextlib.redirect_stdout(io.StringIO()):
+        x1, errors = bramble_pasciak_cg(A, B, None, G, preS, fv, gv, tolerance=1e-9, max_steps=2000, print_rates=False)
+    u1, p1, e_ref, _ = kr.bpcg_v1(s.A, s.B, pa, ps, f, g, kr.scale_factor(kr.lanczos_ritz(s.A, pa, tol=1e-10)),
+                                  tolerance=1e-9, max_steps=2000)
+    np.testing.assert_allclose(errors[:25], e_ref[:25], rtol=1e-8)
+    assert abs(len(errors) - len(e_ref)) <= max(3, int(0.03 * len(e_ref)))
+
+    Km = hipla.BlockMatrix([[A, B.T], [B, None]])
+    Cm = hipla.BlockMatrix([[G, None], [None, preS]])
+    with contextlib.redirect_stdout(io.StringIO()):
+        um, errs = MinRes(mat=Km, pre=Cm, rhs=hipla.BlockVector([fv, gv]), maxsteps=2000, tol=1e-9, printrates=False)
+    _, _, m_ref, _ = kr.minres(s.A, s.B, pa, ps, f, g, maxsteps=2000, tol=1e-9)
+    np.testing.assert_allclose(errs[:40], m_ref[:40], rtol=1e-8)
+    assert np.linalg.norm(b - K @ um.numpy()) < 1e-6 * np.linalg.norm(b)
+
+    # the reference's default driver call: SolveInitial() with GS=True needs fewer iterations
+    from templates.NavierStokesSIMPLE_iterative import NavierStokes, SyntheticMesh
+    counts = {}
+    for gs in (True, False):
+        ns = NavierStokes(SyntheticMesh(0.125, dim=3), nu=0.001, inflow="inlet", outflow="outlet", wall="wall|cyl",
+                          uin=None, timestep=0.002, order=1)
+        with contextlib.redirect_stdout(io.StringIO()):
+            ns.SolveInitial(iterative=True, GS=gs, tol=1e-8)
+        counts[gs] = ns.stokes_bpcg_iterations
+    assert 3 < counts[True] < counts[False]
