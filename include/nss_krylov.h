@@ -78,6 +78,11 @@ NSS_API int nss_stream_triad_f64(int64_t n, double a, const double* x, const dou
  * 98-101,125,127; minres.py:66,97) ---------------------------------------------------- */
 NSS_API int nss_csr_create(int32_t nrows, int32_t ncols, int64_t nnz, const int32_t* h_rowptr,
                            const int32_t* h_col, const double* h_val, nss_csr_t* out);
+/* same, with row positions (ascending, h_cuts[i] in [0, nrows]) that no row block of the launch
+ * plan may span: used where a launch covers only a sub-range of rows (colour by colour) */
+NSS_API int nss_csr_create_cuts(int32_t nrows, int32_t ncols, int64_t nnz, const int32_t* h_rowptr,
+                                const int32_t* h_col, const double* h_val, int32_t ncuts,
+                                const int32_t* h_cuts, nss_csr_t* out);
 NSS_API int nss_csr_destroy(nss_csr_t a);
 /* y = alpha * A x + beta * y   (beta == 0: y is not read).  x must not alias y. */
 NSS_API int nss_csr_spmv_f64(nss_csr_t a, double alpha, const double* x, double beta, double* y,
@@ -110,10 +115,16 @@ NSS_API int nss_bjac_info(nss_bjac_t j, int32_t* bs, int32_t* nblocks, int64_t* 
 /* multiplicative block Gauss-Seidel sweeps `jacobi.Smooth(y, x)` / `jacobi.SmoothBack(y, x)`
  * (templates/NavierStokesSIMPLE_iterative.py:376-381) over a
  * MULTICOLOUR block ordering: the handle's blocks [h_color_ptr[c], h_color_ptr[c+1]) carry colour
- * c and must not be coupled to each other through `a` (the host colours the block graph and
- * creates the handle with its blocks in colour-major order).  All blocks of a colour update in
- * parallel: y_b += A_bb^-1 (xscale * x_b - (a y)_b). */
-NSS_API int nss_bjac_set_colors(nss_bjac_t j, nss_csr_t a, int32_t ncolors, const int32_t* h_color_ptr);
+ * c and must not be coupled to each other (the host colours the block graph and creates the
+ * handle with its blocks in colour-major order).  All blocks of a colour update in parallel:
+ * y_b += A_bb^-1 (xscale * x_b - (A y)_b).
+ * To keep the sweep streaming, the host passes `a_perm` = the rows of A re-ordered block by
+ * block in that colour-major order (columns unchanged; created with nss_csr_create_cuts so
+ * that no row block spans two colours): the residual of a colour is then one CSR-stream SpMV
+ * over a contiguous row range.  h_rowdof[r] = original dof of permuted row r;
+ * h_ridx: int32[bs][nblocks] = permuted row of each block entry (-1 = padding). */
+NSS_API int nss_bjac_set_colors(nss_bjac_t j, nss_csr_t a_perm, int32_t ncolors, const int32_t* h_color_ptr,
+                                const int32_t* h_color_rowptr, const int32_t* h_rowdof, const int32_t* h_ridx);
 /* one sweep: colours ascending (backward == 0) or descending */
 NSS_API int nss_bjac_smooth_f64(nss_bjac_t j, double xscale, const double* x, double* y, int32_t backward,
                                 nss_stream_t stream);

@@ -13,8 +13,12 @@ struct nss_bjac_s {
   int32_t* covered = nullptr;  // dofs that belong to no block (count: n_uncovered)
   int32_t n_uncovered = 0;
   // multicolour Gauss-Seidel mode (nss_bjac_set_colors): blocks are stored colour-major
-  const nss_csr_s* gs_mat = nullptr;
-  std::vector<int32_t> color_ptr;  // ncolors + 1 block offsets (host)
+  const nss_csr_s* gs_mat = nullptr;      // rows of A permuted block by block, colour-major
+  std::vector<int32_t> color_ptr;         // ncolors + 1 block offsets (host)
+  std::vector<int32_t> color_rowblk;      // ncolors + 1 row-block offsets into gs_mat's launch plan (host)
+  int32_t* rowdof = nullptr;              // device: original dof of permuted row r
+  int32_t* ridx = nullptr;                // device [bs][nblocks]: permuted row of a block entry, -1 = padding
+  double* res = nullptr;                  // device: residual of the colour being swept (permuted rows)
 };
 
 namespace nss {

@@ -109,52 +109,57 @@ __global__ __launch_bounds__(kBlock) void bjac_uncovered_kernel(int32_t count, c
   y[d] = beta == 0.0 ? 0.0 : beta * y[d];
 }
 
-// One colour of a multicolour block Gauss-Seidel sweep: one lane per block of the colour.
-// Residual rows first (CSR row walks over the current y), then the dense block solve; blocks
-// of one colour are uncoupled, so no lane reads what another lane of this launch writes.
+// ---- multicolour block Gauss-Seidel ---------------------------------------------------------
+// A colour is swept in two streaming launches:
+//   (1) residual: CSR-stream SpMV over the colour's contiguous rows of the row-permuted copy of
+//       A, epilogue res[r] = xscale * x[dof(r)] - (A y)[r]  (blocks of a colour are uncoupled, so
+//       the old y of the colour itself is all the launch reads of it);
+//   (2) block solve: one lane per block, y[dofs] += A_bb^-1 res_b, inverse blocks and residual
+//       rows contiguous in colour-major order (coalesced), y scattered by original dof.
+struct EpiGsResidual {
+  const int32_t* __restrict__ done;
+  const int32_t* __restrict__ rowdof;
+  const double* __restrict__ x;
+  double* __restrict__ res;
+  double xscale;
+  __device__ bool skip() const { return done && done[0] != 0; }
+  __device__ void row(int r, double ay) const { res[r] = fma(xscale, x[rowdof[r]], -ay); }
+  __device__ void finish(int, double*) const {}
+};
+
 template <int BS>
-__global__ __launch_bounds__(kBlock) void bgs_color_kernel(int32_t b0, int32_t b1, int32_t nb,
+__global__ __launch_bounds__(kBlock) void bgs_solve_kernel(int32_t b0, int32_t b1, int32_t nb,
                                                             const int32_t* __restrict__ idx,
+                                                            const int32_t* __restrict__ ridx,
                                                             const double* __restrict__ inv,
-                                                            const int32_t* __restrict__ rowptr,
-                                                            const int32_t* __restrict__ col,
-                                                            const double* __restrict__ val, double xscale,
-                                                            const double* __restrict__ x, double* y,
+                                                            const double* __restrict__ res, double* __restrict__ y,
                                                             const int32_t* __restrict__ done) {
   if (done && done[0] != 0) return;
   const int b = b0 + blockIdx.x * kBlock + threadIdx.x;
   if (b >= b1) return;
-  int32_t dof[BS];
-  double res[BS];
+  double rv[BS];
 #pragma unroll
-  for (int r = 0; r < BS; ++r) dof[r] = idx[size_t(r) * nb + b];
-#pragma unroll
-  for (int r = 0; r < BS; ++r) {
-    double acc = 0.0;
-    if (dof[r] >= 0) {
-      acc = xscale * x[dof[r]];
-      for (int p = rowptr[dof[r]]; p < rowptr[dof[r] + 1]; ++p) acc = fma(-val[p], y[col[p]], acc);
-    }
-    res[r] = acc;
+  for (int c = 0; c < BS; ++c) {
+    const int rr = ridx[size_t(c) * nb + b];
+    rv[c] = rr >= 0 ? res[rr] : 0.0;
   }
 #pragma unroll
   for (int r = 0; r < BS; ++r) {
-    if (dof[r] < 0) continue;
+    const int dof = idx[size_t(r) * nb + b];
+    if (dof < 0) continue;
     double s = 0.0;
 #pragma unroll
-    for (int c = 0; c < BS; ++c) s = fma(inv[(size_t(r) * BS + c) * nb + b], res[c], s);
-    y[dof[r]] += s;
+    for (int c = 0; c < BS; ++c) s = fma(inv[(size_t(r) * BS + c) * nb + b], rv[c], s);
+    y[dof] += s;
   }
 }
 
 template <int BS>
-static void launch_bgs_color(const nss_bjac_s& j, int c, double xscale, const double* x, double* y,
-                             const int32_t* done, hipStream_t st) {
+static void launch_bgs_solve(const nss_bjac_s& j, int c, double* y, const int32_t* done, hipStream_t st) {
   const int b0 = j.color_ptr[c], b1 = j.color_ptr[c + 1];
   if (b1 <= b0) return;
-  const nss_csr_s& a = *j.gs_mat;
-  hipLaunchKernelGGL((bgs_color_kernel<BS>), dim3((b1 - b0 + kBlock - 1) / kBlock), dim3(kBlock), 0, st, b0, b1,
-                     j.nblocks, j.idx, j.inv, a.rowptr, a.col, a.val, xscale, x, y, done);
+  hipLaunchKernelGGL((bgs_solve_kernel<BS>), dim3((b1 - b0 + kBlock - 1) / kBlock), dim3(kBlock), 0, st, b0, b1,
+                     j.nblocks, j.idx, j.ridx, j.inv, j.res, y, done);
 }
 
 void bjac_smooth(const nss_bjac_s& j, double xscale, const double* x, double* y, bool backward, const int32_t* done,
@@ -163,8 +168,10 @@ void bjac_smooth(const nss_bjac_s& j, double xscale, const double* x, double* y,
   const int nc = int(j.color_ptr.size()) - 1;
   for (int k = 0; k < nc; ++k) {
     const int c = backward ? nc - 1 - k : k;
+    launch_csr_stream(*j.gs_mat, y, EpiGsResidual{done, j.rowdof, x, j.res, xscale}, st, j.color_rowblk[c],
+                      j.color_rowblk[c + 1]);
     switch (j.bs) {
-#define NSS_GS(N) case N: launch_bgs_color<N>(j, c, xscale, x, y, done, st); break;
+#define NSS_GS(N) case N: launch_bgs_solve<N>(j, c, y, done, st); break;
       NSS_GS(1) NSS_GS(2) NSS_GS(3) NSS_GS(4) NSS_GS(5) NSS_GS(6) NSS_GS(7) NSS_GS(8)
       NSS_GS(9) NSS_GS(10) NSS_GS(11) NSS_GS(12) NSS_GS(13) NSS_GS(14) NSS_GS(15) NSS_GS(16)
 #undef NSS_GS
@@ -274,6 +281,9 @@ int nss_bjac_destroy(nss_bjac_t j) {
     (void)hipFree(j->idx);
     (void)hipFree(j->inv);
     (void)hipFree(j->covered);
+    (void)hipFree(j->rowdof);
+    (void)hipFree(j->ridx);
+    (void)hipFree(j->res);
     delete j;
   });
 }
@@ -286,16 +296,45 @@ int nss_bjac_apply_f64(nss_bjac_t j, double alpha, const double* x, double beta,
   });
 }
 
-int nss_bjac_set_colors(nss_bjac_t j, nss_csr_t a, int32_t ncolors, const int32_t* h_color_ptr) {
+int nss_bjac_set_colors(nss_bjac_t j, nss_csr_t a_perm, int32_t ncolors, const int32_t* h_color_ptr,
+                        const int32_t* h_color_rowptr, const int32_t* h_rowdof, const int32_t* h_ridx) {
   return guarded([&] {
-    NSS_REQUIRE(j != nullptr && a != nullptr && h_color_ptr != nullptr, "bjac_set_colors: NULL argument");
-    NSS_REQUIRE(a->m == a->n && a->m == j->n, "bjac_set_colors: matrix does not match the blocks");
+    NSS_REQUIRE(j && a_perm && h_color_ptr && h_color_rowptr && h_rowdof && h_ridx, "bjac_set_colors: NULL argument");
+    NSS_REQUIRE(a_perm->n == j->n, "bjac_set_colors: permuted matrix has the wrong column count");
     NSS_REQUIRE(ncolors >= 1, "bjac_set_colors: need at least one colour");
     NSS_REQUIRE(h_color_ptr[0] == 0 && h_color_ptr[ncolors] == j->nblocks, "bjac_set_colors: colour offsets must span the blocks");
+    NSS_REQUIRE(h_color_rowptr[0] == 0 && h_color_rowptr[ncolors] == a_perm->m, "bjac_set_colors: colour row offsets must span the permuted rows");
     for (int c = 0; c < ncolors; ++c)
-      NSS_REQUIRE(h_color_ptr[c + 1] >= h_color_ptr[c], "bjac_set_colors: colour offsets not monotone");
-    j->gs_mat = a;
+      NSS_REQUIRE(h_color_ptr[c + 1] >= h_color_ptr[c] && h_color_rowptr[c + 1] >= h_color_rowptr[c],
+                  "bjac_set_colors: colour offsets not monotone");
+    for (int32_t r = 0; r < a_perm->m; ++r)
+      NSS_REQUIRE(h_rowdof[r] >= 0 && h_rowdof[r] < j->n, "bjac_set_colors: rowdof out of range");
+    for (int64_t i = 0; i < int64_t(j->bs) * j->nblocks; ++i)
+      NSS_REQUIRE(h_ridx[i] >= -1 && h_ridx[i] < a_perm->m, "bjac_set_colors: ridx out of range");
+    // colour row offsets -> row-block offsets of the permuted matrix's launch plan
+    std::vector<int32_t> rb(size_t(a_perm->nblk) + 1);
+    NSS_HIP(hipMemcpy(rb.data(), a_perm->rowblk, sizeof(int32_t) * rb.size(), hipMemcpyDeviceToHost));
+    std::vector<int32_t> crb(size_t(ncolors) + 1);
+    size_t pos = 0;
+    for (int c = 0; c <= ncolors; ++c) {
+      while (pos < rb.size() && rb[pos] < h_color_rowptr[c]) ++pos;
+      NSS_REQUIRE(pos < rb.size() && rb[pos] == h_color_rowptr[c],
+                  "bjac_set_colors: a row block of the permuted matrix spans two colours (create it with cuts)");
+      crb[c] = int32_t(pos);
+    }
+    (void)hipFree(j->rowdof);
+    (void)hipFree(j->ridx);
+    (void)hipFree(j->res);
+    j->rowdof = j->ridx = nullptr;
+    j->res = nullptr;
+    NSS_HIP(hipMalloc(&j->rowdof, sizeof(int32_t) * std::max<size_t>(1, a_perm->m)));
+    NSS_HIP(hipMalloc(&j->ridx, sizeof(int32_t) * size_t(j->bs) * j->nblocks));
+    NSS_HIP(hipMalloc(&j->res, sizeof(double) * std::max<size_t>(1, a_perm->m)));
+    NSS_HIP(hipMemcpy(j->rowdof, h_rowdof, sizeof(int32_t) * a_perm->m, hipMemcpyHostToDevice));
+    NSS_HIP(hipMemcpy(j->ridx, h_ridx, sizeof(int32_t) * size_t(j->bs) * j->nblocks, hipMemcpyHostToDevice));
+    j->gs_mat = a_perm;
     j->color_ptr.assign(h_color_ptr, h_color_ptr + ncolors + 1);
+    j->color_rowblk = crb;
   });
 }
 

@@ -7,7 +7,7 @@
 namespace nss {
 
 static void plan_row_blocks(int32_t m, int64_t nnz, const int32_t* rowptr, int32_t* rg_out,
-                            std::vector<int32_t>& blk) {
+                            std::vector<int32_t>& blk, const int32_t* cuts = nullptr, int ncuts = 0) {
   const double mean = m > 0 ? double(nnz) / double(m) : 0.0;
   int rg = 1;
   if (mean > 192.0) rg = 64;
@@ -22,10 +22,13 @@ static void plan_row_blocks(int32_t m, int64_t nnz, const int32_t* rowptr, int32
   blk.clear();
   blk.push_back(0);
   int32_t r = 0;
+  int ci = 0;
   while (r < m) {
     const int32_t start = r;
     int64_t acc = 0;
-    while (r < m && r - start < row_cap) {
+    while (ci < ncuts && cuts[ci] <= start) ++ci;          // next cut strictly above the block start
+    const int32_t limit = ci < ncuts ? std::min<int32_t>(m, cuts[ci]) : m;
+    while (r < limit && r - start < row_cap) {
       const int64_t len = int64_t(rowptr[r + 1]) - rowptr[r];
       if (acc + len > kChunk) break;
       acc += len;
@@ -55,7 +58,16 @@ extern "C" {
 
 int nss_csr_create(int32_t nrows, int32_t ncols, int64_t nnz, const int32_t* h_rowptr, const int32_t* h_col,
                    const double* h_val, nss_csr_t* out) {
+  return nss_csr_create_cuts(nrows, ncols, nnz, h_rowptr, h_col, h_val, 0, nullptr, out);
+}
+
+int nss_csr_create_cuts(int32_t nrows, int32_t ncols, int64_t nnz, const int32_t* h_rowptr, const int32_t* h_col,
+                        const double* h_val, int32_t ncuts, const int32_t* h_cuts, nss_csr_t* out) {
   return guarded([&] {
+    NSS_REQUIRE(ncuts >= 0 && (ncuts == 0 || h_cuts != nullptr), "csr_create: bad cuts");
+    for (int i = 0; i < ncuts; ++i)
+      NSS_REQUIRE(h_cuts[i] >= 0 && h_cuts[i] <= nrows && (i == 0 || h_cuts[i] >= h_cuts[i - 1]),
+                  "csr_create: cuts must be ascending row positions");
     NSS_REQUIRE(out != nullptr, "csr_create: out is NULL");
     NSS_REQUIRE(nrows >= 0 && ncols >= 0 && nnz >= 0, "csr_create: negative size");
     NSS_REQUIRE(nnz < (int64_t(1) << 31), "csr_create: nnz must fit int32 offsets");
@@ -71,7 +83,7 @@ int nss_csr_create(int32_t nrows, int32_t ncols, int64_t nnz, const int32_t* h_r
       A->n = ncols;
       A->nnz = nnz;
       std::vector<int32_t> blk;
-      plan_row_blocks(nrows, nnz, h_rowptr, &A->rg, blk);
+      plan_row_blocks(nrows, nnz, h_rowptr, &A->rg, blk, h_cuts, ncuts);
       A->nblk = int32_t(blk.size()) - 1;
       NSS_HIP(hipMalloc(&A->rowptr, sizeof(int32_t) * (size_t(nrows) + 1)));
       NSS_HIP(hipMalloc(&A->col, sizeof(int32_t) * std::max<int64_t>(nnz, 1)));

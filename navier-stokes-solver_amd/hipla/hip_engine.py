@@ -54,7 +54,8 @@ def _signatures():
         "nss_bjac_destroy": (C.c_int, [vp]),
         "nss_bjac_apply_f64": (C.c_int, [vp, dbl, vp, dbl, vp, vp]),
         "nss_bjac_info": (C.c_int, [vp, c_i32_p, c_i32_p, c_i64_p, c_i64_p]),
-        "nss_bjac_set_colors": (C.c_int, [vp, vp, i32, vp]),
+        "nss_bjac_set_colors": (C.c_int, [vp, vp, i32, vp, vp, vp, vp]),
+        "nss_csr_create_cuts": (C.c_int, [i32, i32, i64, vp, vp, vp, i32, vp, C.POINTER(vp)]),
         "nss_bjac_smooth_f64": (C.c_int, [vp, dbl, vp, vp, i32, vp]),
         "nss_bjac_symgs_apply_f64": (C.c_int, [vp, dbl, vp, vp, vp]),
         "nss_bpcg2_workspace": (C.c_int, [vp, c_i64_p, c_i64_p, c_i64_p]),
@@ -255,13 +256,16 @@ class HipEngine:
                                                   self.stream))
 
     # ---- operators ----------------------------------------------------------------------------
-    def csr_create(self, m, n, rowptr, col, val):
+    def csr_create(self, m, n, rowptr, col, val, cuts=None):
+        """`cuts`: ascending row positions no row block of the launch plan may span."""
         rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
         col = np.ascontiguousarray(col, dtype=np.int32)
         val = np.ascontiguousarray(val, dtype=np.float64)
+        cuts = np.zeros(0, dtype=np.int32) if cuts is None else np.ascontiguousarray(cuts, dtype=np.int32)
         out = C.c_void_p()
-        self._check(self.lib.nss_csr_create(m, n, col.size, rowptr.ctypes.data, col.ctypes.data,
-                                            val.ctypes.data, C.byref(out)))
+        self._check(self.lib.nss_csr_create_cuts(m, n, col.size, rowptr.ctypes.data, col.ctypes.data,
+                                                 val.ctypes.data, cuts.size, cuts.ctypes.data if cuts.size else None,
+                                                 C.byref(out)))
         return _CsrHandle(self, out, m, n, int(col.size))
 
     def csr_spmv(self, h, alpha, x, beta, y):
@@ -282,10 +286,11 @@ class HipEngine:
         self._check(self.lib.nss_bjac_create(csr_handle.ptr, bs, nb, idx.ctypes.data, C.byref(out)))
         return _BjacHandle(self, out, bs, nb, csr_handle.m)
 
-    def bjac_set_colors(self, h, csr_handle, color_ptr):
-        color_ptr = np.ascontiguousarray(color_ptr, dtype=np.int32)
-        self._check(self.lib.nss_bjac_set_colors(h.ptr, csr_handle.ptr, color_ptr.size - 1, color_ptr.ctypes.data))
-        h.keep_matrix = csr_handle          # the sweeps walk the CSR rows: keep it alive
+    def bjac_set_colors(self, h, perm_handle, color_ptr, color_rowptr, rowdof, ridx):
+        arrs = [np.ascontiguousarray(a, dtype=np.int32) for a in (color_ptr, color_rowptr, rowdof, ridx)]
+        self._check(self.lib.nss_bjac_set_colors(h.ptr, perm_handle.ptr, arrs[0].size - 1,
+                                                 *[a.ctypes.data for a in arrs]))
+        h.keep_matrix = perm_handle         # the sweeps stream the permuted rows: keep them alive
 
     def bjac_smooth(self, h, xscale, x, y, backward):
         if x.shape[0] != h.n or y.shape[0] != h.n:

@@ -627,7 +627,21 @@ class BlockGaussSeidel(BaseMatrix):
         self.ncolors = int(ptr.size - 1)
         self.bs, self.nblocks = self.idx_host.shape
         self.handle = self.engine.bjac_create(mat.handle, self.idx_host)
-        self.engine.bjac_set_colors(self.handle, mat.handle, ptr)
+        # rows of A re-ordered block by block in colour-major order (columns unchanged): the
+        # residual of one colour becomes a streaming SpMV over a contiguous row range
+        live = self.idx_host.T >= 0                                  # (nblocks, bs), block-major
+        rowdof = self.idx_host.T[live].astype(np.int64)              # original dof of permuted row r
+        ridx = -np.ones(self.idx_host.T.shape, dtype=np.int32)
+        ridx[live] = np.arange(rowdof.size, dtype=np.int32)
+        rows_per_block = live.sum(axis=1)
+        block_row0 = np.concatenate([[0], np.cumsum(rows_per_block)])
+        color_rowptr = block_row0[ptr]
+        perm = mat.to_scipy()[rowdof]
+        perm.sort_indices()
+        self.perm_handle = self.engine.csr_create(perm.shape[0], perm.shape[1], perm.indptr, perm.indices, perm.data,
+                                                  cuts=color_rowptr)
+        self.engine.bjac_set_colors(self.handle, self.perm_handle, ptr, color_rowptr, rowdof,
+                                    np.ascontiguousarray(ridx.T))
 
     def Height(self):
         return self.n

@@ -87,7 +87,7 @@ class NumpyEngine:
         return total
 
     # ---- operators -------------------------------------------------------------
-    def csr_create(self, m, n, rowptr, col, val):
+    def csr_create(self, m, n, rowptr, col, val, cuts=None):
         return _Csr(sp.csr_matrix((val, col, rowptr), shape=(m, n)))
 
     def csr_spmv(self, h, alpha, x, beta, y):
@@ -122,8 +122,12 @@ class NumpyEngine:
         inv = np.linalg.inv(blocks)
         return _Bjac(idx.copy(), inv)
 
-    def bjac_set_colors(self, h, csr_handle, color_ptr):
-        h.mat = csr_handle.mat.tocsr()
+    def bjac_set_colors(self, h, perm_handle, color_ptr, color_rowptr, rowdof, ridx):
+        # undo the row permutation: the checker sweeps on the matrix in its original row order
+        perm = perm_handle.mat.tocsr()
+        coo = perm.tocoo()
+        h.mat = sp.csr_matrix((coo.data, (np.asarray(rowdof, dtype=np.int64)[coo.row], coo.col)),
+                              shape=(perm.shape[1], perm.shape[1]))
         h.color_ptr = np.array(color_ptr, dtype=np.int64)
 
     def bjac_smooth(self, h, xscale, x, y, backward):
