@@ -17,7 +17,7 @@ from staggered_grid import mac_stokes
 
 __all__ = ["taylor_hood", "P1_nonconforming_velocity_constant_pressure", "P2_velocity_constant_pressure",
            "P2_velocity_linear_pressure", "P2_velocity_with_cubic_bubbles_linear_pressure", "mini",
-           "bdm_hybrid", "rt_hybrid", "hcurldiv", "SyntheticMesh", "assemble", "AssembledForm"]
+           "bdm_hybrid", "rt_hybrid", "hcurldiv", "SyntheticMesh", "assemble", "AssembledForm", "CondensedForm"]
 
 
 class SyntheticMesh:
@@ -75,6 +75,32 @@ class AssembledForm:
 
     def Assemble(self):
         return self
+
+
+class CondensedForm:
+    """Statically condensed BilinearForm-like operand (``condense=True, store_inner=True`` of
+    templates/NavierStokesSIMPLE_iterative.py:188): ``.mat`` is the Schur complement on the
+    coupling dofs, plus the harmonic-extension / inner-solve operators
+    solvers/bramblepasciak_new.py:11-17,88 applies.  All operators are CSR matrices in HBM."""
+
+    def __init__(self, system, seed=0):
+        parts = system.condense(seed)
+        self.condense = True
+        self.interior = parts["interior"]
+        self.mat = hipla.SparseMatrix.from_scipy(parts["mat"])
+        self.inner_matrix = hipla.SparseMatrix.from_scipy(parts["inner_matrix"])
+        self.inner_solve = hipla.SparseMatrix.from_scipy(parts["inner_solve"])
+        self.harmonic_extension = hipla.SparseMatrix.from_scipy(parts["harmonic_extension"])
+        self.harmonic_extension_trans = hipla.SparseMatrix.from_scipy(parts["harmonic_extension_trans"])
+        self.schur_host = parts["mat"]
+
+    def jacobi(self):
+        """Point Jacobi of the Schur complement on the coupling dofs (zero on the interior ones) --
+        a preconditioner for the condensed system, as `Preconditioner(blfA, ...)` is in the
+        reference when the form is condensed."""
+        d = self.schur_host.diagonal()
+        inv = np.where(self.interior, 0.0, 1.0 / np.where(d != 0.0, d, 1.0))
+        return hipla.DiagonalMatrix(inv)
 
 
 class AssembledVector:

@@ -140,6 +140,42 @@ class StokesSystem:
         cuts = np.round(np.arange(nranks + 1) * self.n / nranks).astype(np.int64)
         return self.velocity_slab_offsets[cuts].copy(), self.pressure_slab_offsets[cuts].copy()
 
+    def condense(self, seed=0):
+        """Static condensation of A: split the velocity dofs into an
+        *interior* set I (a maximal independent set of A's graph, so A_ii is diagonal -- the role
+        the element-interior dofs play in the reference) and the coupling set C, and return the
+        operators the reference reads off a condensed BilinearForm
+        (solvers/bramblepasciak_new.py:11-17,88): ``mat`` = Schur complement S = A_cc - A_ci A_ii^-1
+        A_ic, ``inner_matrix`` = A_ii, ``inner_solve`` = A_ii^-1, ``harmonic_extension`` = E with
+        E_ic = -A_ii^-1 A_ic, ``harmonic_extension_trans`` = E^T -- all embedded in n_u x n_u, so
+        that (I - E^T)(S + A_ii)(I - E) = A."""
+        from hipla import coloring
+        n = self.n_u
+        singletons = np.arange(n, dtype=np.int32)[None, :]
+        colors = coloring.color_blocks(coloring.block_graph(self.A, singletons), seed)
+        interior = colors == 0
+        I = np.nonzero(interior)[0]
+        Cc = np.nonzero(~interior)[0]
+        A = self.A.tocsr()
+        a_ii = A[I][:, I]
+        assert abs(a_ii - sp.diags(a_ii.diagonal())).max() == 0.0      # independent set: diagonal block
+        dii = a_ii.diagonal()
+        a_ic, a_ci, a_cc = A[I][:, Cc], A[Cc][:, I], A[Cc][:, Cc]
+        schur = (a_cc - a_ci @ sp.diags(1.0 / dii) @ a_ic).tocoo()
+        e_ic = (-(sp.diags(1.0 / dii) @ a_ic)).tocoo()
+
+        def embed(m, rows, cols):
+            return sp.csr_matrix((m.data, (rows[m.row], cols[m.col])), shape=(n, n))
+
+        S = embed(schur, Cc, Cc)
+        E = embed(e_ic, I, Cc)
+        inner = sp.csr_matrix((dii, (I, I)), shape=(n, n))
+        inner_solve = sp.csr_matrix((1.0 / dii, (I, I)), shape=(n, n))
+        for m in (S, E, inner, inner_solve):
+            m.sort_indices()
+        return {"mat": S, "inner_matrix": inner, "inner_solve": inner_solve, "harmonic_extension": E,
+                "harmonic_extension_trans": E.T.tocsr(), "interior": interior}
+
     def inflate(self, bs, seed=1):
         """'HDG-like' stress variant: Kronecker-inflate A with a seeded SPD bs x bs
         block (about 7*bs non-zeros per row, cf. the reference's ~84 at order 2 in 3-D)

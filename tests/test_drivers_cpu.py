@@ -154,3 +154,40 @@ def test_multicolour_block_gauss_seidel_against_sequential_oracle(numpy_engine):
     it_ref, u, p, hist, err0 = kr.bpcg_v2(s.A, s.B, pa, kr.diag_inverse(s.mass), f, gg, k, tol=1e-8, maxsteps=500)
     assert abs(it - it_ref) <= 2
     assert np.linalg.norm(sol.numpy() - np.concatenate([u, p])) < 1e-6 * np.linalg.norm(u)
+
+
+def test_static_condensation_path(numpy_engine):
+    """Scope row N2 through the protocol: (I - E^T)(S + A_ii)(I - E) = A on the synthetic
+    partition, and BramblePasciakCG with ``blfA.condense = True`` (harmonic_extension's condensed
+    branch + the composite A operator, solvers/bramblepasciak_new.py:11-18,84-109) reproduces the
+    uncondensed solve."""
+    import hipla
+    from discretizations import AssembledForm, CondensedForm
+    from solvers.bramblepasciak_new import BramblePasciakCG
+    from staggered_grid import mac_stokes
+    s = mac_stokes(2, 10, 0.01)
+    parts = s.condense()
+    n = s.n_u
+    import scipy.sparse as sp
+    eye = sp.identity(n)
+    recon = (eye - parts["harmonic_extension_trans"]) @ (parts["mat"] + parts["inner_matrix"]) @ (eye - parts["harmonic_extension"])
+    assert abs(recon - s.A).max() < 1e-14 * abs(s.A).max()
+    assert 0.1 * n < parts["interior"].sum() < 0.6 * n
+    blfA = CondensedForm(s)
+    blfB = AssembledForm(hipla.SparseMatrix.from_scipy(s.B))
+    f, g = s.rhs(0)
+    preM = hipla.DiagonalMatrix(1.0 / s.mass)
+    sol = hipla.BlockVector([hipla.Vector(s.n_u), hipla.Vector(s.n_p)])
+    with contextlib.redirect_stdout(io.StringIO()):
+        it, _ = BramblePasciakCG(blfA, blfB, None, hipla.Vector.from_numpy(f), hipla.Vector.from_numpy(g),
+                                 blfA.jacobi(), preM, sol, tol=1e-9, maxsteps=3000)
+    A = hipla.SparseMatrix.from_scipy(s.A)
+    ref = hipla.BlockVector([hipla.Vector(s.n_u), hipla.Vector(s.n_p)])
+    with contextlib.redirect_stdout(io.StringIO()):
+        it_ref, _ = BramblePasciakCG(AssembledForm(A), blfB, None, hipla.Vector.from_numpy(f), hipla.Vector.from_numpy(g),
+                                     hipla.JacobiPreconditioner(A), preM, ref, tol=1e-9, maxsteps=3000)
+    x, xr = sol.numpy(), ref.numpy()
+    b = np.concatenate([f, g])
+    assert np.linalg.norm(b - s.saddle_matrix() @ x) < 1e-5 * np.linalg.norm(b)
+    assert np.linalg.norm(x[:n] - xr[:n]) < 1e-5 * np.linalg.norm(xr[:n])
+    assert 5 < it < 3000

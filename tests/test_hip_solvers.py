@@ -529,3 +529,30 @@ def test_fused_loops_with_block_gauss_seidel_preconditioner(hip_engine):
             ns.SolveInitial(iterative=True, GS=gs, tol=1e-8)
         counts[gs] = ns.stokes_bpcg_iterations
     assert 3 < counts[True] < counts[False]
+
+
+def test_static_condensation_path_on_gpu(hip_engine):
+    """Scope row N2 on the product engine: `blfA.condense = True` drives harmonic_extension's
+    condensed branch and the composite operator (I - H^T)(S + A_ii)(I - H) through the protocol
+    (SpMV / lincomb kernels), and the solve agrees with the uncondensed fused loop."""
+    import hipla
+    from discretizations import AssembledForm, CondensedForm
+    from solvers.bramblepasciak_new import BramblePasciakCG
+    s = mac_stokes(3, 8, 0.01)
+    blfA, blfB = CondensedForm(s), AssembledForm(hipla.SparseMatrix.from_scipy(s.B))
+    f, g = s.rhs(0)
+    preM = hipla.DiagonalMatrix(1.0 / s.mass)
+    sol = hipla.BlockVector([hipla.Vector(s.n_u), hipla.Vector(s.n_p)])
+    with contextlib.redirect_stdout(io.StringIO()):
+        it, _ = BramblePasciakCG(blfA, blfB, None, hipla.Vector.from_numpy(f), hipla.Vector.from_numpy(g),
+                                 blfA.jacobi(), preM, sol, tol=1e-9, maxsteps=5000)
+    A = hipla.SparseMatrix.from_scipy(s.A)
+    ref = hipla.BlockVector([hipla.Vector(s.n_u), hipla.Vector(s.n_p)])
+    with contextlib.redirect_stdout(io.StringIO()):
+        BramblePasciakCG(AssembledForm(A), blfB, None, hipla.Vector.from_numpy(f), hipla.Vector.from_numpy(g),
+                         hipla.JacobiPreconditioner(A), preM, ref, tol=1e-9, maxsteps=5000)
+    x, xr = sol.numpy(), ref.numpy()
+    b = np.concatenate([f, g])
+    assert np.linalg.norm(b - s.saddle_matrix() @ x) < 1e-5 * np.linalg.norm(b)
+    assert np.linalg.norm(x[:s.n_u] - xr[:s.n_u]) < 1e-5 * np.linalg.norm(xr[:s.n_u])
+    assert 5 < it < 5000
