@@ -141,7 +141,7 @@ NSS_API int nss_bjac_symgs_apply_f64(nss_bjac_t j, double xscale, const double* 
  * Vector lengths: n_u for u0,d0,w0,s0,z0,q,t0,t2 ; t1 and t4 are SpMV operands of A and B and
  * have A's / B's column count (n_u plus halo entries in a row-partitioned run); n_p for
  * u1,d1,w1,t3 ; s1 is the operand of B^T (B^T's column count).
- * scal: double[8] = { wd, as_s, wdn, alpha, beta, err0, tol, rel_err(0/1) };
+ * scal: double[16] = { wd (even it), as_s, wdn, alpha, beta, err0, tol, rel_err(0/1), wd (odd it) };
  * ctrl: int32[4]  = { done, it_final, last_it, breakdown };  hist: double[maxsteps]. */
 typedef struct nss_bpcg2_s {
   nss_csr_t A, B, BT;          /* A: n_u rows; B: n_p rows; BT: n_u rows (explicit transpose, :198) */
@@ -162,11 +162,11 @@ enum {
   NSS_BPCG2_K2 = 2,    /* t2 = A t1, t4 = t1 - s0, partials <s0, t2 - t0>                             */
   NSS_BPCG2_K3 = 3,    /* t3 = B t4, partials <s1, t3>                                                */
   NSS_BPCG2_SUM1 = 4,  /* scal[as_s] = local sum of the K2/K3 partials                               */
-  NSS_BPCG2_ALPHA = 5, /* alpha = wd / as_s                                                           */
-  NSS_BPCG2_K4 = 6,    /* u += a s, d -= a v, w -= a C^-1 v, partials <w, d>                         */
+  NSS_BPCG2_ALPHA = 5, /* no-op: alpha = wd / as_s is evaluated inside K4                              */
+  NSS_BPCG2_K4 = 6,    /* alpha; u += a s, d -= a v, w -= a C^-1 v, partials <w, d>                  */
   NSS_BPCG2_SUM2 = 7,  /* scal[wdn] = local sum of the K4 partials                                   */
-  NSS_BPCG2_BETA = 8,  /* beta = wdn / wd, hist[it] = sqrt|wd|, stop test, wd <- wdn                */
-  NSS_BPCG2_K5 = 9     /* s1 = beta s1 + w1                                                           */
+  NSS_BPCG2_BETA = 8,  /* no-op: folded into K5                                                      */
+  NSS_BPCG2_K5 = 9     /* beta = wdn / wd, s1 = beta s1 + w1, hist[it] = sqrt|wd|, stop test          */
 };
 
 NSS_API int nss_bpcg2_workspace(const nss_bpcg2_t* s, int64_t* partials_a, int64_t* partials_b,

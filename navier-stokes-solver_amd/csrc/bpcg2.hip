@@ -11,22 +11,27 @@
 //   [J] block-Jacobi preA: t1 = k * J t0 (:209)
 //   K2  rows of A   :  t2 = A t1 (:210), t4 = t1 - s0 (:212), partial <s0, t2 - t0> (:218,222)
 //   K3  rows of B   :  t3 = B t4 (:213), partial <s1, t3> (:219,222)
-//   R1               :  as_s = sum partials, alpha = wd / as_s (:226)
-//   K4  element-wise:  u += a*s (:228), d -= a*v (:229), w0 -= a*t1, w1 -= a*minv*t3 (:232-233),
-//                      partial <w, d> (:235)
-//   R2               :  wdn, beta = wdn / wd (:236), hist[it] = sqrt|wd| (:243), stop test (:246)
-//   K5  element-wise:  s1 = b*s1 + w1 (:240-241, pressure part)
+//   R1               :  as_s = sum of the partials (one workgroup, fixed order)
+//   K4  element-wise:  alpha = wd / as_s (:226); u += a*s (:228), d -= a*v (:229), w0 -= a*t1,
+//                      w1 -= a*minv*t3 (:232-233), partial <w, d> (:235)
+//   R2               :  wdn = sum of the partials
+//   K5  element-wise:  beta = wdn / wd (:236), s1 = b*s1 + w1 (:240-241, pressure part); one lane:
+//                      hist[it] = sqrt|wd| (:243), stop test (:246)
 //
 // alpha, beta, wd and the `done` flag live in device memory: nothing is copied to the host
 // inside the loop.  Once `done` is set every kernel returns immediately, so the state is
 // frozen exactly at the reference's `break` and the host may poll every m iterations.
-// R1/R2 are split into "local sum" and "scalar step" so that the row-partitioned
-// multi-GPU loop can all-reduce the local sums in between.
+// R1/R2 only form local sums; alpha and beta are evaluated by the consuming kernels, so the
+// row-partitioned multi-GPU loop simply all-reduces scal[as_s] / scal[wdn] in between
+// (SURVEY.md section 8e).
 #include "bpcg2.h"
 
 namespace nss {
 
-enum { S_WD = 0, S_AS = 1, S_WDN = 2, S_ALPHA = 3, S_BETA = 4, S_ERR0 = 5, S_TOL = 6, S_REL = 7 };
+enum { S_WD = 0, S_AS = 1, S_WDN = 2, S_ALPHA = 3, S_BETA = 4, S_ERR0 = 5, S_TOL = 6, S_REL = 7, S_WD_ODD = 8 };
+// wd of iteration `it` lives in slot S_WD (it even) or S_WD_ODD (it odd): K5 of iteration it writes
+// the slot of it+1 while its other lanes still read the slot of it.
+__device__ __forceinline__ int wd_slot(int it) { return (it & 1) ? S_WD_ODD : S_WD; }
 enum { C_DONE = 0, C_IT_FINAL = 1, C_LAST_IT = 2, C_BREAKDOWN = 3 };
 
 struct EpiK1 {
@@ -146,39 +151,10 @@ __global__ __launch_bounds__(kSumBlock) void bpcg2_sum_kernel(const int32_t* __r
   }
 }
 
-// scalar steps (one lane): which = 1 -> alpha; which = 2 -> beta, history, stop test
-__global__ void bpcg2_scalar_kernel(int32_t* __restrict__ ctrl, double* __restrict__ scal, double* __restrict__ hist,
-                                    int which, int it) {
-  if (threadIdx.x != 0 || ctrl[C_DONE] != 0) return;
-  if (which == 1) {
-    // <s, K^ s> == 0: the reference's `alpha = wd / as_s` (:226) raises ZeroDivisionError in Python;
-    // freeze the state and report it (ctrl[3]) so that the host can raise the same error
-    if (scal[S_AS] == 0.0) {
-      ctrl[C_BREAKDOWN] = 1;
-      ctrl[C_IT_FINAL] = it;
-      ctrl[C_DONE] = 1;
-      return;
-    }
-    scal[S_ALPHA] = scal[S_WD] / scal[S_AS];
-  } else {
-    const double wd = scal[S_WD], wdn = scal[S_WDN];
-    scal[S_BETA] = wdn / wd;
-    const double err = sqrt(fabs(wd));
-    hist[it] = err;
-    ctrl[C_LAST_IT] = it;
-    scal[S_WD] = wdn;
-    const double bound = scal[S_TOL] * (scal[S_REL] != 0.0 ? scal[S_ERR0] : 1.0);
-    if (err < bound) {
-      ctrl[C_IT_FINAL] = it;
-      ctrl[C_DONE] = 1;
-    }
-  }
-}
-
 struct K4Args {
-  const int32_t* ctrl;
-  const double* scal;
-  int32_t n_u, n_p;
+  int32_t* ctrl;
+  double* scal;
+  int32_t n_u, n_p, it;
   double *u0, *d0, *w0, *u1, *d1, *w1;
   const double *s0, *t0, *t1, *t2, *s1, *t3, *minv;
   double* partials;
@@ -187,7 +163,20 @@ struct K4Args {
 __global__ __launch_bounds__(kBlock) void bpcg2_k4_kernel(K4Args a) {
   __shared__ double lds[kBlock / kWave];
   if (a.ctrl[C_DONE] != 0) return;
-  const double alpha = a.scal[S_ALPHA];
+  // alpha = wd / <s, K^ s> (:226), evaluated by every lane from the (all-)reduced sum.
+  // <s, K^ s> == 0: the reference raises ZeroDivisionError in Python; freeze the state and report
+  // it (ctrl[3]) so that the host can raise the same error.
+  const double as_s = a.scal[S_AS];
+  if (as_s == 0.0) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      a.ctrl[C_BREAKDOWN] = 1;
+      a.ctrl[C_IT_FINAL] = a.it;
+      a.ctrl[C_DONE] = 1;
+    }
+    return;
+  }
+  const double alpha = a.scal[wd_slot(a.it)] / as_s;
+  if (blockIdx.x == 0 && threadIdx.x == 0) a.scal[S_ALPHA] = alpha;   // K1 of the next iteration
   const int stride = gridDim.x * kBlock;
   double acc = 0.0;
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < a.n_u; i += stride) {
@@ -212,11 +201,27 @@ __global__ __launch_bounds__(kBlock) void bpcg2_k4_kernel(K4Args a) {
   if (threadIdx.x == 0) a.partials[blockIdx.x] = s;
 }
 
-__global__ __launch_bounds__(kBlock) void bpcg2_k5_kernel(const int32_t* __restrict__ ctrl,
-                                                           const double* __restrict__ scal, int32_t n_p,
+// K5: beta = wdn / wd (:236) by every lane; lane 0 of workgroup 0 also keeps the books: history
+// entry (:243), stop test (:246), wd of the next iteration, beta for K1.  The lanes that see the
+// freshly set `done` flag may skip the s1 update of this last iteration: s is not returned.
+__global__ __launch_bounds__(kBlock) void bpcg2_k5_kernel(int32_t* __restrict__ ctrl, double* __restrict__ scal,
+                                                           double* __restrict__ hist, int32_t it, int32_t n_p,
                                                            double* __restrict__ s1, const double* __restrict__ w1) {
   if (ctrl[C_DONE] != 0) return;
-  const double beta = scal[S_BETA];
+  const double wd = scal[wd_slot(it)], wdn = scal[S_WDN];
+  const double beta = wdn / wd;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    scal[S_BETA] = beta;
+    scal[wd_slot(it + 1)] = wdn;
+    const double err = sqrt(fabs(wd));
+    hist[it] = err;
+    ctrl[C_LAST_IT] = it;
+    const double bound = scal[S_TOL] * (scal[S_REL] != 0.0 ? scal[S_ERR0] : 1.0);
+    if (err < bound) {
+      ctrl[C_IT_FINAL] = it;
+      ctrl[C_DONE] = 1;
+    }
+  }
   const int stride = gridDim.x * kBlock;
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < n_p; i += stride) s1[i] = fma(beta, s1[i], w1[i]);
 }
@@ -279,12 +284,10 @@ void bpcg2_phase(const nss_bpcg2_t& s, int which, int it, hipStream_t st) {
                          s.partials_b, s.scal, int(S_AS));
       NSS_CHECK_LAUNCH();
       break;
-    case NSS_BPCG2_ALPHA:
-      hipLaunchKernelGGL(bpcg2_scalar_kernel, dim3(1), dim3(kWave), 0, st, s.ctrl, s.scal, s.hist, 1, it);
-      NSS_CHECK_LAUNCH();
+    case NSS_BPCG2_ALPHA:   // folded into K4 (kept as a phase id for callers that list all phases)
       break;
     case NSS_BPCG2_K4: {
-      K4Args a{s.ctrl, s.scal, s.n_u, s.n_p, s.u0, s.d0, s.w0, s.u1, s.d1, s.w1,
+      K4Args a{s.ctrl, s.scal, s.n_u, s.n_p, it, s.u0, s.d0, s.w0, s.u1, s.d1, s.w1,
                s.s0, s.t0, s.t1, s.t2, s.s1, s.t3, s.minv, s.partials_c};
       hipLaunchKernelGGL(bpcg2_k4_kernel, dim3(k4_grid(s)), dim3(kBlock), 0, st, a);
       NSS_CHECK_LAUNCH();
@@ -295,13 +298,11 @@ void bpcg2_phase(const nss_bpcg2_t& s, int which, int it, hipStream_t st) {
                          s.partials_c, s.scal, int(S_WDN));
       NSS_CHECK_LAUNCH();
       break;
-    case NSS_BPCG2_BETA:
-      hipLaunchKernelGGL(bpcg2_scalar_kernel, dim3(1), dim3(kWave), 0, st, s.ctrl, s.scal, s.hist, 2, it);
-      NSS_CHECK_LAUNCH();
+    case NSS_BPCG2_BETA:    // folded into K5
       break;
     case NSS_BPCG2_K5:
       hipLaunchKernelGGL(bpcg2_k5_kernel, dim3(stream_grid(s.n_p, kBlock * 4)), dim3(kBlock), 0, st, s.ctrl, s.scal,
-                         s.n_p, s.s1, s.w1);
+                         s.hist, it, s.n_p, s.s1, s.w1);
       NSS_CHECK_LAUNCH();
       break;
     default:

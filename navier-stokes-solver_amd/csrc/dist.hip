@@ -10,7 +10,7 @@
 //   X: wait(C) . pack(s1) . group{send,recv} ;  C: K1 interior . wait(X) . K1 boundary . [block-Jacobi]
 //   X: wait(C) . pack(t1) . group{send,recv} ;  C: K2 interior . wait(X) . K2 boundary
 //   X: wait(C) . pack(t4) . group{send,recv} ;  C: K3 interior . wait(X) . K3 boundary
-//   C: SUM1 . allreduce(as_s) . ALPHA . K4 . SUM2 . allreduce(wdn) . BETA . K5
+//   C: SUM1 . allreduce(as_s) . K4 . SUM2 . allreduce(wdn) . K5
 // Interior row blocks touch no ghost column, so they overlap the exchange; xGMI is
 // point-to-point and only slab neighbours talk.  With overlap == 0 everything runs on C.
 #include "bpcg2.h"
@@ -185,12 +185,10 @@ int nss_bpcg2_iterate_dist(const nss_bpcg2_t* s, nss_dist_t d, const nss_halo_t*
       spmv_with_halo(*s, *d, *halo_t4, 2, NSS_BPCG2_K3, it, *s->B, ov, cs);
       bpcg2_phase(*s, NSS_BPCG2_SUM1, it, cs);
       allreduce_slot(*s, *d, S_AS_SLOT, cs);
-      bpcg2_phase(*s, NSS_BPCG2_ALPHA, it, cs);
-      bpcg2_phase(*s, NSS_BPCG2_K4, it, cs);
+      bpcg2_phase(*s, NSS_BPCG2_K4, it, cs);       // alpha inside
       bpcg2_phase(*s, NSS_BPCG2_SUM2, it, cs);
       allreduce_slot(*s, *d, S_WDN_SLOT, cs);
-      bpcg2_phase(*s, NSS_BPCG2_BETA, it, cs);
-      bpcg2_phase(*s, NSS_BPCG2_K5, it, cs);
+      bpcg2_phase(*s, NSS_BPCG2_K5, it, cs);       // beta, history, stop test inside
     }
   });
 }

@@ -130,7 +130,7 @@ class Bpcg2Loop:
         eng._check(self.lib.nss_bpcg2_workspace(C.byref(st), C.byref(na), C.byref(nb), C.byref(nc)))
         self.partials = [eng.zeros(max(1, v.value)) for v in (na, nb, nc)]
         st.partials_a, st.partials_b, st.partials_c = (p.data_ptr() for p in self.partials)
-        self.scal = eng.zeros(8)
+        self.scal = eng.zeros(16)
         self.ctrl = torch.zeros(4, dtype=torch.int32, device=eng.device)
         st.scal, st.ctrl = self.scal.data_ptr(), self.ctrl.data_ptr()
         self.hist = None
@@ -143,7 +143,7 @@ class Bpcg2Loop:
         self.maxsteps = int(maxsteps)
         self.hist = eng.zeros(max(1, self.maxsteps))
         st.hist = self.hist.data_ptr()
-        scal = np.zeros(8)
+        scal = np.zeros(16)
         scal[S_WD], scal[S_ERR0], scal[S_TOL], scal[S_REL] = wdn, err0, tol, 1.0 if rel_err else 0.0
         eng.upload(scal, self.scal)
         self.ctrl.zero_()
