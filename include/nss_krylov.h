@@ -83,6 +83,10 @@ NSS_API int nss_csr_create(int32_t nrows, int32_t ncols, int64_t nnz, const int3
 NSS_API int nss_csr_create_cuts(int32_t nrows, int32_t ncols, int64_t nnz, const int32_t* h_rowptr,
                                 const int32_t* h_col, const double* h_val, int32_t ncuts,
                                 const int32_t* h_cuts, nss_csr_t* out);
+/* explicit transpose as a new CSR handle (`matB.CreateTranspose()`, solvers/bramblepasciak_new.py:198;
+ * `b.T`, run.py:45).  Counting sort on the host inside the library, entries of a row of the result
+ * ordered by column; set-up, not on the iteration path. */
+NSS_API int nss_csr_transpose(nss_csr_t a, nss_csr_t* out);
 NSS_API int nss_csr_destroy(nss_csr_t a);
 /* y = alpha * A x + beta * y   (beta == 0: y is not read).  x must not alias y. */
 NSS_API int nss_csr_spmv_f64(nss_csr_t a, double alpha, const double* x, double beta, double* y,

@@ -41,6 +41,7 @@ def _signatures():
         "nss_stream_triad_f64": (C.c_int, [i64, dbl, vp, vp, vp, vp]),
         "nss_gather_f64": (C.c_int, [i64, vp, vp, vp, vp]),
         "nss_csr_create": (C.c_int, [i32, i32, i64, vp, vp, vp, C.POINTER(vp)]),
+        "nss_csr_transpose": (C.c_int, [vp, C.POINTER(vp)]),
         "nss_csr_destroy": (C.c_int, [vp]),
         "nss_csr_spmv_f64": (C.c_int, [vp, dbl, vp, dbl, vp, vp]),
         "nss_csr_info": (C.c_int, [vp, c_i32_p, c_i32_p, c_i64_p, c_i32_p, c_i32_p, c_i64_p]),
@@ -267,6 +268,11 @@ class HipEngine:
                                                  val.ctypes.data, cuts.size, cuts.ctypes.data if cuts.size else None,
                                                  C.byref(out)))
         return _CsrHandle(self, out, m, n, int(col.size))
+
+    def csr_transpose(self, h):
+        out = C.c_void_p()
+        self._check(self.lib.nss_csr_transpose(h.ptr, C.byref(out)))
+        return _CsrHandle(self, out, h.n, h.m, h.nnz)
 
     def csr_spmv(self, h, alpha, x, beta, y):
         if x.shape[0] != h.n or y.shape[0] != h.m:

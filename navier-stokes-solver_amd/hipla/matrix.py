@@ -397,7 +397,7 @@ class SparseMatrix(BaseMatrix):
     explicit transpose is built once and cached (reference:
     solvers/bramblepasciak_new.py:198 ``matB.CreateTranspose()``)."""
 
-    def __init__(self, m, n, rowptr, col, val, engine=None, host=None):
+    def __init__(self, m, n, rowptr, col, val, engine=None, handle=None):
         super().__init__()
         self.engine = engine if engine is not None else get_engine()
         self.m, self.n = int(m), int(n)
@@ -409,7 +409,7 @@ class SparseMatrix(BaseMatrix):
         if col.size and (col.min() < 0 or col.max() >= self.n):
             raise ValueError("CSR column index out of range")
         self.nnz = int(col.size)
-        self.handle = self.engine.csr_create(self.m, self.n, rowptr, col, val)
+        self.handle = handle if handle is not None else self.engine.csr_create(self.m, self.n, rowptr, col, val)
         self._transpose = None
         self._host = (rowptr, col, val)
 
@@ -446,12 +446,15 @@ class SparseMatrix(BaseMatrix):
         self.CreateTranspose().MultAdd(s, x, y)
 
     def CreateTranspose(self):
+        """Explicit transpose, built once by the engine (``nss_csr_transpose``) and cached."""
         if self._transpose is None:
-            import scipy.sparse as sp
+            th = self.engine.csr_transpose(self.handle)
             rowptr, col, val = self._host
-            t = sp.csr_matrix((val, col, rowptr), shape=(self.m, self.n)).transpose().tocsr()
-            t.sort_indices()
-            tm = SparseMatrix(self.n, self.m, t.indptr, t.indices, t.data, engine=self.engine)
+            # host mirror of the transposed arrays (used by set-up code such as diagonal())
+            order = np.argsort(col, kind="stable")
+            rows = np.repeat(np.arange(self.m, dtype=np.int32), np.diff(rowptr))
+            trow = np.concatenate([[0], np.cumsum(np.bincount(col, minlength=self.n))]).astype(np.int32)
+            tm = SparseMatrix(self.n, self.m, trow, rows[order], val[order], engine=self.engine, handle=th)
             tm._transpose = self
             self._transpose = tm
         return self._transpose

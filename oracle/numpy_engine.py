@@ -90,6 +90,11 @@ class NumpyEngine:
     def csr_create(self, m, n, rowptr, col, val, cuts=None):
         return _Csr(sp.csr_matrix((val, col, rowptr), shape=(m, n)))
 
+    def csr_transpose(self, h):
+        t = h.mat.T.tocsr()
+        t.sort_indices()
+        return _Csr(t)
+
     def csr_spmv(self, h, alpha, x, beta, y):
         ax = h.mat @ x
         if beta == 0.0:

@@ -295,3 +295,25 @@ def test_multicolour_block_gauss_seidel_sweeps(hip_engine, case):
     assert abs(np.dot(out.numpy(), z) - np.dot(x, gz.numpy())) < 1e-10 * np.linalg.norm(x) * np.linalg.norm(gz.numpy())
     out.data = 2.5 * G * X                       # scaled operator (preA = k * preA_unscaled)
     assert relerr(out.numpy(), 2.5 * kr.symmetric_block_gauss_seidel(s.A, G.idx_host)(x)) < 1e-12
+
+
+def test_csr_transpose_native(hip_engine):
+    """nss_csr_transpose (explicit B^T, solvers/bramblepasciak_new.py:198) against scipy, including a
+    ragged matrix with empty rows / columns; the cached transpose round-trips."""
+    import hipla
+    rng = np.random.default_rng(9)
+    mats = [mac_stokes(3, 7).B, mac_stokes(2, 11).A,
+            sp.random(300, 170, density=0.02, random_state=3, format="csr"), sp.csr_matrix((5, 9))]
+    for m in mats:
+        m = sp.csr_matrix(m)
+        m.sort_indices()
+        M = hipla.SparseMatrix.from_scipy(m)
+        T = M.CreateTranspose()
+        assert (T.height, T.width, T.nnz) == (m.shape[1], m.shape[0], m.nnz) and T.CreateTranspose() is M
+        y = rng.standard_normal(m.shape[0])
+        out = hipla.Vector(m.shape[1])
+        out.data = T * hipla.Vector.from_numpy(y)
+        ref = m.T @ y
+        assert np.max(np.abs(out.numpy() - ref)) <= RTOL * (np.abs(m.T) @ np.abs(y) + 1e-300).max()
+        t_host = T.to_scipy()
+        assert abs(t_host - m.T).max() == 0 if m.nnz else True
