@@ -71,3 +71,22 @@ def colour_major_order(colors):
 def check_coloring(g, colors):
     coo = g.tocoo()
     return not np.any(colors[coo.row] == colors[coo.col])
+
+
+def colour_permutation(csr, idx, seed=0):
+    """Colour-major re-ordering of the dofs for a block Gauss-Seidel sweep.
+
+    Returns ``(perm, new_idx, new_colors)``: ``perm[k]`` = old dof at new position k (blocks
+    colour by colour, the dofs of a block adjacent, dofs in no block last), the block table in
+    the new numbering (contiguous ranges) and the colour of each block (ascending).  Apply with
+    ``A' = A[perm][:, perm]``, ``B' = B[:, perm]``, ``f' = f[perm]``; ``u = u'[inverse]``."""
+    colors = color_blocks(block_graph(csr, idx), seed)
+    order, _ = colour_major_order(colors)
+    table = idx[:, order]
+    live = table.T >= 0
+    in_blocks = table.T[live].astype(np.int64)
+    rest = np.setdiff1d(np.arange(csr.shape[0], dtype=np.int64), in_blocks, assume_unique=False)
+    perm = np.concatenate([in_blocks, rest])
+    new_idx = -np.ones(table.T.shape, dtype=np.int32)
+    new_idx[live] = np.arange(in_blocks.size, dtype=np.int32)
+    return perm, np.ascontiguousarray(new_idx.T), colors[order]

@@ -613,7 +613,10 @@ class BlockGaussSeidel(BaseMatrix):
     (``nss_bjac_smooth_f64``); the ordering differs from NGSolve's mesh-facet order (upstream,
     not visible), so iteration counts are pinned against the build's own CPU oracle only."""
 
-    def __init__(self, mat, blocks, seed=0):
+    def __init__(self, mat, blocks, seed=0, colors=None):
+        """`colors` (one int per block) may be supplied when the system has already been
+        re-ordered colour-major on the host (`coloring.colour_permutation`): the sweep then
+        touches x, y and the inverse blocks contiguously."""
         super().__init__()
         from . import coloring
         self.engine = mat.engine
@@ -621,8 +624,8 @@ class BlockGaussSeidel(BaseMatrix):
         self.n = mat.height
         base = BlockJacobi._as_table(blocks)
         graph = coloring.block_graph(mat.to_scipy(), base)
-        colors = coloring.color_blocks(graph, seed)
-        if not coloring.check_coloring(graph, colors):
+        colors = coloring.color_blocks(graph, seed) if colors is None else np.asarray(colors, dtype=np.int32)
+        if colors.shape != (base.shape[1],) or not coloring.check_coloring(graph, colors):
             raise RuntimeError("block colouring is not proper")
         order, ptr = coloring.colour_major_order(colors)
         self.idx_host = np.ascontiguousarray(base[:, order])

@@ -140,6 +140,20 @@ class StokesSystem:
         cuts = np.round(np.arange(nranks + 1) * self.n / nranks).astype(np.int64)
         return self.velocity_slab_offsets[cuts].copy(), self.pressure_slab_offsets[cuts].copy()
 
+    def permuted(self, perm):
+        """The same system with the velocity dofs re-ordered: new dof k = old dof perm[k]
+        (A' = P A P^T, B' = B P^T).  Slab offsets / component ids are dropped (the order is no
+        longer slab-major)."""
+        perm = np.asarray(perm, dtype=np.int64)
+        A = self.A[perm][:, perm].tocsr()
+        B = self.B[:, perm].tocsr()
+        A.sort_indices()
+        B.sort_indices()
+        out = StokesSystem(self.dim, self.n, self.nu, self.h, A, B, self.mass.copy(),
+                           np.zeros(0, dtype=np.int64), self.pressure_slab_offsets.copy(), [], self.block_size)
+        out.velocity_permutation = perm
+        return out
+
     def condense(self, seed=0):
         """Static condensation of A: split the velocity dofs into an
         *interior* set I (a maximal independent set of A's graph, so A_ii is diagonal -- the role
