@@ -82,8 +82,18 @@ def event_time_ms(torch, fn, reps):
     return start.elapsed_time(stop) / reps
 
 
+def emit(fd, doc):
+    """The ONE JSON line, written to the process's original stdout."""
+    os.write(fd, (json.dumps(doc) + "\n").encode())
+
+
 def main():
     args = parse_args()
+    # Everything except the result line goes to stderr -- also what native libraries print
+    # (RCCL writes a version banner to fd 1 when a communicator is created).
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -91,7 +101,10 @@ def main():
     import torch
     import torch.distributed as dist
 
-    if world > 1:
+    # NSS_FORCE_DIST=1 sends a 1-rank launch through the partitioned code path (rehearsal of the
+    # RCCL bootstrap / native loop on a single GPU)
+    partitioned = world > 1 or os.environ.get("NSS_FORCE_DIST") == "1"
+    if partitioned:
         # NSS_DIST_BACKEND=gloo lets several ranks share one GPU for rehearsals (RCCL refuses
         # that); the driver's runs use the default: one rank per GPU over RCCL / xGMI.
         backend = os.environ.get("NSS_DIST_BACKEND", "nccl")
@@ -127,7 +140,7 @@ def main():
         f = f[perm]
     t_asm = time.perf_counter() - t_asm
 
-    if world > 1:
+    if partitioned:
         from distributed import DistributedBpcg2, TorchComm
         comm, comm_kind = None, "torch.distributed/" + backend
         if backend == "nccl" and os.environ.get("NSS_COMM", "rccl") == "rccl":
@@ -200,7 +213,7 @@ def main():
                            "n_u": sysm.n_u, "n_p": sysm.n_p, "nnz_A": int(sysm.A.nnz), "nnz_B": int(sysm.B.nnz)},
                 "valid": ok, "halo_doubles_per_rank": run.halo_summary(), "comm": comm_kind,
             }
-            print(json.dumps(out))
+            emit(result_fd, out)
         dist.destroy_process_group()
         return
 
@@ -313,7 +326,7 @@ def main():
         "parity": parity,
         "setup_s": {"assemble_host": t_asm, "upload_lanczos_initial_residual": t_setup},
     }
-    print(json.dumps(out))
+    emit(result_fd, out)
 
 
 if __name__ == "__main__":
