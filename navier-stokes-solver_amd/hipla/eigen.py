@@ -11,7 +11,7 @@ from math import sqrt
 
 import numpy as np
 
-from .vector import InnerProduct, Vector, BlockVector
+from .vector import BlockVector, InnerProduct
 
 
 def lanczos_start_values(offset, n, total=None):

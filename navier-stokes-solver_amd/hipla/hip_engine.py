@@ -159,7 +159,6 @@ class HipEngine:
         torch.cuda.set_device(self.device)
         if self.lib.nss_abi_version() != 1:
             raise EngineUnavailable("libnsskrylov ABI mismatch")
-        self._stream_cache = None
 
     # ---- plumbing --------------------------------------------------------------------
     def _check(self, rc):

@@ -160,6 +160,17 @@ class BaseVector:
     def Add(self, other, s=1.0):
         self._accumulate(as_expr(other) * s)
 
+    @staticmethod
+    def _merge_self_terms(terms, is_self):
+        """Plain terms that alias the destination are consumed first, as ONE term carrying the
+        sum of their coefficients: evaluating left to right would otherwise overwrite the
+        destination before a later ``c * dest`` term reads it."""
+        mine = [t for t in terms if t.mat is None and is_self(t.vec)]
+        if not mine or (len(mine) == 1 and terms[0] is mine[0]):
+            return terms
+        rest = [t for t in terms if not (t.mat is None and is_self(t.vec))]
+        return [Term(sum(t.scale for t in mine), None, mine[0].vec)] + rest
+
     def CreateColVector(self):
         return self.CreateVector()
 
@@ -298,12 +309,7 @@ class Vector(BaseVector):
             raise ValueError("vector size mismatch: %d vs %d" % (t.vec.size, self.size))
 
     def _assign(self, expr):
-        terms = self._prepare(expr)
-        # a plain term that aliases the destination must be consumed first
-        for i, t in enumerate(terms):
-            if t.mat is None and self._same_storage(t.vec) and i > 0:
-                terms.insert(0, terms.pop(i))
-                break
+        terms = self._merge_self_terms(self._prepare(expr), self._same_storage)
         eng = self.engine
         if all(t.mat is None for t in terms) and len(terms) <= _MAX_FUSED_TERMS:
             for t in terms:
@@ -321,7 +327,12 @@ class Vector(BaseVector):
         self._add_terms(rest)
 
     def _accumulate(self, expr):
-        self._add_terms(self._prepare(expr))
+        terms = self._prepare(expr)
+        if any(t.mat is None and self._same_storage(t.vec) for t in terms):
+            # ``x += c * x + ...``: every c * x must see the old x -> evaluate as one assignment
+            self._assign(Expr([Term(1.0, None, self)] + terms))
+            return
+        self._add_terms(terms)
 
     def _add_terms(self, terms):
         eng = self.engine
@@ -434,11 +445,7 @@ class BlockVector(BaseVector):
         return terms
 
     def _assign(self, expr):
-        terms = self._prepare(expr)
-        for i, t in enumerate(terms):
-            if t.mat is None and t.vec is self and i > 0:
-                terms.insert(0, terms.pop(i))
-                break
+        terms = self._merge_self_terms(self._prepare(expr), lambda v: v is self)
         if all(t.mat is None for t in terms):
             for i, c in enumerate(self.components):
                 c._assign(Expr([self._component_terms(t, i) for t in terms]))
@@ -454,7 +461,11 @@ class BlockVector(BaseVector):
         self._add_terms(rest)
 
     def _accumulate(self, expr):
-        self._add_terms(self._prepare(expr))
+        terms = self._prepare(expr)
+        if any(t.mat is None and t.vec is self for t in terms):
+            self._assign(Expr([Term(1.0, None, self)] + terms))
+            return
+        self._add_terms(terms)
 
     def _add_terms(self, terms):
         run = []
