@@ -31,6 +31,10 @@ namespace nss {
 #define NSS_STREAM_NT 1
 #endif
 
+#ifndef NSS_STREAM_VEC2
+#define NSS_STREAM_VEC2 0   // 1: 16-byte (val) / 8-byte (col) loads, two consecutive entries per lane
+#endif
+
 constexpr int kChunk = 2048;            // products staged per workgroup: 16 KiB of LDS
 constexpr int kMaxRowsPerBlock = 2048;  // bound for blocks of empty / very short rows
 constexpr int kXcds = 8;
@@ -91,6 +95,31 @@ __global__ __launch_bounds__(kBlock) void csr_stream_kernel(CsrView a, const dou
     const int cnt = a.rowptr[r1] - p0;
     if (cnt <= kChunk) {
       // ---- phase 1: coalesced stream of (col, val), gather x, stage products ---------
+#if NSS_STREAM_VEC2
+      // two consecutive entries per lane from an even-aligned base: 16-byte val / 8-byte col loads
+      constexpr int kPer = kChunk / (2 * kBlock);
+      const int pa = p0 & ~1;
+      const int lead = p0 - pa;                  // 0 or 1 entries in front of the row block
+      const int span = cnt + lead;
+      typedef int int2v __attribute__((ext_vector_type(2)));
+      typedef double double2v __attribute__((ext_vector_type(2)));
+      int2v c[kPer + 1];
+      double2v v[kPer + 1];
+#pragma unroll
+      for (int k = 0; k <= kPer; ++k) {
+        const int e = 2 * (tid + k * kBlock);     // entry offset from pa
+        const bool live = e < span;
+        c[k] = live ? __builtin_nontemporal_load(reinterpret_cast<const int2v*>(a.col + pa + e)) : int2v{0, 0};
+        v[k] = live ? __builtin_nontemporal_load(reinterpret_cast<const double2v*>(a.val + pa + e)) : double2v{0.0, 0.0};
+      }
+#pragma unroll
+      for (int k = 0; k <= kPer; ++k) {
+        const int e = 2 * (tid + k * kBlock);
+        const int i0 = e - lead, i1 = e + 1 - lead;          // LDS slots of the two entries
+        if (i0 >= 0 && i0 < cnt) prod[i0] = v[k].x * x[c[k].x];
+        if (i1 < cnt && e < span) prod[i1] = v[k].y * x[c[k].y];
+      }
+#else
       constexpr int kPer = kChunk / kBlock;
       int32_t c[kPer];
       double v[kPer];
@@ -112,6 +141,7 @@ __global__ __launch_bounds__(kBlock) void csr_stream_kernel(CsrView a, const dou
 #pragma unroll
       for (int k = 0; k < kPer; ++k)
         if (tid + k * kBlock < cnt) prod[tid + k * kBlock] = v[k] * xv[k];
+#endif
       __syncthreads();
       // ---- phase 2: per-row reduction from LDS -----------------------------------------
       constexpr int kRowsPerPass = kBlock / RG;

@@ -86,10 +86,12 @@ int nss_csr_create_cuts(int32_t nrows, int32_t ncols, int64_t nnz, const int32_t
       plan_row_blocks(nrows, nnz, h_rowptr, &A->rg, blk, h_cuts, ncuts);
       A->nblk = int32_t(blk.size()) - 1;
       NSS_HIP(hipMalloc(&A->rowptr, sizeof(int32_t) * (size_t(nrows) + 1)));
-      NSS_HIP(hipMalloc(&A->col, sizeof(int32_t) * std::max<int64_t>(nnz, 1)));
-      NSS_HIP(hipMalloc(&A->val, sizeof(double) * std::max<int64_t>(nnz, 1)));
+      NSS_HIP(hipMalloc(&A->col, sizeof(int32_t) * (nnz + 4)));   // +4: paired loads may touch one entry past the end
+      NSS_HIP(hipMalloc(&A->val, sizeof(double) * (nnz + 4)));
       NSS_HIP(hipMalloc(&A->rowblk, sizeof(int32_t) * blk.size()));
       NSS_HIP(hipMemcpy(A->rowptr, h_rowptr, sizeof(int32_t) * (size_t(nrows) + 1), hipMemcpyHostToDevice));
+      NSS_HIP(hipMemset(A->col, 0, sizeof(int32_t) * (nnz + 4)));
+      NSS_HIP(hipMemset(A->val, 0, sizeof(double) * (nnz + 4)));
       if (nnz > 0) {
         NSS_HIP(hipMemcpy(A->col, h_col, sizeof(int32_t) * nnz, hipMemcpyHostToDevice));
         NSS_HIP(hipMemcpy(A->val, h_val, sizeof(double) * nnz, hipMemcpyHostToDevice));

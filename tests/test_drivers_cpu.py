@@ -191,3 +191,15 @@ def test_static_condensation_path(numpy_engine):
     assert np.linalg.norm(b - s.saddle_matrix() @ x) < 1e-5 * np.linalg.norm(b)
     assert np.linalg.norm(x[:n] - xr[:n]) < 1e-5 * np.linalg.norm(xr[:n])
     assert 5 < it < 3000
+
+
+def test_heat_config1_driver(numpy_engine):
+    """BASELINE config 1 through the package's heat.py: CG history and Galerkin spectrum against the
+    golden produced with the reference's orthonormalization.py."""
+    import heat
+    d = np.load(__import__("conftest").golden_path("cfg1_heat_plumbing"))
+    x, hist, gal = heat.solve(n=int(d["n"]), seed=int(d["seed"]))
+    assert len(hist) - 1 == int(d["cg_iterations"])
+    np.testing.assert_allclose(hist, d["cg_history"], rtol=1e-8)
+    assert abs(np.linalg.norm(x.numpy()) - float(d["cg_x_norm"])) < 1e-9 * float(d["cg_x_norm"])
+    np.testing.assert_allclose(np.linalg.eigvalsh(gal), np.linalg.eigvalsh(d["galerkin"]), rtol=1e-7)
