@@ -442,6 +442,7 @@ class DistributedBpcg2:
         """Issue the partitioned iterations from C (nss_bpcg2_iterate_dist): RCCL calls, halo
         packs, events and the interior/boundary split without Python in the loop."""
         import ctypes as C
+        self.close()
         handle = C.c_void_p()
         eng = self.engine
         eng._check(eng.lib.nss_dist_create(comm_handle, self.comm.size, self.comm.rank, C.byref(handle)))
@@ -450,6 +451,17 @@ class DistributedBpcg2:
         halos = (ops.BT.native_halo(self.s1, interior.get("s1")), ops.A.native_halo(self.t1, interior.get("t1")),
                  ops.B.native_halo(self.t4, interior.get("t4")))
         self.native = (handle, halos)
+
+    def close(self):
+        if getattr(self, "native", None) is not None:
+            self.engine.lib.nss_dist_destroy(self.native[0])
+            self.native = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def start(self, tol, maxsteps, rel_err=True):
         self.first_direction()

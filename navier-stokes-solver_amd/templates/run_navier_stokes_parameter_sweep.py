@@ -40,5 +40,26 @@ def sweep(mesh_sizes, orders, gauss_seidel_enabled=(True, False), out="data.csv"
     return data
 
 
+def sweep_reynolds(reynolds=(100, 400, 1000), mesh_size=1.0 / 32, order=1, dim=3, gauss_seidel=False, out="data_re.csv",
+                   tol=1e-10, maxsteps=100000):
+    """BASELINE.json config 5 restates the sweep over Reynolds numbers (nu = 1/Re) on one 3-D
+    mesh: in the Stokes operator nu only rescales the velocity block
+    (templates/NavierStokesSIMPLE_iterative.py:66,72), so this measures how the iteration count of
+    the Bramble-Pasciak solve moves with it.  Same CSV columns plus ``reynolds``."""
+    frames = []
+    mesh = create_mesh(mesh_size, dim)
+    for re in reynolds:
+        navstokes = create_nav_stokes(mesh, order, nu=1.0 / re)
+        navstokes.SolveInitial(iterative=True, GS=gauss_seidel, tol=tol, maxsteps=maxsteps)
+        frames.append(pd.DataFrame({'mesh_size': mesh_size, 'order': order, 'reynolds': re,
+                                    'iterations': navstokes.stokes_bpcg_iterations,
+                                    'time': navstokes.stokes_bpcg_time,
+                                    'gauss_seidel_enabled': gauss_seidel}, index=[0]))
+    data = pd.concat(frames, ignore_index=True)
+    if out:
+        data.to_csv(out)
+    return data
+
+
 if __name__ == "__main__":
     sweep([2 ** -i for i in range(5, 1, -1)], range(3, 1, -1), (True, False))

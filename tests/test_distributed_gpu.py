@@ -39,7 +39,7 @@ def single_gpu(dim, n, pre, tol, maxsteps):
     return s, dict(it=it, hist=hist, k=ses.k, err0=ses.err0, u=sol[0].numpy(), p=sol[1].numpy())
 
 
-@pytest.mark.parametrize("world,dim,n,pre", [(2, 3, 10, "bjac"), (3, 2, 24, "jacobi")])
+@pytest.mark.parametrize("world,dim,n,pre", [(2, 3, 10, "bjac"), (3, 2, 24, "jacobi"), (5, 3, 10, "jacobi")])
 def test_fused_distributed_loop_matches_single_gpu(hip_engine, world, dim, n, pre):
     tol, maxsteps = 1e-8, 4000
     s, ref = single_gpu(dim, n, pre, tol, maxsteps)

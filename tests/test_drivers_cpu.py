@@ -83,6 +83,10 @@ def test_navier_stokes_class_and_sweep(numpy_engine, tmp_path):
     with contextlib.redirect_stdout(io.StringIO()):
         data = sweep([0.25, 0.2], [2, 1], (True, False), out=str(tmp_path / "data.csv"), tol=1e-6)
     assert list(data.columns) == ['mesh_size', 'order', 'iterations', 'time', 'gauss_seidel_enabled']
+    from templates.run_navier_stokes_parameter_sweep import sweep_reynolds
+    with contextlib.redirect_stdout(io.StringIO()):
+        re_data = sweep_reynolds((100, 1000), mesh_size=0.25, dim=3, out=str(tmp_path / "re.csv"), tol=1e-6)
+    assert list(re_data.reynolds) == [100, 1000] and (re_data.iterations > 0).all()
     assert len(data) == 8 and (data.iterations > 0).all() and data.gauss_seidel_enabled.sum() == 4
     for _, grp in data.groupby(["mesh_size", "order"]):
         gs = grp[grp.gauss_seidel_enabled].iterations.iloc[0]
