@@ -136,6 +136,25 @@ NSS_API int nss_bjac_smooth_f64(nss_bjac_t j, double xscale, const double* x, do
 NSS_API int nss_bjac_symgs_apply_f64(nss_bjac_t j, double xscale, const double* x, double* y,
                                      nss_stream_t stream);
 
+/* ---- smoothed-aggregation AMG V(1,1)-cycle -------------------------------------------------
+ * Counterpart of the 'h1amg' correction inside the reference's MypreA
+ * (templates/NavierStokesSIMPLE_iterative.py:320-357,380,383).  The
+ * hierarchy (A_l, P_l, R_l = P_l^T, inverse diagonals, dense inverse of the coarsest operator as
+ * a CSR matrix) is built by the host; the cycle runs on the device with CSR-stream SpMVs:
+ *   x = w D^-1 b;  r = b - A x;  x += P V(R r);  x += w D^-1 (b - A x).
+ * The library allocates the per-level work vectors. */
+typedef struct nss_amg_level_s {
+  nss_csr_t A;          /* level operator (n x n)                                  */
+  nss_csr_t P, R;       /* prolongation (n x n_coarse) and restriction; NULL on the coarsest level */
+  const double* dinv;   /* DEVICE: inverse diagonal of A (n)                        */
+} nss_amg_level_t;
+typedef struct nss_amg_s* nss_amg_t;
+NSS_API int nss_amg_create(int32_t nlevels, const nss_amg_level_t* h_levels, nss_csr_t coarse_inverse,
+                           double omega, nss_amg_t* out);
+NSS_API int nss_amg_destroy(nss_amg_t a);
+/* x = V(bscale * b);  b and x have the finest level's size and must not alias */
+NSS_API int nss_amg_apply_f64(nss_amg_t a, double bscale, const double* b, double* x, nss_stream_t stream);
+
 /* ---- fused Bramble-Pasciak CG, recurrence-optimised form ---------------------------------
  * Replaces the loop body of solvers/bramblepasciak_new.py:200-249 (the solver the SIMPLE
  * drivers call, templates/NavierStokesSIMPLE_iterative.py:397).  The host fills this struct
@@ -150,7 +169,10 @@ NSS_API int nss_bjac_symgs_apply_f64(nss_bjac_t j, double xscale, const double* 
 typedef struct nss_bpcg2_s {
   nss_csr_t A, B, BT;          /* A: n_u rows; B: n_p rows; BT: n_u rows (explicit transpose, :198) */
   const double* pre_diag;      /* point-Jacobi preA (inverse diagonal, n_u)  -- or NULL          */
-  nss_bjac_t pre_bjac;         /* block-Jacobi preA                          -- or NULL          */
+  nss_bjac_t pre_bjac;         /* block-Jacobi / block-GS preA               -- or NULL          */
+  nss_amg_t pre_amg;           /* AMG V-cycle, added to the above (either may be NULL; at least
+                                  one of the three is set): preA_unscaled = AMG + Jacobi part,
+                                  the additive form of MypreA (:383)                             */
   const double* minv;          /* preM = Preconditioner(mass,'local'): inverse mass diagonal, n_p */
   double *u0, *u1, *d0, *d1, *w0, *w1, *s0, *s1, *z0, *q, *t0, *t1, *t2, *t3, *t4;
   double* scal;

@@ -1,0 +1,154 @@
+// Smoothed-aggregation AMG V(1,1)-cycle on the device (hierarchy built by the host,
+// hipla/amg.py).  Every operation of the cycle is a CSR-stream SpMV with a fused epilogue or a
+// diagonal scale, all on one stream:
+//
+//   level l:  x  = w D^-1 b                      diag_scale            (pre-smoothing from x = 0)
+//             r  = b - A x                       SpMV, EpiResidual
+//             b' = R r                           SpMV                  (restriction)
+//             x' = V_{l+1}(b')                   recursion; coarsest: x' = A^-1 b' (dense inverse, SpMV)
+//             x += P x'                          SpMV, beta = 1        (prolongation + correction)
+//             y  = x + w D^-1 (b - A x)          SpMV, EpiJacobi       (post-smoothing, into the output)
+//
+// One pre- and one post-smoothing step with the same damping make the cycle symmetric, so it is
+// an SPD preconditioner for the Bramble-Pasciak CG.
+#include "amg.h"
+
+#include <vector>
+
+namespace nss {
+
+struct EpiResidual {   // r = b - A x
+  const double* __restrict__ b;
+  double* __restrict__ r;
+  __device__ bool skip() const { return false; }
+  __device__ void row(int i, double ax) const { r[i] = b[i] - ax; }
+  __device__ void finish(int, double*) const {}
+};
+
+struct EpiJacobi {     // y = x + w dinv (b - A x)
+  const double* __restrict__ b;
+  const double* __restrict__ x;
+  const double* __restrict__ dinv;
+  double* __restrict__ y;
+  double w;
+  __device__ bool skip() const { return false; }
+  __device__ void row(int i, double ax) const { y[i] = fma(w * dinv[i], b[i] - ax, x[i]); }
+  __device__ void finish(int, double*) const {}
+};
+
+// y = s * d .* x
+__global__ __launch_bounds__(kBlock) void amg_diag_kernel(int32_t n, double s, const double* __restrict__ d,
+                                                           const double* __restrict__ x, double* __restrict__ y) {
+  const int stride = gridDim.x * kBlock;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) y[i] = s * (d[i] * x[i]);
+}
+
+// y = s * x
+__global__ __launch_bounds__(kBlock) void amg_scale_kernel(int32_t n, double s, const double* __restrict__ x,
+                                                            double* __restrict__ y) {
+  const int stride = gridDim.x * kBlock;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) y[i] = s * x[i];
+}
+
+static void cycle(const nss_amg_s& a, int l, const double* b, double* out, hipStream_t st) {
+  const AmgLevel& lv = a.levels[l];
+  if (l == int(a.levels.size()) - 1) {
+    launch_csr_stream(*a.coarse_inverse, b, EpiAxpby{1.0, 0.0, out}, st);   // x = A^-1 b
+    return;
+  }
+  const int n = lv.n;
+  hipLaunchKernelGGL(amg_diag_kernel, dim3(stream_grid(n, kBlock * 4)), dim3(kBlock), 0, st, n, a.omega, lv.dinv, b,
+                     lv.x);
+  NSS_CHECK_LAUNCH();
+  launch_csr_stream(*lv.A, lv.x, EpiResidual{b, lv.r}, st);
+  const AmgLevel& next = a.levels[l + 1];
+  launch_csr_stream(*lv.R, lv.r, EpiAxpby{1.0, 0.0, next.b}, st);
+  cycle(a, l + 1, next.b, next.y, st);
+  launch_csr_stream(*lv.P, next.y, EpiAxpby{1.0, 1.0, lv.x}, st);
+  launch_csr_stream(*lv.A, lv.x, EpiJacobi{b, lv.x, lv.dinv, out, a.omega}, st);
+}
+
+void amg_apply(const nss_amg_s& a, double bscale, const double* b, double* x, hipStream_t st) {
+  const double* rhs = b;
+  if (bscale != 1.0) {   // the cycle is linear: scale the right-hand side once
+    const int n = a.levels[0].n;
+    hipLaunchKernelGGL(amg_scale_kernel, dim3(stream_grid(n, kBlock * 4)), dim3(kBlock), 0, st, n, bscale, b,
+                       a.levels[0].b);
+    NSS_CHECK_LAUNCH();
+    rhs = a.levels[0].b;
+  }
+  cycle(a, 0, rhs, x, st);
+}
+
+}  // namespace nss
+
+using namespace nss;
+
+extern "C" {
+
+int nss_amg_create(int32_t nlevels, const nss_amg_level_t* h_levels, nss_csr_t coarse_inverse, double omega,
+                   nss_amg_t* out) {
+  return guarded([&] {
+    NSS_REQUIRE(out && h_levels && coarse_inverse, "amg_create: NULL argument");
+    NSS_REQUIRE(nlevels >= 1 && nlevels <= 32, "amg_create: 1 <= nlevels <= 32");
+    nss_amg_s* a = new nss_amg_s;
+    try {
+      a->omega = omega;
+      a->coarse_inverse = coarse_inverse;
+      for (int l = 0; l < nlevels; ++l) {
+        const nss_amg_level_t& in = h_levels[l];
+        NSS_REQUIRE(in.A && in.dinv, "amg_create: level without operator / diagonal");
+        NSS_REQUIRE(in.A->m == in.A->n, "amg_create: level operator must be square");
+        AmgLevel lv;
+        lv.n = in.A->m;
+        lv.A = in.A;
+        lv.dinv = in.dinv;
+        if (l + 1 < nlevels) {
+          NSS_REQUIRE(in.P && in.R, "amg_create: missing transfer operators");
+          const nss_csr_s* nextA = h_levels[l + 1].A;
+          NSS_REQUIRE(nextA && in.P->m == lv.n && in.P->n == nextA->m && in.R->m == nextA->m && in.R->n == lv.n,
+                      "amg_create: transfer operator shapes do not chain");
+          lv.P = in.P;
+          lv.R = in.R;
+        }
+        a->levels.push_back(lv);
+      }
+      NSS_REQUIRE(coarse_inverse->m == a->levels.back().n && coarse_inverse->n == a->levels.back().n,
+                  "amg_create: coarse inverse has the wrong size");
+      for (auto& lv : a->levels) {
+        const size_t bytes = sizeof(double) * size_t(std::max(1, lv.n));
+        NSS_HIP(hipMalloc(&lv.x, bytes));
+        NSS_HIP(hipMalloc(&lv.r, bytes));
+        NSS_HIP(hipMalloc(&lv.b, bytes));
+        NSS_HIP(hipMalloc(&lv.y, bytes));
+      }
+    } catch (...) {
+      nss_amg_destroy(a);
+      throw;
+    }
+    *out = a;
+  });
+}
+
+int nss_amg_destroy(nss_amg_t a) {
+  return guarded([&] {
+    if (!a) return;
+    for (auto& lv : a->levels) {
+      (void)hipFree(lv.x);
+      (void)hipFree(lv.r);
+      (void)hipFree(lv.b);
+      (void)hipFree(lv.y);
+    }
+    delete a;
+  });
+}
+
+int nss_amg_apply_f64(nss_amg_t a, double bscale, const double* b, double* x, nss_stream_t stream) {
+  return guarded([&] {
+    NSS_REQUIRE(a != nullptr, "amg_apply: NULL handle");
+    NSS_REQUIRE(b != x, "amg_apply: b must not alias x");
+    amg_apply(*a, bscale, b, x, as_stream(stream));
+  });
+}
+
+}  // extern "C"

@@ -1,5 +1,6 @@
 #pragma once
 
+#include "amg.h"
 #include "precond.h"
 
 namespace nss {

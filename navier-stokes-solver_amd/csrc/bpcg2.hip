@@ -232,7 +232,10 @@ void bpcg2_check_state(const nss_bpcg2_t* s) {
   NSS_REQUIRE(s != nullptr, "bpcg2: NULL state");
   NSS_REQUIRE(s->A && s->B && s->BT, "bpcg2: NULL matrix handle");
   NSS_REQUIRE(s->A->m == s->n_u && s->BT->m == s->n_u && s->B->m == s->n_p, "bpcg2: matrix row counts do not match n_u/n_p");
-  NSS_REQUIRE((s->pre_diag != nullptr) != (s->pre_bjac != nullptr), "bpcg2: exactly one of pre_diag / pre_bjac");
+  NSS_REQUIRE(!(s->pre_diag && s->pre_bjac), "bpcg2: pre_diag and pre_bjac are exclusive");
+  NSS_REQUIRE(s->pre_diag || s->pre_bjac || s->pre_amg, "bpcg2: no preconditioner for the velocity block");
+  NSS_REQUIRE(!s->pre_amg || s->pre_amg->levels[0].n == s->n_u, "bpcg2: AMG size mismatch");
+  NSS_REQUIRE(!(s->pre_amg && s->pre_bjac && s->pre_bjac->gs_mat), "bpcg2: AMG + Gauss-Seidel mode is not additive");
   NSS_REQUIRE(!s->pre_bjac || s->pre_bjac->n == s->n_u, "bpcg2: block-Jacobi size mismatch");
   NSS_REQUIRE(s->minv && s->scal && s->ctrl && s->hist && s->partials_a && s->partials_b && s->partials_c,
               "bpcg2: NULL work buffer");
@@ -246,7 +249,9 @@ void bpcg2_check_state(const nss_bpcg2_t* s) {
 void bpcg2_spmv_phase(const nss_bpcg2_t& s, int which, int it, hipStream_t st, int b0, int b1) {
   switch (which) {
     case NSS_BPCG2_K1: {
-      EpiK1 e{s.ctrl, s.scal, s.q, s.z0, s.t2, s.s0, s.w0, s.t0, s.t1, s.pre_diag, s.k, it == 0 ? 1 : 0};
+      // the point-Jacobi apply rides in the epilogue unless an AMG term comes first
+      EpiK1 e{s.ctrl, s.scal, s.q, s.z0, s.t2, s.s0, s.w0, s.t0, s.t1, s.pre_amg ? nullptr : s.pre_diag, s.k,
+              it == 0 ? 1 : 0};
       launch_csr_stream(*s.BT, s.s1, e, st, b0, b1);
       break;
     }
@@ -265,7 +270,18 @@ void bpcg2_spmv_phase(const nss_bpcg2_t& s, int which, int it, hipStream_t st, i
   }
 }
 
+// t1 = k * preA_unscaled t0 for everything that is not fused into K1's epilogue:
+// [AMG V-cycle] + [block Jacobi / block Gauss-Seidel | point Jacobi]  (additive MypreA, :383)
 void bpcg2_k1_finish(const nss_bpcg2_t& s, hipStream_t st) {
+  if (s.pre_amg) {
+    amg_apply(*s.pre_amg, s.k, s.t0, s.t1, st);
+    if (s.pre_bjac) bjac_apply(*s.pre_bjac, s.k, s.t0, 1.0, s.t1, s.ctrl, st);
+    if (s.pre_diag) {
+      const int rc = nss_diag_apply_f64(s.n_u, s.pre_diag, s.k, s.t0, 1.0, s.t1, st);
+      if (rc != 0) throw Error(nss_last_error());
+    }
+    return;
+  }
   if (s.pre_bjac) bjac_apply_guarded(*s.pre_bjac, s.k, s.t0, s.t1, s.ctrl, st);
 }
 

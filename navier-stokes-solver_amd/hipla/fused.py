@@ -15,7 +15,9 @@ import os
 
 import numpy as np
 
-from .matrix import BlockGaussSeidel, BlockJacobi, BlockMatrix, DiagonalMatrix, ScaledMatrix, SparseMatrix
+from .amg import SmoothedAggregationAMG
+from .matrix import (BlockGaussSeidel, BlockJacobi, BlockMatrix, DiagonalMatrix, ScaledMatrix, SparseMatrix,
+                     SumMatrix)
 from .vector import BlockVector, Vector
 
 POLL_EVERY = int(os.environ.get("NSS_POLL_EVERY", "32"))
@@ -24,7 +26,7 @@ ENABLED = True      # tests flip this to force the protocol path on native opera
 
 class Bpcg2State(C.Structure):
     """ctypes mirror of ``nss_bpcg2_t`` (include/nss_krylov.h)."""
-    _fields_ = ([(n, C.c_void_p) for n in ("A", "B", "BT", "pre_diag", "pre_bjac", "minv")]
+    _fields_ = ([(n, C.c_void_p) for n in ("A", "B", "BT", "pre_diag", "pre_bjac", "pre_amg", "minv")]
                 + [(n, C.c_void_p) for n in ("u0", "u1", "d0", "d1", "w0", "w1", "s0", "s1", "z0", "q",
                                              "t0", "t1", "t2", "t3", "t4")]
                 + [("scal", C.c_void_p), ("ctrl", C.c_void_p), ("hist", C.c_void_p),
@@ -70,6 +72,34 @@ def native_bjac(op):
     return None
 
 
+def native_velocity_pre(op):
+    """Decompose a velocity-block preconditioner into what the fused BPCG loop applies natively:
+    ``scale * (AMG + J)`` with J a point / block Jacobi (or block Gauss-Seidel when there is no AMG
+    term) -- the additive form of the reference's MypreA
+    (templates/NavierStokesSIMPLE_iterative.py:383).  Returns dict(scale, amg, diag, bjac) or None."""
+    scale = 1.0
+    if isinstance(op, ScaledMatrix):
+        scale, op = op.scale, op.mat
+    parts = [op]
+    if isinstance(op, SumMatrix):
+        if op.sb != 1.0:
+            return None
+        parts = [op.a, op.b]
+    out = {"scale": scale, "amg": None, "diag": None, "bjac": None}
+    for part in parts:
+        if isinstance(part, SmoothedAggregationAMG) and out["amg"] is None:
+            out["amg"] = part
+        elif isinstance(part, DiagonalMatrix) and out["diag"] is None and out["bjac"] is None:
+            out["diag"] = part
+        elif isinstance(part, (BlockJacobi, BlockGaussSeidel)) and out["diag"] is None and out["bjac"] is None:
+            out["bjac"] = part
+        else:
+            return None
+    if out["amg"] is not None and isinstance(out["bjac"], BlockGaussSeidel):
+        return None
+    return out
+
+
 def _plain(v, n):
     return isinstance(v, Vector) and v.size == n
 
@@ -95,28 +125,25 @@ class Bpcg2Loop:
         if distributed and (matA.width < n_u or matB.width < n_u or matBT.width < n_p):
             return None
         pm = native_diag(preM)
-        pa_d, pa_b = native_diag(preA_unscaled), native_bjac(preA_unscaled)
-        if pm is None or (pa_d is None and pa_b is None):
+        pa = native_velocity_pre(preA_unscaled)
+        if pm is None or pa is None:
             return None
         sizes = {"u0": n_u, "d0": n_u, "w0": n_u, "s0": n_u, "z0": n_u, "q": n_u, "t0": n_u, "t1": n_u,
                  "t2": n_u, "t4": n_u, "u1": n_p, "d1": n_p, "w1": n_p, "s1": n_p, "t3": n_p}
         if any(not _plain(vecs.get(name), n) for name, n in sizes.items()):
             return None
-        return cls(eng, matA, matB, matBT, pa_d, pa_b, k, pm, vecs)
+        return cls(eng, matA, matB, matBT, pa, k, pm, vecs)
 
-    def __init__(self, eng, matA, matB, matBT, pa_d, pa_b, k, pm, vecs):
+    def __init__(self, eng, matA, matB, matBT, pa, k, pm, vecs):
         torch = eng.torch
         self.eng, self.lib = eng, eng.lib
-        self.keep = [matA, matB, matBT, vecs, pa_d, pa_b, pm]       # keep device memory alive
+        self.keep = [matA, matB, matBT, vecs, pa, pm]       # keep device memory alive
         st = Bpcg2State()
         st.A, st.B, st.BT = matA.handle.ptr, matB.handle.ptr, matBT.handle.ptr
-        if pa_d is not None:
-            scale, op = pa_d
-            st.pre_diag, st.pre_bjac = op.d.data_ptr(), None
-        else:
-            scale, op = pa_b
-            st.pre_diag, st.pre_bjac = None, op.handle.ptr
-        st.k = float(k) * scale
+        st.pre_diag = pa["diag"].d.data_ptr() if pa["diag"] is not None else None
+        st.pre_bjac = pa["bjac"].handle.ptr if pa["bjac"] is not None else None
+        st.pre_amg = pa["amg"].handle.ptr if pa["amg"] is not None else None
+        st.k = float(k) * pa["scale"]
         mscale, mop = pm
         if mscale != 1.0:
             self.minv = mop.d * mscale

@@ -59,6 +59,9 @@ def _signatures():
         "nss_csr_create_cuts": (C.c_int, [i32, i32, i64, vp, vp, vp, i32, vp, C.POINTER(vp)]),
         "nss_bjac_smooth_f64": (C.c_int, [vp, dbl, vp, vp, i32, vp]),
         "nss_bjac_symgs_apply_f64": (C.c_int, [vp, dbl, vp, vp, vp]),
+        "nss_amg_create": (C.c_int, [i32, vp, vp, dbl, C.POINTER(vp)]),
+        "nss_amg_destroy": (C.c_int, [vp]),
+        "nss_amg_apply_f64": (C.c_int, [vp, dbl, vp, vp, vp]),
         "nss_bpcg2_workspace": (C.c_int, [vp, c_i64_p, c_i64_p, c_i64_p]),
         "nss_bpcg2_phase": (C.c_int, [vp, i32, i32, vp]),
         "nss_bpcg2_phases": (C.c_int, [vp, i32, i32, i32, vp]),
@@ -138,6 +141,24 @@ class _BjacHandle:
         try:
             if self.ptr:
                 self.engine.lib.nss_bjac_destroy(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+class AmgLevelStruct(C.Structure):
+    """ctypes mirror of ``nss_amg_level_t``."""
+    _fields_ = [("A", C.c_void_p), ("P", C.c_void_p), ("R", C.c_void_p), ("dinv", C.c_void_p)]
+
+
+class _AmgHandle:
+    def __init__(self, engine, ptr, keep):
+        self.engine, self.ptr, self.keep = engine, ptr, keep
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                self.engine.lib.nss_amg_destroy(self.ptr)
                 self.ptr = None
         except Exception:
             pass
@@ -283,6 +304,22 @@ class HipEngine:
             raise ValueError("diag_apply shape mismatch")
         self._check(self.lib.nss_diag_apply_f64(d.shape[0], d.data_ptr(), alpha, x.data_ptr(), beta,
                                                 y.data_ptr(), self.stream))
+
+    def amg_create(self, levels, omega):
+        """`levels`: list of dicts (A, P, R as SparseMatrix, dinv as device buffer; the last one
+        carries `inv` = dense inverse as SparseMatrix) from hipla/amg.py."""
+        arr = (AmgLevelStruct * len(levels))()
+        for i, lv in enumerate(levels):
+            arr[i].A = lv["A"].handle.ptr
+            arr[i].P = lv["P"].handle.ptr if "P" in lv else None
+            arr[i].R = lv["R"].handle.ptr if "R" in lv else None
+            arr[i].dinv = lv["dinv"].data_ptr()
+        out = C.c_void_p()
+        self._check(self.lib.nss_amg_create(len(levels), arr, levels[-1]["inv"].handle.ptr, float(omega), C.byref(out)))
+        return _AmgHandle(self, out, levels)
+
+    def amg_apply(self, h, bscale, b, x):
+        self._check(self.lib.nss_amg_apply_f64(h.ptr, float(bscale), b.data_ptr(), x.data_ptr(), self.stream))
 
     def bjac_create(self, csr_handle, idx):
         idx = np.ascontiguousarray(idx, dtype=np.int32)

@@ -5,10 +5,11 @@ from .vector import BaseVector, BlockVector, Expr, InnerProduct, Norm, Vector
 from .matrix import (BaseMatrix, BlockGaussSeidel, BlockJacobi, BlockMatrix, DiagonalMatrix, IdentityMatrix,
                      JacobiPreconditioner, Preconditioner, ProductMatrix, Projector,
                      ScaledMatrix, SparseMatrix, SumMatrix, TransposeMatrix)
+from .amg import SmoothedAggregationAMG
 from .eigen import EigenValues_Preconditioner, lanczos_ritz, lanczos_start_values
 
 __all__ = ["BaseVector", "BlockVector", "Expr", "InnerProduct", "Norm", "Vector",
            "BaseMatrix", "BlockGaussSeidel", "BlockJacobi", "BlockMatrix", "DiagonalMatrix", "IdentityMatrix",
            "JacobiPreconditioner", "Preconditioner", "ProductMatrix", "Projector",
            "ScaledMatrix", "SparseMatrix", "SumMatrix", "TransposeMatrix",
-           "EigenValues_Preconditioner", "lanczos_ritz", "lanczos_start_values"]
+           "EigenValues_Preconditioner", "lanczos_ritz", "lanczos_start_values", "SmoothedAggregationAMG"]

@@ -104,6 +104,23 @@ class NumpyEngine:
                 y *= beta
             y += alpha * ax if alpha != 1.0 else ax
 
+    # ---- smoothed-aggregation V(1,1)-cycle on the hierarchy built by hipla/amg.py -----------------
+    def amg_create(self, levels, omega):
+        return {"levels": levels, "omega": float(omega)}
+
+    def amg_apply(self, h, bscale, b, x):
+        x[:] = self._vcycle(h, 0, bscale * b)
+
+    def _vcycle(self, h, l, b):
+        lv, w = h["levels"][l], h["omega"]
+        if "inv" in lv:
+            return lv["inv"].handle.mat @ b
+        A, dinv = lv["A"].handle.mat, lv["dinv"]
+        x = w * (dinv * b)                                   # pre-smoothing from x = 0
+        r = b - A @ x
+        x = x + lv["P"].handle.mat @ self._vcycle(h, l + 1, lv["R"].handle.mat @ r)
+        return x + w * (dinv * (b - A @ x))                  # post-smoothing
+
     def diag_apply(self, d, alpha, x, beta, y):
         dx = d * x
         if beta == 0.0:

@@ -568,3 +568,62 @@ def test_heat_config1_driver(hip_engine):
     np.testing.assert_allclose(hist, d["cg_history"], rtol=1e-8)
     assert abs(np.linalg.norm(x.numpy()) - float(d["cg_x_norm"])) < 1e-9 * float(d["cg_x_norm"])
     np.testing.assert_allclose(np.linalg.eigvalsh(gal), np.linalg.eigvalsh(d["galerkin"]), rtol=1e-7)
+
+
+def test_amg_vcycle_and_fused_bpcg_with_amg(hip_engine):
+    """Scope row N3: the smoothed-aggregation V(1,1)-cycle on the device against the identical
+    cycle on the identical hierarchy run by the numpy checker engine; the fused BPCG loop with
+    preA = AMG and with the additive MypreA form AMG + block Jacobi (:383) against the protocol loop
+    on the checker engine; mesh-independent iteration counts."""
+    import hipla
+    from oracle.numpy_engine import NumpyEngine
+    from solvers.bramblepasciak_new import BpcgSession, BramblePasciakCG
+    results = {}
+    for n in (12, 20):
+        s = mac_stokes(3, n, 0.01)
+        f, g = s.rhs(0)
+        x = np.random.default_rng(n).standard_normal(s.n_u)
+        per_engine = {}
+        for name in ("hip", "numpy"):
+            eng = hip_engine if name == "hip" else NumpyEngine()
+            prev = hipla.set_engine(eng)
+            try:
+                A, B = hipla.SparseMatrix.from_scipy(s.A), hipla.SparseMatrix.from_scipy(s.B)
+                V = hipla.SmoothedAggregationAMG(A, coarse_size=300)
+                J = hipla.BlockJacobi(A, s.line_blocks(3))
+                preS = hipla.DiagonalMatrix(1.0 / s.mass)
+                y = hipla.Vector(s.n_u)
+                y.data = V * hipla.Vector.from_numpy(x)
+                y2 = hipla.Vector(s.n_u)
+                y2.data = 1.5 * V * hipla.Vector.from_numpy(x)
+                runs = {}
+                for label, pre in (("amg", V), ("amg+bjac", V + J)):
+                    sol = hipla.BlockVector([hipla.Vector(s.n_u), hipla.Vector(s.n_p)])
+                    if name == "hip":
+                        with contextlib.redirect_stdout(io.StringIO()):
+                            ses = BpcgSession(Form(A), Form(B), None, hipla.Vector.from_numpy(f),
+                                              hipla.Vector.from_numpy(g), pre, preS, sol=sol)
+                        assert ses.fused is not None            # native: takes the device-resident loop
+                        sol = hipla.BlockVector([hipla.Vector(s.n_u), hipla.Vector(s.n_p)])
+                    out = io.StringIO()
+                    with contextlib.redirect_stdout(out):
+                        it, _ = BramblePasciakCG(Form(A), Form(B), None, hipla.Vector.from_numpy(f),
+                                                 hipla.Vector.from_numpy(g), pre, preS, sol, tol=1e-9, maxsteps=2000)
+                    hist = np.array([float(m) for m in re.findall(r"it =\s+\d+\s+err =\s+(\S+)", out.getvalue())])
+                    runs[label] = (it, hist, sol.numpy())
+                per_engine[name] = (V.level_sizes, y.numpy(), y2.numpy(), runs)
+            finally:
+                hipla.set_engine(prev)
+        (lv_h, y_h, y2_h, runs_h), (lv_n, y_n, y2_n, runs_n) = per_engine["hip"], per_engine["numpy"]
+        assert lv_h == lv_n and len(lv_h) >= 2
+        assert np.linalg.norm(y_h - y_n) <= 1e-12 * np.linalg.norm(y_n)
+        assert np.linalg.norm(y2_h - 1.5 * y_n) <= 1e-12 * np.linalg.norm(y_n)
+        b = np.concatenate([f, g])
+        for label in ("amg", "amg+bjac"):
+            it_h, hist_h, x_h = runs_h[label]
+            it_n, hist_n, x_n = runs_n[label]
+            np.testing.assert_allclose(hist_h[:25], hist_n[:25], rtol=1e-8)
+            assert abs(it_h - it_n) <= max(3, int(0.03 * it_n))
+            assert np.linalg.norm(b - s.saddle_matrix() @ x_h) < 1e-6 * np.linalg.norm(b)
+        results[n] = runs_h["amg"][0]
+    assert results[20] < 1.5 * results[12] + 10           # iteration count nearly mesh-independent
