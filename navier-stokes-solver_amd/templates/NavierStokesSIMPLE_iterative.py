@@ -24,18 +24,51 @@ from solvers.bramblepasciak_new import BramblePasciakCG
 __all__ = ["NavierStokes", "SyntheticMesh", "MypreA"]
 
 
-def MypreA(space, a, jacblocks, GS):
+class _MultiplicativePreA(hipla.BaseMatrix):
+    """``y = 0; J.Smooth(y, x); r = x - A y; y += AMG r; J.SmoothBack(y, x)`` -- the
+    ``GS=True`` branch of the reference's MypreA.Mult
+    (templates/NavierStokesSIMPLE_iterative.py:376-381) with the build's AMG V-cycle in the place
+    of ``transform @ preAh1 @ transform.T``.  Runs through the protocol (sweeps, SpMV, V-cycle are
+    device kernels; the composition is host-driven)."""
+
+    def __init__(self, space, a, jacblocks):
+        super().__init__()
+        self.space, self.mat, self.GS = space, a.mat, True
+        self.jacobi = hipla.BlockGaussSeidel(a.mat, jacblocks)
+        self.amg = hipla.SmoothedAggregationAMG(a.mat)
+        self.temp = a.mat.CreateColVector()
+
+    def Mult(self, x, y):
+        y[:] = 0
+        self.jacobi.Smooth(y, x)
+        self.temp.data = x - self.mat * y
+        y.data += self.amg * self.temp
+        self.jacobi.SmoothBack(y, x)
+
+    def Height(self):
+        return self.mat.height
+
+    def Width(self):
+        return self.mat.width
+
+
+def MypreA(space, a, jacblocks, GS, amg=False):
     """``MypreA(space, a, jacblocks, GS)`` of the reference
-    (templates/NavierStokesSIMPLE_iterative.py:364-391) without its auxiliary-space term
-    ``transform @ preAh1 @ transform.T`` (:380,383; needs the AMG hierarchy, scope row N3):
+    (templates/NavierStokesSIMPLE_iterative.py:364-391).  Its auxiliary-space term
+    ``transform @ preAh1 @ transform.T`` (:380,383) is NGSolve FE machinery; ``amg=True`` puts the
+    build's smoothed-aggregation V-cycle on ``a.mat`` in its place (scope row N3):
 
-    * ``GS=False`` -> additive ``y = J x`` with ``J = a.mat.CreateBlockSmoother(jacblocks)`` (:383);
-    * ``GS=True``  -> ``y = 0; J.Smooth(y, x); J.SmoothBack(y, x)`` (:376-381), the symmetric
-      multiplicative sweep over a multicolour block ordering (scope row N1).
-
-    Both are native operators, so the fused device-resident loops take them."""
+    * ``GS=False`` -> additive ``y = (AMG + J) x`` with ``J = a.mat.CreateBlockSmoother(jacblocks)``
+      (:383); without ``amg`` just ``J``.  Native: applied inside the fused loops.
+    * ``GS=True``  -> ``y = 0; J.Smooth(y, x); [r = x - A y; y += AMG r;] J.SmoothBack(y, x)``
+      (:376-381) over a multicolour block ordering (scope row N1).  Without ``amg`` native (fused
+      loops); with ``amg`` the multiplicative composition runs through the protocol."""
+    if GS and amg:
+        return _MultiplicativePreA(space, a, jacblocks)
     op = hipla.BlockGaussSeidel(a.mat, jacblocks) if GS else hipla.BlockJacobi(a.mat, jacblocks)
     op.space, op.GS = space, GS
+    if amg:
+        return hipla.SmoothedAggregationAMG(a.mat) + op
     return op
 
 
@@ -60,7 +93,8 @@ class NavierStokes:
         out.data = -self.gfup                          # reference: pressure = -gfup (:163-165)
         return out
 
-    def SolveInitial(self, timesteps=None, iterative=True, GS=True, tol=1e-10, maxsteps=100000, printrates=False):
+    def SolveInitial(self, timesteps=None, iterative=True, GS=True, tol=1e-10, maxsteps=100000, printrates=False,
+                     amg=False):
         if timesteps:
             raise NotImplementedError("projection time stepping: SURVEY.md section 8f row N4")
         if not iterative:
@@ -68,7 +102,7 @@ class NavierStokes:
         blfA = AssembledForm(self.a.mat)
         blfB = AssembledForm(self.b.mat)
         preM = hipla.Preconditioner(self.mp, "local")
-        preA = MypreA(self.V, blfA, self.system.facet_blocks(), GS=GS)
+        preA = MypreA(self.V, blfA, self.system.facet_blocks(), GS=GS, amg=amg)
         sol = BlockVector([self.gfu, self.gfup])       # aliases the grid-function storage (:206)
         out = BramblePasciakCG(blfA, blfB, None, self.f.vec, self.g.vec, preA, preM, sol, initialize=False,
                                tol=tol, maxsteps=maxsteps, rel_err=True, printrates=printrates)

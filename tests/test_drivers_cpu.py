@@ -207,3 +207,31 @@ def test_heat_config1_driver(numpy_engine):
     np.testing.assert_allclose(hist, d["cg_history"], rtol=1e-8)
     assert abs(np.linalg.norm(x.numpy()) - float(d["cg_x_norm"])) < 1e-9 * float(d["cg_x_norm"])
     np.testing.assert_allclose(np.linalg.eigvalsh(gal), np.linalg.eigvalsh(d["galerkin"]), rtol=1e-7)
+
+
+def test_mypre_a_with_amg_term(numpy_engine):
+    """MypreA with the AMG term in both of the reference's forms (additive :383, multiplicative
+    :376-381): both are symmetric positive operators and cut the iteration count of the driver."""
+    import hipla
+    from templates.NavierStokesSIMPLE_iterative import MypreA, NavierStokes, SyntheticMesh
+    ns = NavierStokes(SyntheticMesh(0.125, dim=2), nu=0.001, inflow="inlet", outflow="outlet", wall="wall|cyl", uin=None,
+                      timestep=0.001, order=1)
+    blocks = ns.system.facet_blocks()
+    rng = np.random.default_rng(0)
+    x, z = rng.standard_normal(ns.V.ndof), rng.standard_normal(ns.V.ndof)
+    for gs in (False, True):
+        P = MypreA(ns.V, ns.a, blocks, GS=gs, amg=True)
+        px, pz = hipla.Vector(ns.V.ndof), hipla.Vector(ns.V.ndof)
+        px.data = P * hipla.Vector.from_numpy(x)
+        pz.data = P * hipla.Vector.from_numpy(z)
+        assert abs(px.numpy() @ z - x @ pz.numpy()) < 1e-9 * abs(px.numpy() @ z) + 1e-12
+        assert px.numpy() @ x > 0
+    counts = {}
+    for amg in (False, True):
+        for gs in (False, True):
+            ns.gfu[:] = 0.0
+            ns.gfup[:] = 0.0
+            with contextlib.redirect_stdout(io.StringIO()):
+                ns.SolveInitial(iterative=True, GS=gs, amg=amg, tol=1e-8)
+            counts[(amg, gs)] = ns.stokes_bpcg_iterations
+    assert counts[(True, False)] < counts[(False, False)] and counts[(True, True)] < counts[(False, True)]
