@@ -671,6 +671,66 @@ class BlockGaussSeidel(BaseMatrix):
         return self
 
 
+class CGSolver(BaseMatrix):
+    """``CGSolver(mat, pre, precision, maxsteps, printrates)`` as an operator ``y = mat^-1 x`` --
+    the NGSolve class the reference uses for its inner solves
+    (templates/NavierStokesSIMPLE_iterative.py:92 ``invmstar1``, :130 ``invproj1``).  Preconditioned
+    conjugate gradients through the protocol (SpMV / lincomb / dot kernels); stops when
+    ``sqrt(<r, pre r>)`` has dropped by ``precision`` relative to its initial value."""
+
+    def __init__(self, mat, pre=None, precision=1e-8, maxsteps=200, printrates=False, inner=None):
+        super().__init__()
+        from .vector import InnerProduct
+        self.mat, self.pre = mat, pre
+        self.precision, self.maxsteps, self.printrates = float(precision), int(maxsteps), printrates
+        self.inner = inner if inner is not None else InnerProduct
+        self.iterations = 0
+        self.errors = []
+
+    def Height(self):
+        return self.mat.height
+
+    def Width(self):
+        return self.mat.width
+
+    def Mult(self, x, y):
+        from math import sqrt
+        dot = self.inner
+        r, z, p, q = (y.CreateVector() for _ in range(4))
+        y[:] = 0.0
+        r.data = x
+        z.data = self.pre * r if self.pre is not None else r
+        p.data = z
+        rz = dot(r, z)
+        err0 = sqrt(abs(rz))
+        self.errors = [err0]
+        self.iterations = 0
+        if err0 == 0.0:
+            return
+        for it in range(self.maxsteps):
+            q.data = self.mat * p
+            alpha = rz / dot(p, q)
+            y.data += alpha * p
+            r.data -= alpha * q
+            z.data = self.pre * r if self.pre is not None else r
+            rz_new = dot(r, z)
+            err = sqrt(abs(rz_new))
+            self.errors.append(err)
+            self.iterations = it + 1
+            if self.printrates:
+                print("it = ", it, " err = ", err)
+            if err < self.precision * err0:
+                break
+            p.data = z + (rz_new / rz) * p
+            rz = rz_new
+
+    MultTrans = Mult          # mat symmetric on this path
+
+    @property
+    def T(self):
+        return self
+
+
 class Projector(BaseMatrix):
     """``Projector(mask, range)``: keeps entries where ``mask == range``."""
 

@@ -11,13 +11,21 @@ with ``preA`` = facet-block Jacobi (``MypreA`` with ``GS=False`` minus the AMG t
 ``GS=True`` (the reference's default) selects the symmetric multiplicative block Gauss-Seidel
 sweep (:376-381) over a multicolour block ordering, ``GS=False`` the additive block Jacobi.
 
-Out of scope (SURVEY.md sections 2 and 8f): the MCS/HDG assembly, the auxiliary-space AMG
-correction (N3), static condensation (N2), the IMEX time stepping ``DoTimeStep`` / ``Project``
-(N4) and the sparse direct branch ``iterative=False``.  Those raise ``NotImplementedError``
-naming the row."""
+``DoTimeStep`` / ``Project`` / ``SolveInitial(timesteps=N)`` (:400-443, scope row N4) are the
+reference's orchestration restated on the staggered-grid operators: ``invmstar`` = CG on
+``M_u + timestep * A`` (:85-96), ``Project`` = pressure projection through CG on ``B M_u^-1 B^T``
+(:115-144,440-443), explicit Euler update ``u += timestep * temp2`` (:438).  The convection term
+(:106-113, JIT-compiled nonlinear form) is not modelled: ``conv_operator`` is ``None`` unless the
+caller installs an operator.
+
+Out of scope: the MCS/HDG assembly itself and the sparse direct branch
+``iterative=False`` (raises ``NotImplementedError``)."""
+
+import numpy as np
+import scipy.sparse as sp
 
 import hipla
-from hipla import BlockVector
+from hipla import BlockVector, CGSolver
 from discretizations import AssembledForm, SyntheticMesh, assemble, bdm_hybrid
 from solvers.bramblepasciak_new import BramblePasciakCG
 
@@ -82,6 +90,26 @@ class NavierStokes:
         self.gfup = hipla.Vector(self.Q.ndof)
         self.stokes_bpcg_iterations = None
         self.stokes_bpcg_time = None
+        self.conv_operator = None
+        self._stepping = None
+
+    def _time_stepping_operators(self):
+        """mstar = M_u + timestep*A with its CG inverse (:85-96) and the projection operators
+        (:115-144): pressure operator B M_u^-1 B^T, CG inverse, velocity correction M_u^-1 B^T."""
+        if self._stepping is None:
+            s = self.system
+            mass_u = s.h ** s.dim * self.V.dofs_per_site ** 0       # lumped velocity mass: cell volume
+            m_u = np.full(s.n_u, mass_u)
+            mstar = hipla.SparseMatrix.from_scipy((sp.diags(m_u) + self.timestep * s.A).tocsr())
+            invmstar = CGSolver(mstar, pre=hipla.JacobiPreconditioner(mstar), precision=1e-4, maxsteps=500)
+            bt_scaled = (sp.diags(1.0 / m_u) @ s.B.T).tocsr()
+            lap_p = (s.B @ bt_scaled).tocsr()
+            lap_p.sort_indices()
+            Lp = hipla.SparseMatrix.from_scipy(lap_p)
+            invproj = CGSolver(Lp, pre=hipla.JacobiPreconditioner(Lp), precision=1e-8, maxsteps=5000)
+            self._stepping = dict(invmstar=invmstar, invproj=invproj, correct=hipla.SparseMatrix.from_scipy(bt_scaled),
+                                  mstar=mstar, Lp=Lp)
+        return self._stepping
 
     @property
     def velocity(self):
@@ -95,8 +123,19 @@ class NavierStokes:
 
     def SolveInitial(self, timesteps=None, iterative=True, GS=True, tol=1e-10, maxsteps=100000, printrates=False,
                      amg=False):
-        if timesteps:
-            raise NotImplementedError("projection time stepping: SURVEY.md section 8f row N4")
+        if timesteps:                                     # pseudo time stepping to the Stokes state (:406-417)
+            ops = self._time_stepping_operators()
+            self.Project(self.gfu)
+            for it in range(timesteps):
+                print("it =", it)
+                temp = self.a.mat.CreateColVector()
+                temp2 = self.a.mat.CreateColVector()
+                temp.data = -self.a.mat * self.gfu
+                temp2.data = ops["invmstar"] * temp
+                self.Project(temp2)
+                self.gfu.data += self.timestep * temp2
+                self.Project(self.gfu)
+            return
         if not iterative:
             raise NotImplementedError("sparse direct initial solve is not on the Krylov path")
         blfA = AssembledForm(self.a.mat)
@@ -111,8 +150,31 @@ class NavierStokes:
         else:                                          # zero initial residual: bare vector (:191-192)
             self.stokes_bpcg_iterations, self.stokes_bpcg_time = 0, 0.0
 
+    def AddForce(self, force):
+        """`force`: host array of nodal forces on the velocity dofs, added to f (:419-422)."""
+        self.f.vec.data += hipla.Vector.from_numpy(np.asarray(force, dtype=np.float64))
+
     def DoTimeStep(self):
-        raise NotImplementedError("IMEX time stepping: SURVEY.md section 8f row N4")
+        """One IMEX step (:424-438): temp = conv(u) + f - A u;  temp2 = invmstar temp;
+        Project(temp2);  u += timestep * temp2."""
+        ops = self._time_stepping_operators()
+        temp = self.a.mat.CreateColVector()
+        temp2 = self.a.mat.CreateColVector()
+        if self.conv_operator is not None:
+            temp.data = self.conv_operator * self.gfu
+        else:
+            temp[:] = 0.0
+        temp.data += self.f.vec
+        temp.data += -self.a.mat * self.gfu
+        temp2.data = ops["invmstar"] * temp
+        self.Project(temp2)
+        self.gfu.data += self.timestep * temp2
 
     def Project(self, vel):
-        raise NotImplementedError("pressure projection: SURVEY.md section 8f row N4")
+        """Make `vel` discretely divergence-free (:440-443): phi = (B M_u^-1 B^T)^-1 B vel;
+        pressure <- phi;  vel -= M_u^-1 B^T phi."""
+        ops = self._time_stepping_operators()
+        rhs = self.b.mat.CreateColVector()
+        rhs.data = self.b.mat * vel
+        self.gfup.data = ops["invproj"] * rhs
+        vel.data -= ops["correct"] * self.gfup

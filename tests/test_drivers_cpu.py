@@ -63,8 +63,6 @@ def test_navier_stokes_class_and_sweep(numpy_engine, tmp_path):
     from templates.run_navier_stokes_parameter_sweep import sweep
     ns = NavierStokes(SyntheticMesh(0.2, dim=2), nu=0.001, inflow="inlet", outflow="outlet", wall="wall|cyl", uin=None,
                       timestep=0.001, order=2)
-    with pytest.raises(NotImplementedError):
-        ns.DoTimeStep()
     with contextlib.redirect_stdout(io.StringIO()):
         ns.SolveInitial(iterative=True, GS=False, tol=1e-8)
     its_jacobi = ns.stokes_bpcg_iterations
@@ -235,3 +233,51 @@ def test_mypre_a_with_amg_term(numpy_engine):
                 ns.SolveInitial(iterative=True, GS=gs, amg=amg, tol=1e-8)
             counts[(amg, gs)] = ns.stokes_bpcg_iterations
     assert counts[(True, False)] < counts[(False, False)] and counts[(True, True)] < counts[(False, True)]
+
+
+def test_time_stepping_orchestration(numpy_engine):
+    """Scope row N4: CGSolver as an operator, pressure projection, IMEX step and the pseudo time
+    stepping branch of SolveInitial, checked against dense host algebra."""
+    import hipla
+    from templates.NavierStokesSIMPLE_iterative import NavierStokes, SyntheticMesh
+    ns = NavierStokes(SyntheticMesh(0.125, dim=2), nu=0.01, inflow="inlet", outflow="outlet", wall="wall|cyl", uin=None,
+                      timestep=0.05, order=1)
+    s = ns.system
+    ops = ns._time_stepping_operators()
+    rng = np.random.default_rng(2)
+    # CGSolver = inverse of M_u + tau A to its precision
+    r = rng.standard_normal(s.n_u)
+    y = hipla.Vector(s.n_u)
+    y.data = ops["invmstar"] * hipla.Vector.from_numpy(r)
+    mstar = ops["mstar"].to_scipy().toarray()
+    exact = np.linalg.solve(mstar, r)
+    assert np.linalg.norm(y.numpy() - exact) < 2e-3 * np.linalg.norm(exact) and 1 < ops["invmstar"].iterations < 500
+    # projection: divergence-free afterwards, idempotent, pressure = potential
+    v0 = rng.standard_normal(s.n_u)
+    vel = hipla.Vector.from_numpy(v0)
+    ns.Project(vel)
+    assert np.linalg.norm(s.B @ vel.numpy()) < 1e-6 * np.linalg.norm(s.B @ v0)
+    once = vel.numpy().copy()
+    ns.Project(vel)
+    assert np.linalg.norm(vel.numpy() - once) < 1e-6 * np.linalg.norm(once)
+    # one IMEX step against the dense computation (convection absent)
+    u0 = once
+    ns.gfu.set_from(u0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        ns.DoTimeStep()
+    f = ns.f.vec.numpy()
+    t2 = np.linalg.solve(mstar, f - s.A @ u0)
+    m_u = np.full(s.n_u, s.h ** s.dim)
+    L = s.B @ np.diag(1.0 / m_u) @ s.B.T
+    phi = np.linalg.lstsq(np.asarray(L), s.B @ t2, rcond=None)[0]
+    t2p = t2 - (s.B.T @ phi) / m_u
+    assert np.linalg.norm(ns.gfu.numpy() - (u0 + ns.timestep * t2p)) < 5e-3 * np.linalg.norm(ns.timestep * t2p)
+    assert np.linalg.norm(s.B @ ns.gfu.numpy()) < 1e-5 * np.linalg.norm(ns.gfu.numpy()) * abs(s.B).max()
+    # pseudo time stepping (SolveInitial(timesteps=N), :406-417) decays towards the Stokes state of f = 0 forcing
+    ns.f.vec[:] = 0.0
+    ns.gfu.set_from(once)
+    e0 = float(once @ (s.A @ once))
+    with contextlib.redirect_stdout(io.StringIO()):
+        ns.SolveInitial(timesteps=5)
+    u5 = ns.gfu.numpy()
+    assert float(u5 @ (s.A @ u5)) < 0.9 * e0 and np.linalg.norm(s.B @ u5) < 1e-5 * np.linalg.norm(u5) * abs(s.B).max()

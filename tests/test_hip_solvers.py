@@ -627,3 +627,31 @@ def test_amg_vcycle_and_fused_bpcg_with_amg(hip_engine):
             assert np.linalg.norm(b - s.saddle_matrix() @ x_h) < 1e-6 * np.linalg.norm(b)
         results[n] = runs_h["amg"][0]
     assert results[20] < 1.5 * results[12] + 10           # iteration count nearly mesh-independent
+
+
+def test_time_stepping_on_gpu(hip_engine):
+    """Scope row N4 on the product engine: CGSolver inner solves, Project and DoTimeStep keep the
+    velocity discretely divergence-free and agree with the host computation."""
+    import hipla
+    from templates.NavierStokesSIMPLE_iterative import NavierStokes, SyntheticMesh
+    ns = NavierStokes(SyntheticMesh(0.1, dim=3), nu=0.01, inflow="inlet", outflow="outlet", wall="wall|cyl", uin=None,
+                      timestep=0.05, order=1)
+    s = ns.system
+    v0 = np.random.default_rng(2).standard_normal(s.n_u)
+    vel = hipla.Vector.from_numpy(v0)
+    ns.Project(vel)
+    assert np.linalg.norm(s.B @ vel.numpy()) < 1e-6 * np.linalg.norm(s.B @ v0)
+    ns.gfu.data = vel
+    u0 = vel.numpy()
+    with contextlib.redirect_stdout(io.StringIO()):
+        ns.DoTimeStep()
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spl
+    m_u = np.full(s.n_u, s.h ** s.dim)
+    t2 = spl.spsolve((sp.diags(m_u) + ns.timestep * s.A).tocsc(), ns.f.vec.numpy() - s.A @ u0)
+    du = (ns.gfu.numpy() - u0) / ns.timestep
+    assert np.linalg.norm(s.B @ ns.gfu.numpy()) < 1e-5 * np.linalg.norm(ns.gfu.numpy()) * abs(s.B).max()
+    # du is the divergence-free part of t2: their difference is a discrete gradient M_u^-1 B^T phi
+    diff = (t2 - du) * m_u
+    phi = spl.lsqr(s.B.T.tocsr(), diff, atol=1e-12, btol=1e-12)[0]
+    assert np.linalg.norm(s.B.T @ phi - diff) < 5e-3 * np.linalg.norm(diff)
