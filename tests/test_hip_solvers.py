@@ -597,7 +597,7 @@ def test_amg_vcycle_and_fused_bpcg_with_amg(hip_engine):
                 y2 = hipla.Vector(s.n_u)
                 y2.data = 1.5 * V * hipla.Vector.from_numpy(x)
                 runs = {}
-                for label, pre in (("amg", V), ("amg+bjac", V + J)):
+                for label, pre in (("amg", V), ("amg+bjac", V + J), ("amg+jacobi", V + hipla.JacobiPreconditioner(A))):
                     sol = hipla.BlockVector([hipla.Vector(s.n_u), hipla.Vector(s.n_p)])
                     if name == "hip":
                         with contextlib.redirect_stdout(io.StringIO()):
@@ -619,7 +619,7 @@ def test_amg_vcycle_and_fused_bpcg_with_amg(hip_engine):
         assert np.linalg.norm(y_h - y_n) <= 1e-12 * np.linalg.norm(y_n)
         assert np.linalg.norm(y2_h - 1.5 * y_n) <= 1e-12 * np.linalg.norm(y_n)
         b = np.concatenate([f, g])
-        for label in ("amg", "amg+bjac"):
+        for label in ("amg", "amg+bjac", "amg+jacobi"):
             it_h, hist_h, x_h = runs_h[label]
             it_n, hist_n, x_n = runs_n[label]
             np.testing.assert_allclose(hist_h[:25], hist_n[:25], rtol=1e-8)
