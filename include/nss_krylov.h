@@ -248,6 +248,31 @@ NSS_API int nss_bpcg2_iterate_dist(const nss_bpcg2_t* s, nss_dist_t d, const nss
                                    const nss_halo_t* halo_t1, const nss_halo_t* halo_t4, int32_t overlap,
                                    int32_t it_begin, int32_t it_end, nss_stream_t stream);
 
+/* ---- fused preconditioned conjugate gradients -------------------------------------------------
+ * The inner solver of the reference's time stepping (`CGSolver(mstar.mat, pre=..)`,
+ * templates/NavierStokesSIMPLE_iterative.py:92,130) and the "CG" of BASELINE config 1.
+ * x (start value given), r = b - A x, z = pre r, p = z prepared by the host; per iteration:
+ * q = A p with partial <p,q>;  alpha = rz / <p,q>;  x += alpha p, r -= alpha q;  z = pre r with
+ * partial <r,z>;  beta = rz_new / rz;  p = z + beta p.  Stops when sqrt|<r,z>| < tol * err0.
+ * scal: double[8] = { rz, <p,q>, rz_new, err0, tol, -, -, - };  ctrl: int32[4] = { done, it_final,
+ * last_it, - };  hist[it] = sqrt|<r,z>| after iteration it. */
+typedef struct nss_cg_s {
+  nss_csr_t A;
+  const double* pre_diag;     /* z = dinv r            -- or NULL */
+  nss_bjac_t pre_bjac;        /* block Jacobi / GS     -- or NULL */
+  nss_amg_t pre_amg;          /* AMG V-cycle           -- or NULL; none of the three: z = r */
+  double *x, *r, *z, *p, *q;
+  double* scal;
+  int32_t* ctrl;
+  double* hist;
+  double *partials_a, *partials_b;  /* A's row-block count / element-wise grid: nss_cg_workspace() */
+  int32_t n;
+} nss_cg_t;
+NSS_API int nss_cg_workspace(const nss_cg_t* s, int64_t* partials_a, int64_t* partials_b);
+NSS_API int nss_cg_iterate(const nss_cg_t* s, int32_t it_begin, int32_t it_end, nss_stream_t stream);
+NSS_API int nss_cg_poll(const nss_cg_t* s, int32_t* done, int32_t* it_final, int32_t* last_it,
+                        nss_stream_t stream);
+
 /* ---- fused preconditioned MINRES ----------------------------------------------------------
  * Replaces the loop body of minres.py:96-144 for K = [[A, B^T], [B, 0]], C = diag(preA, preS)
  * (the operands run.py:45-46 builds).  Vectors are given per block component ([0] velocity, n_u;

@@ -40,6 +40,14 @@ def conjugate_gradients(mat, rhs, tol=1e-10, maxsteps=1000):
     return x, history
 
 
+def conjugate_gradients_fused(mat, rhs, tol=1e-10, maxsteps=1000):
+    """The same CG through `hipla.CGSolver` (device-resident loop ``nss_cg_*`` on the GPU)."""
+    solver = hipla.CGSolver(mat, pre=None, precision=tol, maxsteps=maxsteps)
+    x = rhs.CreateVector()
+    x.data = solver * rhs
+    return x, solver.errors
+
+
 def krylov_galerkin(mat, start, dimension=5):
     """Krylov basis {v, Mv, .., M^(d-1) v}, orthonormalised (heat.py:95-100), and its Galerkin
     matrix G[r, c] = <b_r, M b_c> (heat.py:109-118)."""

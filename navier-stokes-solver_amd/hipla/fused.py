@@ -416,3 +416,95 @@ class Bpcg1Loop:
                 break
         count = it_stop.value + 1 if stop.value else max_steps
         return [float(x) for x in eng.to_host(self.hist)[:count]], bool(stop.value)
+
+
+class CgState(C.Structure):
+    """ctypes mirror of ``nss_cg_t`` (include/nss_krylov.h)."""
+    _fields_ = ([(n, C.c_void_p) for n in ("A", "pre_diag", "pre_bjac", "pre_amg", "x", "r", "z", "p", "q",
+                                           "scal", "ctrl", "hist", "partials_a", "partials_b")]
+                + [("n", C.c_int32)])
+
+
+class CgLoop:
+    """Device-resident preconditioned CG (``nss_cg_*``) behind `hipla.CGSolver`."""
+
+    @classmethod
+    def try_create(cls, mat, pre):
+        if not isinstance(mat, SparseMatrix) or mat.height != mat.width:
+            return None
+        eng = mat.engine
+        if not ENABLED or not _hip(eng) or not hasattr(eng.lib, "nss_cg_iterate"):
+            return None
+        kind = None
+        if pre is None:
+            kind = ("none", None)
+        elif isinstance(pre, DiagonalMatrix):
+            kind = ("diag", pre)
+        elif isinstance(pre, (BlockJacobi, BlockGaussSeidel)):
+            kind = ("bjac", pre)
+        elif isinstance(pre, SmoothedAggregationAMG):
+            kind = ("amg", pre)
+        if kind is None:
+            return None
+        return cls(eng, mat, kind)
+
+    def __init__(self, eng, mat, kind):
+        torch = eng.torch
+        self.eng, self.lib, self.mat, self.kind = eng, eng.lib, mat, kind
+        n = mat.height
+        self.work = {name: eng.zeros(n) for name in ("r", "z", "p", "q")}
+        st = CgState()
+        st.A, st.n = mat.handle.ptr, n
+        st.pre_diag = kind[1].d.data_ptr() if kind[0] == "diag" else None
+        st.pre_bjac = kind[1].handle.ptr if kind[0] == "bjac" else None
+        st.pre_amg = kind[1].handle.ptr if kind[0] == "amg" else None
+        for name, buf in self.work.items():
+            setattr(st, name, buf.data_ptr())
+        na, nb = C.c_int64(), C.c_int64()
+        eng._check(self.lib.nss_cg_workspace(C.byref(st), C.byref(na), C.byref(nb)))
+        self.partials = [eng.zeros(max(1, v.value)) for v in (na, nb)]
+        st.partials_a, st.partials_b = (p.data_ptr() for p in self.partials)
+        self.scal = eng.zeros(8)
+        self.ctrl = torch.zeros(4, dtype=torch.int32, device=eng.device)
+        st.scal, st.ctrl = self.scal.data_ptr(), self.ctrl.data_ptr()
+        self.state = st
+        self.hist = None
+
+    def solve(self, b, x, precision, maxsteps, poll_every=None):
+        """x = mat^-1 b from x = 0.  Returns (iterations, errors) with errors[0] = err0."""
+        from math import sqrt
+        eng, st, w = self.eng, self.state, self.work
+        poll_every = poll_every or POLL_EVERY
+        eng.fill(x, 0.0)
+        eng.copy(b, w["r"])
+        kind, pre = self.kind
+        if kind == "none":
+            eng.copy(w["r"], w["z"])
+        elif kind == "diag":
+            eng.diag_apply(pre.d, 1.0, w["r"], 0.0, w["z"])
+        elif kind == "bjac":
+            eng.bjac_apply(pre.handle, 1.0, w["r"], 0.0, w["z"])
+        else:
+            eng.amg_apply(pre.handle, 1.0, w["r"], w["z"])
+        eng.copy(w["z"], w["p"])
+        rz = eng.dot(w["r"], w["z"])
+        err0 = sqrt(abs(rz))
+        if err0 == 0.0:
+            return 0, [0.0]
+        self.hist = eng.zeros(max(1, maxsteps))
+        st.hist, st.x = self.hist.data_ptr(), x.data_ptr()
+        scal = np.zeros(8)
+        scal[0], scal[3], scal[4] = rz, err0, precision
+        eng.upload(scal, self.scal)
+        self.ctrl.zero_()
+        done, it_final, last = C.c_int32(), C.c_int32(), C.c_int32()
+        it = 0
+        while it < maxsteps:
+            end = min(maxsteps, it + poll_every)
+            eng._check(self.lib.nss_cg_iterate(C.byref(st), it, end, eng.stream))
+            it = end
+            eng._check(self.lib.nss_cg_poll(C.byref(st), C.byref(done), C.byref(it_final), C.byref(last), eng.stream))
+            if done.value:
+                break
+        count = it_final.value + 1 if done.value else maxsteps
+        return count, [err0] + [float(v) for v in eng.to_host(self.hist)[:count]]

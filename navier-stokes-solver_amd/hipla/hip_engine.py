@@ -62,6 +62,9 @@ def _signatures():
         "nss_amg_create": (C.c_int, [i32, vp, vp, dbl, C.POINTER(vp)]),
         "nss_amg_destroy": (C.c_int, [vp]),
         "nss_amg_apply_f64": (C.c_int, [vp, dbl, vp, vp, vp]),
+        "nss_cg_workspace": (C.c_int, [vp, c_i64_p, c_i64_p]),
+        "nss_cg_iterate": (C.c_int, [vp, i32, i32, vp]),
+        "nss_cg_poll": (C.c_int, [vp, c_i32_p, c_i32_p, c_i32_p, vp]),
         "nss_bpcg2_workspace": (C.c_int, [vp, c_i64_p, c_i64_p, c_i64_p]),
         "nss_bpcg2_phase": (C.c_int, [vp, i32, i32, vp]),
         "nss_bpcg2_phases": (C.c_int, [vp, i32, i32, i32, vp]),

@@ -686,6 +686,7 @@ class CGSolver(BaseMatrix):
         self.inner = inner if inner is not None else InnerProduct
         self.iterations = 0
         self.errors = []
+        self._fused = False           # device-resident loop (nss_cg_*), created on first use
 
     def Height(self):
         return self.mat.height
@@ -695,6 +696,13 @@ class CGSolver(BaseMatrix):
 
     def Mult(self, x, y):
         from math import sqrt
+        from .vector import InnerProduct, Vector
+        if self._fused is False:
+            from .fused import CgLoop
+            self._fused = CgLoop.try_create(self.mat, self.pre) if self.inner is InnerProduct else None
+        if self._fused is not None and isinstance(x, Vector) and isinstance(y, Vector) and not self.printrates:
+            self.iterations, self.errors = self._fused.solve(x.buf, y.buf, self.precision, self.maxsteps)
+            return
         dot = self.inner
         r, z, p, q = (y.CreateVector() for _ in range(4))
         y[:] = 0.0

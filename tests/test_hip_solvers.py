@@ -655,3 +655,44 @@ def test_time_stepping_on_gpu(hip_engine):
     diff = (t2 - du) * m_u
     phi = spl.lsqr(s.B.T.tocsr(), diff, atol=1e-12, btol=1e-12)[0]
     assert np.linalg.norm(s.B.T @ phi - diff) < 5e-3 * np.linalg.norm(diff)
+
+
+def test_fused_cg_solver(hip_engine):
+    """hipla.CGSolver on native operands takes the device-resident loop (nss_cg_*): same history as
+    the protocol loop, all preconditioner kinds, config-1 CG against the golden."""
+    import heat
+    import hipla
+    from hipla import fused
+    s = mac_stokes(3, 9, 0.01)
+    A = hipla.SparseMatrix.from_scipy(s.A)
+    b = np.random.default_rng(1).standard_normal(s.n_u)
+    bv = hipla.Vector.from_numpy(b)
+    import scipy.sparse.linalg as spl
+    exact = spl.spsolve(s.A.tocsc(), b)
+    pres = {"none": None, "jacobi": hipla.JacobiPreconditioner(A), "bjac": hipla.BlockJacobi(A, s.line_blocks(3)),
+            "bgs": hipla.BlockGaussSeidel(A, s.line_blocks(3)), "amg": hipla.SmoothedAggregationAMG(A, coarse_size=200)}
+    for name, pre in pres.items():
+        runs = {}
+        for mode in ("fused", "protocol"):
+            fused.ENABLED = mode == "fused"
+            try:
+                cg = hipla.CGSolver(A, pre=pre, precision=1e-10, maxsteps=2000)
+                x = hipla.Vector(s.n_u)
+                x.data = cg * bv
+                assert (cg._fused is not None) == (mode == "fused")
+                runs[mode] = (cg.iterations, np.array(cg.errors), x.numpy())
+            finally:
+                fused.ENABLED = True
+        (it_f, e_f, x_f), (it_p, e_p, x_p) = runs["fused"], runs["protocol"]
+        assert abs(it_f - it_p) <= max(2, int(0.03 * it_p)), (name, it_f, it_p)
+        m = min(25, len(e_f), len(e_p))
+        np.testing.assert_allclose(e_f[:m], e_p[:m], rtol=1e-8)
+        assert np.linalg.norm(x_f - exact) < 1e-7 * np.linalg.norm(exact), name
+    assert runs["fused"][0] < 60                                     # AMG-preconditioned CG
+    d = np.load(golden_path("cfg1_heat_plumbing"))
+    from staggered_grid import diffusion_2d
+    M = hipla.SparseMatrix.from_scipy(diffusion_2d(int(d["n"])))
+    rhs = hipla.Vector.from_numpy(np.random.default_rng(int(d["seed"])).standard_normal(M.height))
+    x, errors = heat.conjugate_gradients_fused(M, rhs, tol=1e-10)
+    assert len(errors) - 1 == int(d["cg_iterations"])
+    np.testing.assert_allclose(errors, d["cg_history"], rtol=1e-8)
