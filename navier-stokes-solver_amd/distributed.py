@@ -138,8 +138,8 @@ class TorchComm:
     def exchange(self, plan, sendbuf, ext):
         """Fill ext[n_owned:] with the ghost entries; `sendbuf` already holds the packed
         entries for every destination (ordered by destination rank)."""
-        if self.size == 1 or (plan.n_ghost == 0 and sendbuf.shape[0] == 0):
-            return
+        if self.size == 1:
+            return                 # (with more ranks the all-to-all is collective: never skip it)
         tail, send = self._t(ext)[plan.n_owned:], self._t(sendbuf)
         outs, ins = [int(c) for c in plan.recv_counts], [int(c) for c in plan.send_counts]
         if self.stage and tail.is_cuda:
@@ -186,6 +186,7 @@ class DistSparseMatrix(BaseMatrix):
         self.local_scipy = loc
         self.local = SparseMatrix.from_scipy(loc, engine=self.engine)
         self.plan = HaloPlan(r, comm.size, self.n_cols_owned, ghosts, self.col_offsets)
+
         def requests_of(q):
             _, gq = localize_rows(global_csr, (self.row_offsets[q], self.row_offsets[q + 1]), self.col_offsets, q)
             return HaloPlan(q, comm.size, self.col_offsets[q + 1] - self.col_offsets[q], gq, self.col_offsets).requests()
