@@ -40,7 +40,10 @@ def main():
               ("symmetric block Gauss-Seidel bs=3 (GS=True)", lambda: hipla.BlockGaussSeidel(A, s.line_blocks(3))),
               ("AMG V(1,1)", lambda: hipla.SmoothedAggregationAMG(A)),
               ("AMG V(1,1) + block Jacobi (additive MypreA)", lambda: hipla.SmoothedAggregationAMG(A) + hipla.BlockJacobi(A, s.line_blocks(3)))]
+    only = sys.argv[3].split(",") if len(sys.argv) > 3 else None
     for label, make in makers:
+        if only and not any(label.startswith(o) for o in only):
+            continue
         t0 = time.perf_counter()
         pre = make()
         torch.cuda.synchronize()
