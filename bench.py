@@ -37,6 +37,9 @@ def parse_args():
     ap.add_argument("--nu", type=float, default=0.01, help="1/Re")
     ap.add_argument("--pre", default="bjac3", choices=["bjac3", "jacobi", "bgs3", "bgs3p"],
                     help="preA: block Jacobi bs=3 (headline), point Jacobi, symmetric block Gauss-Seidel bs=3")
+    ap.add_argument("--inflate", type=int, default=1,
+                    help="HDG-like stress variant: Kronecker-inflate the operator with bs x bs blocks "
+                         "(12 -> ~84 nnz per row as the reference's order-2 3-D spaces); preA = facet blocks")
     ap.add_argument("--cpu-iters", type=int, default=-1, help="oracle iterations to time (-1: auto, 0: skip)")
     ap.add_argument("--kernel-reps", type=int, default=30)
     return ap.parse_args()
@@ -130,8 +133,12 @@ def main():
 
     t_asm = time.perf_counter()
     sysm = mac_stokes(args.dim, args.n, args.nu)
+    if args.inflate > 1:
+        sysm = sysm.inflate(args.inflate)
     f, g = sysm.rhs(0)
     blocks = sysm.line_blocks(3) if args.pre in ("bjac3", "bgs3", "bgs3p") else None
+    if args.inflate > 1 and blocks is not None:
+        blocks = sysm.facet_blocks() if sysm.dim * args.inflate <= 16 else sysm.line_blocks(1)
     gs_colors = None
     if args.pre == "bgs3p":        # block Gauss-Seidel in the colour-permuted dof space
         from hipla import coloring
