@@ -37,7 +37,6 @@ namespace nss {
 
 constexpr int kChunk = 2048;            // products staged per workgroup: 16 KiB of LDS
 constexpr int kMaxRowsPerBlock = 2048;  // bound for blocks of empty / very short rows
-constexpr int kMaxRowsWide = 256;       // rows per block when several lanes share a row (RG > 1)
 constexpr int kXcds = 8;
 
 struct CsrView {
@@ -81,7 +80,6 @@ template <int RG, class Epi>
 __global__ __launch_bounds__(kBlock) void csr_stream_kernel(CsrView a, const double* __restrict__ x, Epi epi) {
   __shared__ double prod[kChunk];
   __shared__ double red[kBlock / kWave];
-  __shared__ double rowsum[RG > 1 ? kMaxRowsWide : 1];
   if (epi.skip()) return;
   const int tid = threadIdx.x;
   // XCD-aware map: workgroups with equal (blockIdx & 7) share an XCD; XCD i owns the i-th
@@ -148,29 +146,16 @@ __global__ __launch_bounds__(kBlock) void csr_stream_kernel(CsrView a, const dou
       // ---- phase 2: per-row reduction from LDS -----------------------------------------
       constexpr int kRowsPerPass = kBlock / RG;
       const int sub = tid % RG;
-      if (RG == 1) {
-        for (int r = r0 + tid; r < r1; r += kRowsPerPass) {
-          const int s = a.rowptr[r] - p0;
-          const int e = a.rowptr[r + 1] - p0;
-          double sum = 0.0;
-          for (int j = s; j < e; ++j) sum += prod[j];
-          epi.row(r, sum);
-        }
-      } else {
-        // RG lanes per row + butterfly; the row sums are parked in LDS so that the epilogue
-        // (extra vector loads / stores of the fused loops) runs with one lane per row on
-        // consecutive rows -- coalesced -- instead of on every RG-th lane.
-        for (int r = r0 + tid / RG; r < r1; r += kRowsPerPass) {
-          const int s = a.rowptr[r] - p0;
-          const int e = a.rowptr[r + 1] - p0;
-          double sum = 0.0;
-          for (int j = s + sub; j < e; j += RG) sum += prod[j];
+      for (int r = r0 + tid / RG; r < r1; r += kRowsPerPass) {
+        const int s = a.rowptr[r] - p0;
+        const int e = a.rowptr[r + 1] - p0;
+        double sum = 0.0;
+        for (int j = s + sub; j < e; j += RG) sum += prod[j];
+        if (RG > 1) {
 #pragma unroll
           for (int off = RG / 2; off > 0; off >>= 1) sum += __shfl_xor(sum, off, kWave);
-          if (sub == 0) rowsum[r - r0] = sum;
         }
-        __syncthreads();
-        for (int r = r0 + tid; r < r1; r += kBlock) epi.row(r, rowsum[r - r0]);
+        if (sub == 0) epi.row(r, sum);
       }
     } else {
       // ---- one row longer than the LDS chunk: the whole workgroup reduces it ----------

@@ -18,7 +18,7 @@ static void plan_row_blocks(int32_t m, int64_t nnz, const int32_t* rowptr, int32
   const int rows_per_pass = kBlock / rg;
   int passes = mean > 0.0 ? int(double(kChunk) / (mean * rows_per_pass)) : kMaxRowsPerBlock / rows_per_pass;
   passes = std::max(1, passes);
-  const int row_cap = std::min(rg > 1 ? kMaxRowsWide : kMaxRowsPerBlock, passes * rows_per_pass);
+  const int row_cap = std::min(kMaxRowsPerBlock, passes * rows_per_pass);
   blk.clear();
   blk.push_back(0);
   int32_t r = 0;
