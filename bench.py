@@ -134,6 +134,10 @@ def main():
     t_asm = time.perf_counter()
     sysm = mac_stokes(args.dim, args.n, args.nu)
     if args.inflate > 1:
+        est = sysm.A.nnz * args.inflate ** 2
+        if est > 6e8:                                    # host assembly needs ~100 B per non-zero
+            raise SystemExit("--inflate %d of --grid %d would give %.1e non-zeros in A; use a smaller "
+                             "--grid (e.g. --grid 44 --inflate 12, --grid 60 --inflate 5)" % (args.inflate, args.n, est))
         sysm = sysm.inflate(args.inflate)
     f, g = sysm.rhs(0)
     blocks = sysm.line_blocks(3) if args.pre in ("bjac3", "bgs3", "bgs3p") else None

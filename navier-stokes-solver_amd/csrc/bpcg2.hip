@@ -75,11 +75,12 @@ struct EpiK2 {
   double* __restrict__ partials;
   double acc = 0.0;
   __device__ bool skip() const { return ctrl[C_DONE] != 0; }
-  __device__ void row(int r, double at1) {
-    const double sv = s0[r];
+  struct Pre { double s0 = 0.0, t1 = 0.0, t0 = 0.0; };
+  __device__ Pre fetch(int r) const { return Pre{s0[r], t1[r], t0[r]}; }
+  __device__ void row(int r, double at1, const Pre& p) {
     t2[r] = at1;
-    t4[r] = t1[r] - sv;
-    acc = fma(sv, at1 - t0[r], acc);
+    t4[r] = p.t1 - p.s0;
+    acc = fma(p.s0, at1 - p.t0, acc);
   }
   __device__ void finish(int b, double* lds) {
     const double s = block_sum(acc, lds);
@@ -94,9 +95,11 @@ struct EpiK3 {
   double* __restrict__ partials;
   double acc = 0.0;
   __device__ bool skip() const { return ctrl[C_DONE] != 0; }
-  __device__ void row(int r, double bt4) {
+  struct Pre { double s1 = 0.0; };
+  __device__ Pre fetch(int r) const { return Pre{s1[r]}; }
+  __device__ void row(int r, double bt4, const Pre& p) {
     t3[r] = bt4;
-    acc = fma(s1[r], bt4, acc);
+    acc = fma(p.s1, bt4, acc);
   }
   __device__ void finish(int b, double* lds) {
     const double s = block_sum(acc, lds);

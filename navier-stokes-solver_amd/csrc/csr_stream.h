@@ -7,7 +7,7 @@
 //   phase 1  every lane streams val[] / col[] with unit stride (fully coalesced HBM
 //            reads, 8 independent loads in flight per lane), gathers x[col] (served by
 //            L2 / Infinity Cache for banded operators) and stages the products in LDS;
-//   phase 2  each row is reduced from LDS by RG lanes (RG = 1, 4, 16 or 64 chosen from
+//   phase 2  each row is reduced from LDS by RG lanes (RG = 1 ... 64, a power of two chosen from
 //            the mean row length) with a __shfl_xor butterfly, in a fixed order -- no
 //            atomics, bit-reproducible;
 //   epilogue a functor consumes (row, A x) -- plain alpha/beta update or the fused
@@ -20,6 +20,8 @@
 // L2 keeps one window of x instead of all eight L2s caching the same window.
 #pragma once
 
+#include <type_traits>
+
 #include "nss_common.h"
 
 namespace nss {
@@ -29,6 +31,10 @@ namespace nss {
 // case (interleaved A/B, one box): plain A SpMV 0.173 -> 0.163 ms, BPCG iteration +4 %.
 #ifndef NSS_STREAM_NT
 #define NSS_STREAM_NT 1
+#endif
+
+#ifndef NSS_STREAM_PREFETCH
+#define NSS_STREAM_PREFETCH 1   // request row bounds + epilogue operands before the matrix stream
 #endif
 
 #ifndef NSS_STREAM_VEC2
@@ -72,10 +78,26 @@ namespace nss {
 
 // Epi interface:
 //   __device__ void row(int r, double ax);          // called once per row by one lane
+// or, to have the row's read-only operands requested before the matrix stream,
+//   struct Pre;  __device__ Pre fetch(int r) const;
+//   __device__ void row(int r, double ax, const Pre&);
 //   __device__ void finish(int b, double* lds);     // called by all threads at the end; b = row
 //                                                   // block of this workgroup (-1: padding), the
 //                                                   // slot of its dot partial
 //   __device__ bool skip() const;                   // e.g. solver already converged
+template <class E, class = void>
+struct EpiPre {
+  struct type {};
+  static __device__ type fetch(const E&, int) { return type{}; }
+  static __device__ void row(E& e, int r, double ax, const type&) { e.row(r, ax); }
+};
+template <class E>
+struct EpiPre<E, std::void_t<typename E::Pre>> {
+  using type = typename E::Pre;
+  static __device__ type fetch(const E& e, int r) { return e.fetch(r); }
+  static __device__ void row(E& e, int r, double ax, const type& p) { e.row(r, ax, p); }
+};
+
 template <int RG, class Epi>
 __global__ __launch_bounds__(kBlock) void csr_stream_kernel(CsrView a, const double* __restrict__ x, Epi epi) {
   __shared__ double prod[kChunk];
@@ -93,6 +115,15 @@ __global__ __launch_bounds__(kBlock) void csr_stream_kernel(CsrView a, const dou
     const int r1 = a.rowblk[b + 1];
     const int p0 = a.rowptr[r0];
     const int cnt = a.rowptr[r1] - p0;
+#if NSS_STREAM_PREFETCH
+    // Row bounds and epilogue operands of this lane's first phase-2 row are requested now, so
+    // their HBM latency overlaps the matrix stream instead of following the barrier.
+    const int rf = r0 + tid / RG;
+    const bool has_first = rf < r1;
+    const int rf_s = has_first ? a.rowptr[rf] : 0;
+    const int rf_e = has_first ? a.rowptr[rf + 1] : 0;
+    typename EpiPre<Epi>::type pre0 = has_first ? EpiPre<Epi>::fetch(epi, rf) : typename EpiPre<Epi>::type{};
+#endif
     if (cnt <= kChunk) {
       // ---- phase 1: coalesced stream of (col, val), gather x, stage products ---------
 #if NSS_STREAM_VEC2
@@ -146,6 +177,20 @@ __global__ __launch_bounds__(kBlock) void csr_stream_kernel(CsrView a, const dou
       // ---- phase 2: per-row reduction from LDS -----------------------------------------
       constexpr int kRowsPerPass = kBlock / RG;
       const int sub = tid % RG;
+#if NSS_STREAM_PREFETCH
+      for (int r = rf; r < r1; r += kRowsPerPass) {
+        const bool first = r == rf;
+        const int s = (first ? rf_s : a.rowptr[r]) - p0;
+        const int e = (first ? rf_e : a.rowptr[r + 1]) - p0;
+        double sum = 0.0;
+        for (int j = s + sub; j < e; j += RG) sum += prod[j];
+        if (RG > 1) {
+#pragma unroll
+          for (int off = RG / 2; off > 0; off >>= 1) sum += __shfl_xor(sum, off, kWave);
+        }
+        if (sub == 0) EpiPre<Epi>::row(epi, r, sum, first ? pre0 : EpiPre<Epi>::fetch(epi, r));
+      }
+#else
       for (int r = r0 + tid / RG; r < r1; r += kRowsPerPass) {
         const int s = a.rowptr[r] - p0;
         const int e = a.rowptr[r + 1] - p0;
@@ -155,14 +200,15 @@ __global__ __launch_bounds__(kBlock) void csr_stream_kernel(CsrView a, const dou
 #pragma unroll
           for (int off = RG / 2; off > 0; off >>= 1) sum += __shfl_xor(sum, off, kWave);
         }
-        if (sub == 0) epi.row(r, sum);
+        if (sub == 0) EpiPre<Epi>::row(epi, r, sum, EpiPre<Epi>::fetch(epi, r));
       }
+#endif
     } else {
       // ---- one row longer than the LDS chunk: the whole workgroup reduces it ----------
       double acc = 0.0;
       for (int i = tid; i < cnt; i += kBlock) acc = fma(a.val[p0 + i], x[a.col[p0 + i]], acc);
       const double sum = block_sum(acc, red);
-      if (tid == 0) epi.row(r0, sum);
+      if (tid == 0) EpiPre<Epi>::row(epi, r0, sum, EpiPre<Epi>::fetch(epi, r0));
     }
   }
   epi.finish(b, red);  // one dot partial per row block
@@ -178,8 +224,11 @@ inline void launch_csr_stream(const nss_csr_s& A, const double* x, const Epi& ep
   const dim3 grid(nss_csr_s::grid(b1 - b0)), block(kBlock);
   switch (A.rg) {
     case 1: hipLaunchKernelGGL((csr_stream_kernel<1, Epi>), grid, block, 0, st, v, x, epi); break;
+    case 2: hipLaunchKernelGGL((csr_stream_kernel<2, Epi>), grid, block, 0, st, v, x, epi); break;
     case 4: hipLaunchKernelGGL((csr_stream_kernel<4, Epi>), grid, block, 0, st, v, x, epi); break;
+    case 8: hipLaunchKernelGGL((csr_stream_kernel<8, Epi>), grid, block, 0, st, v, x, epi); break;
     case 16: hipLaunchKernelGGL((csr_stream_kernel<16, Epi>), grid, block, 0, st, v, x, epi); break;
+    case 32: hipLaunchKernelGGL((csr_stream_kernel<32, Epi>), grid, block, 0, st, v, x, epi); break;
     default: hipLaunchKernelGGL((csr_stream_kernel<64, Epi>), grid, block, 0, st, v, x, epi); break;
   }
   NSS_CHECK_LAUNCH();
@@ -189,10 +238,12 @@ inline void launch_csr_stream(const nss_csr_s& A, const double* x, const Epi& ep
 struct EpiAxpby {
   double alpha, beta;
   double* __restrict__ y;
+  struct Pre { double y = 0.0; };
   __device__ bool skip() const { return false; }
-  __device__ void row(int r, double ax) const {
+  __device__ Pre fetch(int r) const { return Pre{beta != 0.0 ? y[r] : 0.0}; }
+  __device__ void row(int r, double ax, const Pre& p) const {
     double t = alpha * ax;
-    if (beta != 0.0) t = fma(beta, y[r], t);
+    if (beta != 0.0) t = fma(beta, p.y, t);
     y[r] = t;
   }
   __device__ void finish(int, double*) const {}

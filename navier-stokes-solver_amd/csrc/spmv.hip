@@ -9,15 +9,19 @@ namespace nss {
 static void plan_row_blocks(int32_t m, int64_t nnz, const int32_t* rowptr, int32_t* rg_out,
                             std::vector<int32_t>& blk, const int32_t* cuts = nullptr, int ncuts = 0) {
   const double mean = m > 0 ? double(nnz) / double(m) : 0.0;
+  // Lanes per row: the largest power of two for which one reduce pass (kBlock / rg rows) still
+  // covers a full chunk of products, i.e. rg ~ mean / 8.  Long rows then fill the LDS chunk
+  // (all 8 loads per lane in flight) and every row's bounds and epilogue operands are
+  // prefetched (csr_stream.h); rows shorter than 8 take several passes with one lane per row.
   int rg = 1;
-  if (mean > 192.0) rg = 64;
-  else if (mean > 48.0) rg = 16;
-  else if (mean > 12.0) rg = 4;
+  while (rg < kWave && double(2 * rg) * (kChunk / kBlock) <= mean) rg *= 2;
   *rg_out = rg;
-  // rows per block: a whole number of reduce passes whose products still fit the chunk
   const int rows_per_pass = kBlock / rg;
-  int passes = mean > 0.0 ? int(double(kChunk) / (mean * rows_per_pass)) : kMaxRowsPerBlock / rows_per_pass;
-  passes = std::max(1, passes);
+  int passes = 1;
+  if (rg == 1) {
+    passes = mean > 0.0 ? int(double(kChunk) / (mean * rows_per_pass)) : kMaxRowsPerBlock / rows_per_pass;
+    passes = std::max(1, passes);
+  }
   const int row_cap = std::min(kMaxRowsPerBlock, passes * rows_per_pass);
   blk.clear();
   blk.push_back(0);

