@@ -21,7 +21,9 @@ struct EpiResidual {   // r = b - A x
   const double* __restrict__ b;
   double* __restrict__ r;
   __device__ bool skip() const { return false; }
-  __device__ void row(int i, double ax) const { r[i] = b[i] - ax; }
+  struct Pre { double b = 0.0; };
+  __device__ Pre fetch(int i) const { return Pre{b[i]}; }
+  __device__ void row(int i, double ax, const Pre& p) const { r[i] = p.b - ax; }
   __device__ void finish(int, double*) const {}
 };
 
@@ -32,7 +34,9 @@ struct EpiJacobi {     // y = x + w dinv (b - A x)
   double* __restrict__ y;
   double w;
   __device__ bool skip() const { return false; }
-  __device__ void row(int i, double ax) const { y[i] = fma(w * dinv[i], b[i] - ax, x[i]); }
+  struct Pre { double b = 0.0, x = 0.0, dinv = 0.0; };
+  __device__ Pre fetch(int i) const { return Pre{b[i], x[i], dinv[i]}; }
+  __device__ void row(int i, double ax, const Pre& p) const { y[i] = fma(w * p.dinv, p.b - ax, p.x); }
   __device__ void finish(int, double*) const {}
 };
 

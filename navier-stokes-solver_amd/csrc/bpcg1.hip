@@ -37,10 +37,12 @@ struct EpiV1b {
   const double* __restrict__ dinv;
   double k;
   __device__ bool skip() const { return ctrl[PC_STOP] != 0; }
-  __device__ void row(int r, double btp) const {
-    const double ku = t1u[r] + btp;
+  struct Pre { double t1u = 0.0, dinv = 0.0; };
+  __device__ Pre fetch(int r) const { return Pre{t1u[r], dinv ? dinv[r] : 0.0}; }
+  __device__ void row(int r, double btp, const Pre& p) const {
+    const double ku = p.t1u + btp;
     t1u[r] = -ku;
-    if (dinv) t2u[r] = k * (dinv[r] * ku);
+    if (dinv) t2u[r] = k * (p.dinv * ku);
   }
   __device__ void finish(int, double*) const {}
 };
@@ -64,10 +66,12 @@ struct EpiV3 {  // y += A x ; partial <d, y>
   double* __restrict__ partials;
   double acc = 0.0;
   __device__ bool skip() const { return ctrl[PC_STOP] != 0; }
-  __device__ void row(int r, double ax) {
-    const double t = y[r] + ax;
+  struct Pre { double y = 0.0, d = 0.0; };
+  __device__ Pre fetch(int r) const { return Pre{y[r], d[r]}; }
+  __device__ void row(int r, double ax, const Pre& p) {
+    const double t = p.y + ax;
     y[r] = t;
-    acc = fma(d[r], t, acc);
+    acc = fma(p.d, t, acc);
   }
   __device__ void finish(int b, double* lds) {
     const double s = block_sum(acc, lds);
@@ -84,10 +88,12 @@ struct EpiV5 {
   double* __restrict__ partials;
   double acc = 0.0;
   __device__ bool skip() const { return ctrl[PC_STOP] != 0; }
-  __device__ void row(int r, double bau) {
-    const double t = minv[r] * (bau - ap[r]);
+  struct Pre { double minv = 0.0, ap = 0.0, rp = 0.0; };
+  __device__ Pre fetch(int r) const { return Pre{minv[r], ap[r], rp[r]}; }
+  __device__ void row(int r, double bau, const Pre& p) {
+    const double t = p.minv * (bau - p.ap);
     t1p[r] = t;
-    acc = fma(t, rp[r], acc);
+    acc = fma(t, p.rp, acc);
   }
   __device__ void finish(int b, double* lds) {
     const double s = block_sum(acc, lds);

@@ -22,9 +22,11 @@ struct EpiCgQ {
   double* __restrict__ partials;
   double acc = 0.0;
   __device__ bool skip() const { return ctrl[GC_DONE] != 0; }
-  __device__ void row(int r, double ap) {
+  struct Pre { double p = 0.0; };
+  __device__ Pre fetch(int r) const { return Pre{p[r]}; }
+  __device__ void row(int r, double ap, const Pre& pre) {
     q[r] = ap;
-    acc = fma(p[r], ap, acc);
+    acc = fma(pre.p, ap, acc);
   }
   __device__ void finish(int b, double* lds) {
     const double s = block_sum(acc, lds);

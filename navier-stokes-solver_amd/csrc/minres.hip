@@ -49,10 +49,12 @@ struct EpiMAccDot {  // y (+)= A x ; partial <y, z>
   double* __restrict__ partials;
   double acc = 0.0;
   __device__ bool skip() const { return minres_skip(ctrl, k); }
-  __device__ void row(int r, double ax) {
-    const double t = accumulate ? y[r] + ax : ax;
+  struct Pre { double y = 0.0, z = 0.0; };
+  __device__ Pre fetch(int r) const { return Pre{accumulate ? y[r] : 0.0, z[r]}; }
+  __device__ void row(int r, double ax, const Pre& p) {
+    const double t = accumulate ? p.y + ax : ax;
     y[r] = t;
-    acc = fma(t, z[r], acc);
+    acc = fma(t, p.z, acc);
   }
   __device__ void finish(int b, double* lds) {
     const double s = block_sum(acc, lds);

@@ -123,7 +123,9 @@ struct EpiGsResidual {
   double* __restrict__ res;
   double xscale;
   __device__ bool skip() const { return done && done[0] != 0; }
-  __device__ void row(int r, double ay) const { res[r] = fma(xscale, x[rowdof[r]], -ay); }
+  struct Pre { double x = 0.0; };
+  __device__ Pre fetch(int r) const { return Pre{x[rowdof[r]]}; }
+  __device__ void row(int r, double ay, const Pre& p) const { res[r] = fma(xscale, p.x, -ay); }
   __device__ void finish(int, double*) const {}
 };
 

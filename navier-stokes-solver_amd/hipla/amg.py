@@ -93,7 +93,7 @@ def _coarsest(A, d, omega, dense_limit):
     return sp.diags(omega / d).tocsr()
 
 
-def build_hierarchy(A, max_levels=10, coarse_size=2000, omega=2.0 / 3.0, seed=0, theta=0.0,
+def build_hierarchy(A, max_levels=10, coarse_size=2000, omega=2.0 / 3.0, seed=0, theta=0.04,
                     dense_limit=6000):
     """List of levels, finest first: dict(A, dinv, P, R) and on the coarsest dict(A, dinv, inv).
     `theta` is the strength-of-connection threshold of the aggregation on the coarse levels (the
@@ -127,7 +127,7 @@ class SmoothedAggregationAMG(BaseMatrix):
     """``y = V(x)``: one symmetric V(1,1)-cycle of the smoothed-aggregation hierarchy of `mat`
     (a `SparseMatrix`), applied on the engine."""
 
-    def __init__(self, mat, max_levels=10, coarse_size=2000, omega=2.0 / 3.0, seed=0, theta=0.0):
+    def __init__(self, mat, max_levels=10, coarse_size=2000, omega=2.0 / 3.0, seed=0, theta=0.04):
         super().__init__()
         if not isinstance(mat, SparseMatrix):
             raise TypeError("SmoothedAggregationAMG needs a SparseMatrix")
