@@ -50,6 +50,8 @@ NSS_API int nss_stream_synchronize(nss_stream_t stream);
 NSS_API int nss_fill_f64(int64_t n, double value, double* x, nss_stream_t stream);
 NSS_API int nss_copy_f64(int64_t n, const double* x, double* y, nss_stream_t stream);
 NSS_API int nss_scal_f64(int64_t n, double a, double* x, nss_stream_t stream);
+/* y_i = 1 / x_i (inverse diagonals of the AMG levels; IEEE division) */
+NSS_API int nss_reciprocal_f64(int64_t n, const double* x, double* y, nss_stream_t stream);
 /* y = sum_{i<nterms} h_coeff[i] * x_i, 1 <= nterms <= 4, evaluated left to right;
  * y may alias any x_i (element-wise).  h_x is a HOST array of device pointers. */
 NSS_API int nss_lincomb_f64(int64_t n, int32_t nterms, const double* h_coeff,
@@ -84,9 +86,17 @@ NSS_API int nss_csr_create_cuts(int32_t nrows, int32_t ncols, int64_t nnz, const
                                 const int32_t* h_col, const double* h_val, int32_t ncuts,
                                 const int32_t* h_cuts, nss_csr_t* out);
 /* explicit transpose as a new CSR handle (`matB.CreateTranspose()`, solvers/bramblepasciak_new.py:198;
- * `b.T`, run.py:45).  Counting sort on the host inside the library, entries of a row of the result
- * ordered by column; set-up, not on the iteration path. */
+ * `b.T`, run.py:45).  Stable radix sort of the entries by column on the device, entries of a row of
+ * the result ordered by column; set-up, not on the iteration path. */
 NSS_API int nss_csr_transpose(nss_csr_t a, nss_csr_t* out);
+/* C = X Y as a new CSR handle (Galerkin products of the AMG set-up).  Expand / stable sort / compress
+ * on the device: no atomics, every c_ij is the sum of x_ik * y_kj in ascending k, each product and
+ * each addition rounded once (no FMA) -- bit-identical to a row-wise CPU product.  Rows are processed
+ * in passes of at most max_products_per_pass products (<= 0: library default, 2^27). */
+NSS_API int nss_csr_spgemm(nss_csr_t x, nss_csr_t y, int64_t max_products_per_pass, nss_csr_t* out,
+                           nss_stream_t stream);
+/* copy the CSR arrays back to HOST buffers (rows+1 / nnz / nnz entries; sizes from nss_csr_info) */
+NSS_API int nss_csr_download(nss_csr_t a, int32_t* h_rowptr, int32_t* h_col, double* h_val);
 NSS_API int nss_csr_destroy(nss_csr_t a);
 /* y = alpha * A x + beta * y   (beta == 0: y is not read).  x must not alias y. */
 NSS_API int nss_csr_spmv_f64(nss_csr_t a, double alpha, const double* x, double beta, double* y,
@@ -140,9 +150,22 @@ NSS_API int nss_bjac_symgs_apply_f64(nss_bjac_t j, double xscale, const double* 
  * Counterpart of the 'h1amg' correction inside the reference's MypreA
  * (templates/NavierStokesSIMPLE_iterative.py:320-357,380,383).  The
  * hierarchy (A_l, P_l, R_l = P_l^T, inverse diagonals, dense inverse of the coarsest operator as
- * a CSR matrix) is built by the host; the cycle runs on the device with CSR-stream SpMVs:
+ * a CSR matrix) is built with the set-up entry points below; the cycle runs on the device with CSR-stream SpMVs:
  *   x = w D^-1 b;  r = b - A x;  x += P V(R r);  x += w D^-1 (b - A x).
  * The library allocates the per-level work vectors. */
+/* Set-up on the device.
+ * nss_amg_aggregate: aggregates of smoothed aggregation over the strength graph of A
+ *   (j strong for i  <=>  j != i and |a_ij| >= theta * sqrt(|a_ii a_jj|); theta <= 0: every
+ *   off-diagonal entry).  Roots = maximal independent set of the distance-2 graph (Luby rounds with
+ *   the caller's distinct positive priorities, DEVICE int64[n]); roots are numbered in index order,
+ *   unaggregated nodes join their first aggregated strong neighbour in four sweeps, the rest become
+ *   singletons.  d_agg: DEVICE int64[n] out; *nagg_out: number of aggregates.  Integer state only:
+ *   the result is identical to oracle/krylov_ref.py::sa_aggregate.
+ * nss_amg_prolongator: P = (I - omega D^-1 A) T, T = piecewise-constant prolongator of d_agg. */
+NSS_API int nss_amg_aggregate(nss_csr_t a, double theta, const int64_t* d_priority, int64_t* d_agg,
+                              int64_t* nagg_out, nss_stream_t stream);
+NSS_API int nss_amg_prolongator(nss_csr_t a, const int64_t* d_agg, int64_t nagg, double omega, nss_csr_t* out,
+                                nss_stream_t stream);
 typedef struct nss_amg_level_s {
   nss_csr_t A;          /* level operator (n x n)                                  */
   nss_csr_t P, R;       /* prolongation (n x n_coarse) and restriction; NULL on the coarsest level */

@@ -31,6 +31,12 @@ Scratch& scratch() {
 }
 
 // ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void reciprocal_kernel(int64_t n, const double* __restrict__ x,
+                                                             double* __restrict__ y) {
+  const int64_t stride = int64_t(gridDim.x) * kBlock;
+  for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride) y[i] = 1.0 / x[i];
+}
+
 template <bool VEC2>
 __global__ __launch_bounds__(kBlock) void fill_kernel(int64_t n, double value, double* __restrict__ x) {
   const int64_t stride = int64_t(gridDim.x) * kBlock;
@@ -260,6 +266,14 @@ int nss_fill_f64(int64_t n, double value, double* x, nss_stream_t stream) {
       hipLaunchKernelGGL(fill_kernel<true>, dim3(grid), dim3(kBlock), 0, as_stream(stream), n, value, x);
     else
       hipLaunchKernelGGL(fill_kernel<false>, dim3(grid), dim3(kBlock), 0, as_stream(stream), n, value, x);
+    NSS_CHECK_LAUNCH();
+  });
+}
+
+int nss_reciprocal_f64(int64_t n, const double* x, double* y, nss_stream_t stream) {
+  return guarded([&] {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(reciprocal_kernel, dim3(stream_grid(n, kBlock)), dim3(kBlock), 0, as_stream(stream), n, x, y);
     NSS_CHECK_LAUNCH();
   });
 }

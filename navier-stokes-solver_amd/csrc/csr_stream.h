@@ -21,6 +21,7 @@
 #pragma once
 
 #include <type_traits>
+#include <vector>
 
 #include "nss_common.h"
 
@@ -75,6 +76,10 @@ struct nss_csr_s {
 };
 
 namespace nss {
+
+// Launch plan of a CSR matrix: lanes per row (*rg_out) and the row-block boundaries (spmv.hip).
+void plan_row_blocks(int32_t m, int64_t nnz, const int32_t* rowptr, int32_t* rg_out, std::vector<int32_t>& blk,
+                     const int32_t* cuts = nullptr, int ncuts = 0);
 
 // Epi interface:
 //   __device__ void row(int r, double ax);          // called once per row by one lane

@@ -6,8 +6,8 @@
 
 namespace nss {
 
-static void plan_row_blocks(int32_t m, int64_t nnz, const int32_t* rowptr, int32_t* rg_out,
-                            std::vector<int32_t>& blk, const int32_t* cuts = nullptr, int ncuts = 0) {
+void plan_row_blocks(int32_t m, int64_t nnz, const int32_t* rowptr, int32_t* rg_out, std::vector<int32_t>& blk,
+                     const int32_t* cuts, int ncuts) {
   const double mean = m > 0 ? double(nnz) / double(m) : 0.0;
   // Lanes per row: the largest power of two for which one reduce pass (kBlock / rg rows) still
   // covers a full chunk of products, i.e. rg ~ mean / 8.  Long rows then fill the LDS chunk
@@ -106,34 +106,6 @@ int nss_csr_create_cuts(int32_t nrows, int32_t ncols, int64_t nnz, const int32_t
       throw;
     }
     *out = A;
-  });
-}
-
-int nss_csr_transpose(nss_csr_t a, nss_csr_t* out) {
-  return guarded([&] {
-    NSS_REQUIRE(a != nullptr && out != nullptr, "csr_transpose: NULL argument");
-    const int32_t m = a->m, n = a->n;
-    const int64_t nnz = a->nnz;
-    std::vector<int32_t> rowptr(size_t(m) + 1), col(size_t(std::max<int64_t>(nnz, 1)));
-    std::vector<double> val(size_t(std::max<int64_t>(nnz, 1)));
-    NSS_HIP(hipMemcpy(rowptr.data(), a->rowptr, sizeof(int32_t) * (size_t(m) + 1), hipMemcpyDeviceToHost));
-    if (nnz > 0) {
-      NSS_HIP(hipMemcpy(col.data(), a->col, sizeof(int32_t) * nnz, hipMemcpyDeviceToHost));
-      NSS_HIP(hipMemcpy(val.data(), a->val, sizeof(double) * nnz, hipMemcpyDeviceToHost));
-    }
-    std::vector<int32_t> trow(size_t(n) + 1, 0), tcol(size_t(std::max<int64_t>(nnz, 1)));
-    std::vector<double> tval(size_t(std::max<int64_t>(nnz, 1)));
-    for (int64_t p = 0; p < nnz; ++p) ++trow[size_t(col[p]) + 1];
-    for (int32_t c = 0; c < n; ++c) trow[size_t(c) + 1] += trow[c];
-    std::vector<int32_t> fill(trow.begin(), trow.end() - 1);
-    for (int32_t r = 0; r < m; ++r)          // rows ascending: every transposed row comes out sorted
-      for (int32_t p = rowptr[r]; p < rowptr[r + 1]; ++p) {
-        const int32_t q = fill[col[p]]++;
-        tcol[q] = r;
-        tval[q] = val[p];
-      }
-    const int rc = nss_csr_create(n, m, nnz, trow.data(), tcol.data(), tval.data(), out);
-    if (rc != 0) throw Error(nss_last_error());
   });
 }
 

@@ -42,6 +42,11 @@ def _signatures():
         "nss_gather_f64": (C.c_int, [i64, vp, vp, vp, vp]),
         "nss_csr_create": (C.c_int, [i32, i32, i64, vp, vp, vp, C.POINTER(vp)]),
         "nss_csr_transpose": (C.c_int, [vp, C.POINTER(vp)]),
+        "nss_csr_spgemm": (C.c_int, [vp, vp, i64, C.POINTER(vp), vp]),
+        "nss_csr_download": (C.c_int, [vp, vp, vp, vp]),
+        "nss_reciprocal_f64": (C.c_int, [i64, vp, vp, vp]),
+        "nss_amg_aggregate": (C.c_int, [vp, dbl, vp, vp, c_i64_p, vp]),
+        "nss_amg_prolongator": (C.c_int, [vp, vp, i64, dbl, C.POINTER(vp), vp]),
         "nss_csr_destroy": (C.c_int, [vp]),
         "nss_csr_spmv_f64": (C.c_int, [vp, dbl, vp, dbl, vp, vp]),
         "nss_csr_info": (C.c_int, [vp, c_i32_p, c_i32_p, c_i64_p, c_i32_p, c_i32_p, c_i64_p]),
@@ -292,10 +297,62 @@ class HipEngine:
                                                  C.byref(out)))
         return _CsrHandle(self, out, m, n, int(col.size))
 
+    def _wrap_csr(self, ptr):
+        h = _CsrHandle(self, ptr, 0, 0, 0)
+        info = h.info()
+        h.m, h.n, h.nnz = info["rows"], info["cols"], info["nnz"]
+        return h
+
     def csr_transpose(self, h):
         out = C.c_void_p()
         self._check(self.lib.nss_csr_transpose(h.ptr, C.byref(out)))
         return _CsrHandle(self, out, h.n, h.m, h.nnz)
+
+    def csr_spgemm(self, x, y, max_products_per_pass=0):
+        """C = X Y on the device (expand / stable sort / compress, `nss_csr_spgemm`)."""
+        if x.n != y.m:
+            raise ValueError("spgemm shape mismatch: %dx%d times %dx%d" % (x.m, x.n, y.m, y.n))
+        out = C.c_void_p()
+        self._check(self.lib.nss_csr_spgemm(x.ptr, y.ptr, int(max_products_per_pass), C.byref(out), self.stream))
+        return self._wrap_csr(out)
+
+    def csr_to_host(self, h):
+        rowptr = np.zeros(h.m + 1, dtype=np.int32)
+        col = np.zeros(h.nnz, dtype=np.int32)
+        val = np.zeros(h.nnz, dtype=np.float64)
+        self._check(self.lib.nss_csr_download(h.ptr, rowptr.ctypes.data, col.ctypes.data if h.nnz else None,
+                                              val.ctypes.data if h.nnz else None))
+        return rowptr, col, val
+
+    def csr_inverse_diagonal(self, h):
+        """Device buffer 1 / diag(A)."""
+        d = self.empty(min(h.m, h.n))
+        self._check(self.lib.nss_csr_diagonal(h.ptr, d.data_ptr(), self.stream))
+        self._check(self.lib.nss_reciprocal_f64(d.shape[0], d.data_ptr(), d.data_ptr(), self.stream))
+        return d
+
+    # ---- AMG set-up (device) ------------------------------------------------------------------
+    def amg_aggregate(self, h, theta, priority):
+        """Aggregates of the strength graph of `h` (`nss_amg_aggregate`).  `priority`: host int64,
+        distinct and positive.  Returns (device int64 tensor of aggregate ids, number of aggregates)."""
+        priority = np.ascontiguousarray(priority, dtype=np.int64)
+        if priority.shape != (h.m,):
+            raise ValueError("one priority per row expected")
+        pri = self.torch.from_numpy(priority).to(self.device)
+        agg = self.torch.empty(h.m, dtype=self.torch.int64, device=self.device)
+        nagg = C.c_int64()
+        self._check(self.lib.nss_amg_aggregate(h.ptr, float(theta), pri.data_ptr(), agg.data_ptr(), C.byref(nagg),
+                                               self.stream))
+        return agg, int(nagg.value)
+
+    def amg_prolongator(self, h, agg, nagg, omega):
+        out = C.c_void_p()
+        self._check(self.lib.nss_amg_prolongator(h.ptr, agg.data_ptr(), int(nagg), float(omega), C.byref(out),
+                                                 self.stream))
+        return self._wrap_csr(out)
+
+    def index_to_host(self, buf):
+        return buf.cpu().numpy()
 
     def csr_spmv(self, h, alpha, x, beta, y):
         if x.shape[0] != h.n or y.shape[0] != h.m:

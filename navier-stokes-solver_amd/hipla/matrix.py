@@ -419,12 +419,27 @@ class SparseMatrix(BaseMatrix):
         csr.sort_indices()
         return cls(csr.shape[0], csr.shape[1], csr.indptr, csr.indices, csr.data, engine=engine)
 
+    @classmethod
+    def from_handle(cls, handle, engine=None):
+        """Wrap a matrix the engine built itself (transpose, sparse product, prolongator); the host
+        copy of its arrays is fetched only if somebody asks for it."""
+        self = cls.__new__(cls)
+        BaseMatrix.__init__(self)
+        self.engine = engine if engine is not None else get_engine()
+        self.m, self.n, self.nnz = int(handle.m), int(handle.n), int(handle.nnz)
+        self.handle = handle
+        self._transpose = None
+        self._host = None
+        return self
+
     def to_scipy(self):
         import scipy.sparse as sp
-        rowptr, col, val = self._host
+        rowptr, col, val = self.host_csr()
         return sp.csr_matrix((val, col, rowptr), shape=(self.m, self.n))
 
     def host_csr(self):
+        if self._host is None:
+            self._host = self.engine.csr_to_host(self.handle)
         return self._host
 
     def Height(self):
@@ -448,13 +463,7 @@ class SparseMatrix(BaseMatrix):
     def CreateTranspose(self):
         """Explicit transpose, built once by the engine (``nss_csr_transpose``) and cached."""
         if self._transpose is None:
-            th = self.engine.csr_transpose(self.handle)
-            rowptr, col, val = self._host
-            # host mirror of the transposed arrays (used by set-up code such as diagonal())
-            order = np.argsort(col, kind="stable")
-            rows = np.repeat(np.arange(self.m, dtype=np.int32), np.diff(rowptr))
-            trow = np.concatenate([[0], np.cumsum(np.bincount(col, minlength=self.n))]).astype(np.int32)
-            tm = SparseMatrix(self.n, self.m, trow, rows[order], val[order], engine=self.engine, handle=th)
+            tm = SparseMatrix.from_handle(self.engine.csr_transpose(self.handle), self.engine)
             tm._transpose = self
             self._transpose = tm
         return self._transpose
@@ -464,7 +473,7 @@ class SparseMatrix(BaseMatrix):
         return self.CreateTranspose()
 
     def diagonal(self):
-        rowptr, col, val = self._host
+        rowptr, col, val = self.host_csr()
         d = np.zeros(min(self.m, self.n))
         rows = np.repeat(np.arange(self.m, dtype=np.int64), np.diff(rowptr))
         on = rows == col

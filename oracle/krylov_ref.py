@@ -396,3 +396,87 @@ def cg(M, b, pre=None, tol=1e-10, maxsteps=1000):
         p = z + (rz_new / rz) * p
         rz = rz_new
     return x, np.array(hist)
+
+
+# ---- smoothed-aggregation set-up (restates csrc/amg_setup.hip; scope row N3) -----------------------
+def _neighbour_max(g, values):
+    """max over graph neighbours of `values` (0 for isolated nodes)."""
+    out = np.zeros(g.shape[0], dtype=values.dtype)
+    has = np.diff(g.indptr) > 0
+    if g.nnz:
+        out[has] = np.maximum.reduceat(values[g.indices], g.indptr[:-1][has])
+    return out
+
+
+def sa_strength_graph(A, theta):
+    """Pattern of the strong couplings: off-diagonal and ``|a_ij| >= theta * sqrt(|a_ii| |a_jj|)``
+    (theta <= 0: every stored off-diagonal entry)."""
+    coo = sp.csr_matrix(A).tocoo()
+    d = np.abs(A.diagonal())
+    keep = coo.row != coo.col
+    if theta > 0.0:
+        keep &= np.abs(coo.data) >= theta * np.sqrt(d[coo.row] * d[coo.col])
+    g = sp.csr_matrix((np.ones(int(keep.sum()), dtype=np.int8), (coo.row[keep], coo.col[keep])), shape=A.shape)
+    g.sort_indices()
+    return g
+
+
+def sa_mis2(g, priority):
+    """Roots of the aggregates: maximal independent set of the distance-2 graph of `g` by Luby
+    rounds with the given distinct positive priorities (two-hop propagation, g @ g never formed)."""
+    cand = np.ones(g.shape[0], dtype=bool)
+    roots = np.zeros(g.shape[0], dtype=bool)
+    while cand.any():
+        pri = np.where(cand, priority, 0)
+        one = _neighbour_max(g, pri)
+        two = _neighbour_max(g, np.maximum(pri, one))
+        winners = cand & (pri >= np.maximum(one, two)) & (pri > one)
+        roots |= winners
+        w = winners.astype(np.int64)
+        near1 = _neighbour_max(g, w)
+        near2 = _neighbour_max(g, np.maximum(w, near1))
+        cand &= ~(winners | (near1 > 0) | (near2 > 0))
+    return roots
+
+
+def sa_aggregate(A, theta, priority):
+    """(aggregate id per node, number of aggregates): roots numbered in index order, four sweeps in
+    which an unaggregated node joins its first aggregated strong neighbour, the rest singletons."""
+    A = sp.csr_matrix(A)
+    A.sort_indices()
+    n = A.shape[0]
+    g = sa_strength_graph(A, theta)
+    roots = np.nonzero(sa_mis2(g, np.asarray(priority, dtype=np.int64)))[0]
+    agg = -np.ones(n, dtype=np.int64)
+    agg[roots] = np.arange(roots.size)
+    rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(g.indptr))
+    cols = g.indices
+    for _ in range(4):
+        left = agg < 0
+        m = left[rows] & (agg[cols] >= 0)
+        r, first = np.unique(rows[m], return_index=True)
+        agg[r] = agg[cols[m][first]]
+    left = np.nonzero(agg < 0)[0]
+    agg[left] = roots.size + np.arange(left.size)
+    return agg, int(roots.size + left.size)
+
+
+def sa_spgemm(X, Y):
+    """C = X Y row by row in ascending k, every product and sum rounded once (scipy's csr_matmat;
+    no FMA) -- the association csrc/amg_setup.hip reproduces on the device."""
+    C = (sp.csr_matrix(X) @ sp.csr_matrix(Y)).tocsr()
+    C.sort_indices()
+    return C
+
+
+def sa_prolongator(A, agg, nagg, omega):
+    """P = T - omega * (D^-1 (A T)), T the piecewise-constant prolongator of `agg`."""
+    A = sp.csr_matrix(A)
+    n = A.shape[0]
+    tent = sp.csr_matrix((np.ones(n), (np.arange(n), agg)), shape=(n, int(nagg)))
+    AT = sa_spgemm(A, tent)                               # sums that are exactly zero are not stored
+    rows = np.repeat(np.arange(n), np.diff(AT.indptr))
+    AT.data = omega * ((1.0 / A.diagonal())[rows] * AT.data)
+    P = (tent - AT).tocsr()                               # 1 - x, 1 (zero sum) or -x; zeros not stored
+    P.sort_indices()
+    return P

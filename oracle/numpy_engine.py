@@ -16,6 +16,18 @@ class _Csr:
     def __init__(self, mat):
         self.mat = mat
 
+    @property
+    def m(self):
+        return self.mat.shape[0]
+
+    @property
+    def n(self):
+        return self.mat.shape[1]
+
+    @property
+    def nnz(self):
+        return self.mat.nnz
+
 
 class _Bjac:
     def __init__(self, idx, inv):
@@ -103,6 +115,30 @@ class NumpyEngine:
             if beta != 1.0:
                 y *= beta
             y += alpha * ax if alpha != 1.0 else ax
+
+    def csr_to_host(self, h):
+        m = h.mat.tocsr()
+        m.sort_indices()
+        return m.indptr.astype(np.int32), m.indices.astype(np.int32), m.data.astype(np.float64)
+
+    def csr_inverse_diagonal(self, h):
+        return 1.0 / h.mat.diagonal()
+
+    def index_to_host(self, buf):
+        return np.asarray(buf)
+
+    # ---- smoothed-aggregation set-up: the CPU restatement in oracle/krylov_ref.py ------------------
+    def csr_spgemm(self, x, y, max_products_per_pass=0):
+        from . import krylov_ref as kr
+        return _Csr(kr.sa_spgemm(x.mat, y.mat))
+
+    def amg_aggregate(self, h, theta, priority):
+        from . import krylov_ref as kr
+        return kr.sa_aggregate(h.mat, theta, priority)
+
+    def amg_prolongator(self, h, agg, nagg, omega):
+        from . import krylov_ref as kr
+        return _Csr(kr.sa_prolongator(h.mat, agg, nagg, omega))
 
     # ---- smoothed-aggregation V(1,1)-cycle on the hierarchy built by hipla/amg.py -----------------
     def amg_create(self, levels, omega):

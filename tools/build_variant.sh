@@ -8,7 +8,8 @@ SRC=$(dirname $0)/../navier-stokes-solver_amd/csrc
 OUT=$(dirname $0)/../build/ab
 mkdir -p $OUT/obj_$NAME
 for f in $SRC/*.hip; do
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -fvisibility=hidden --offload-arch=gfx950 $FLAGS -c $f -o $OUT/obj_$NAME/$(basename $f .hip).o &
+  EXTRA=""; [ "$(basename $f)" = amg_setup.hip ] && EXTRA="-ffp-contract=off"
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -fvisibility=hidden --offload-arch=gfx950 $FLAGS $EXTRA -c $f -o $OUT/obj_$NAME/$(basename $f .hip).o &
 done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libnss_$NAME.so $OUT/obj_$NAME/*.o
