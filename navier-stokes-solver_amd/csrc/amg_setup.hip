@@ -39,6 +39,10 @@ struct Dev {  // owning device array
   explicit Dev(size_t count) { alloc(count); }
   Dev(const Dev&) = delete;
   Dev& operator=(const Dev&) = delete;
+  Dev(Dev&& o) noexcept : p(o.p), n(o.n) {
+    o.p = nullptr;
+    o.n = 0;
+  }
   ~Dev() { release(); }
   void alloc(size_t count) {
     release();
@@ -218,10 +222,12 @@ __global__ __launch_bounds__(kBlock) void gather_offsets_kernel(int32_t m, const
   if (i <= m) roff[i] = off[rowptr[i]];
 }
 
-// products of the X rows [ra, rb): key = ((row - ra) << cbits | column) << ebits | position of the
-// X entry in its row -- unique, so the order of equal (row, column) pairs after the sort is the
-// k order whatever the sort does with ties; value = x * y
-__global__ __launch_bounds__(kBlock) void expand_kernel(int32_t ra, int32_t rb, const int32_t* __restrict__ xrowptr,
+// products of the X entries [e_begin, e_end): key = ((row - ra) << cbits | column) << ebits | position
+// of the X entry in its row -- unique, so the order of equal (row, column) pairs after the sort is
+// the k order whatever the sort does with ties; value = x * y.  One lane per X entry.
+__global__ __launch_bounds__(kBlock) void expand_kernel(int64_t e_begin, int64_t e_end, int32_t ra,
+                                                         const int32_t* __restrict__ xrowptr,
+                                                         const int32_t* __restrict__ xrows,
                                                          const int32_t* __restrict__ xcol,
                                                          const double* __restrict__ xval,
                                                          const int32_t* __restrict__ yrowptr,
@@ -230,58 +236,72 @@ __global__ __launch_bounds__(kBlock) void expand_kernel(int32_t ra, int32_t rb, 
                                                          const int64_t* __restrict__ off, int64_t off0, int cbits,
                                                          int ebits, uint64_t* __restrict__ keys,
                                                          double* __restrict__ vals) {
-  const int i = ra + blockIdx.x * (kBlock / 8) + threadIdx.x / 8;   // 8 lanes share a row of X
-  if (i >= rb) return;
+  const int64_t e = e_begin + int64_t(blockIdx.x) * kBlock + threadIdx.x;
+  if (e >= e_end) return;
+  const int i = xrows[e];
   const uint64_t hi = uint64_t(i - ra) << cbits;
-  const int e0 = xrowptr[i];
-  for (int e = e0 + (threadIdx.x & 7); e < xrowptr[i + 1]; e += 8) {
-    const int k = xcol[e];
-    const double xv = xval[e];
-    int64_t o = off[e] - off0;
-    for (int q = yrowptr[k]; q < yrowptr[k + 1]; ++q, ++o) {
-      keys[o] = ((hi | uint64_t(uint32_t(ycol[q]))) << ebits) | uint64_t(e - e0);
-      vals[o] = __dmul_rn(xv, yval[q]);
-    }
+  const uint64_t lo = uint64_t(e - xrowptr[i]);
+  const int k = xcol[e];
+  const double xv = xval[e];
+  int64_t o = off[e] - off0;
+  for (int q = yrowptr[k]; q < yrowptr[k + 1]; ++q, ++o) {
+    keys[o] = ((hi | uint64_t(uint32_t(ycol[q]))) << ebits) | lo;
+    vals[o] = __dmul_rn(xv, yval[q]);
   }
 }
 
-// distinct keys per row of the sorted products
-__global__ __launch_bounds__(kBlock) void unique_count_kernel(int32_t ra, int32_t rb,
-                                                               const int64_t* __restrict__ roff, int64_t off0,
-                                                               const uint64_t* __restrict__ keys, int ebits,
-                                                               int32_t* __restrict__ rowcnt) {
-  const int i = ra + blockIdx.x * kBlock + threadIdx.x;
-  if (i >= rb) return;
-  const int64_t a = roff[i] - off0, b = roff[i + 1] - off0;
-  int c = 0;
-  for (int64_t p = a; p < b; ++p)
-    if (p == a || (keys[p] >> ebits) != (keys[p - 1] >> ebits)) ++c;
-  rowcnt[i] = c;
+// head[p] = 1 where a new (row, column) pair starts in the sorted products
+__global__ __launch_bounds__(kBlock) void head_flag_kernel(int64_t count, const uint64_t* __restrict__ keys,
+                                                            int ebits, uint32_t* __restrict__ head) {
+  const int64_t p = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+  if (p < count) head[p] = (p == 0 || (keys[p] >> ebits) != (keys[p - 1] >> ebits)) ? 1u : 0u;
 }
 
-// one lane per row adds each run of equal keys in its stored (= original k) order
-__global__ __launch_bounds__(kBlock) void compress_kernel(int32_t ra, int32_t rb, const int64_t* __restrict__ roff,
-                                                           int64_t off0, const uint64_t* __restrict__ keys,
-                                                           const double* __restrict__ vals, uint64_t cmask,
-                                                           int ebits, const int32_t* __restrict__ out_rowptr,
-                                                           int32_t* __restrict__ out_col,
-                                                           double* __restrict__ out_val) {
+__global__ __launch_bounds__(kBlock) void run_start_kernel(int64_t count, const uint32_t* __restrict__ head,
+                                                            const uint32_t* __restrict__ pos,
+                                                            uint32_t* __restrict__ start) {
+  const int64_t p = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+  if (p < count && head[p]) start[pos[p]] = uint32_t(p);
+  if (p == count) start[pos[count]] = uint32_t(count);
+}
+
+// one lane per (row, column) pair adds its products in their stored (= ascending k) order
+__global__ __launch_bounds__(kBlock) void run_sum_kernel(int64_t runs, const uint32_t* __restrict__ start,
+                                                          const uint64_t* __restrict__ keys,
+                                                          const double* __restrict__ vals, uint64_t cmask,
+                                                          int ebits, int32_t* __restrict__ out_col,
+                                                          double* __restrict__ out_val) {
+  const int64_t u = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+  if (u >= runs) return;
+  const uint32_t a = start[u], b = start[u + 1];
+  double s = vals[a];
+  for (uint32_t p = a + 1; p < b; ++p) s = __dadd_rn(s, vals[p]);
+  out_col[u] = int32_t((keys[a] >> ebits) & cmask);
+  out_val[u] = s;
+}
+
+// row pointers of the rows [ra, rb] of this chunk: pairs before the first product of the row
+__global__ __launch_bounds__(kBlock) void chunk_rowptr_kernel(int32_t ra, int32_t rb, const int64_t* __restrict__ roff,
+                                                               int64_t off0, const uint32_t* __restrict__ pos,
+                                                               int64_t base, int32_t* __restrict__ out_rowptr) {
   const int i = ra + blockIdx.x * kBlock + threadIdx.x;
-  if (i >= rb) return;
-  const int64_t a = roff[i] - off0, b = roff[i + 1] - off0;
-  int w = out_rowptr[i] - 1;
-  double s = 0.0;
-  for (int64_t p = a; p < b; ++p) {
-    if (p == a || (keys[p] >> ebits) != (keys[p - 1] >> ebits)) {
-      if (p != a) out_val[w] = s;
-      ++w;
-      out_col[w] = int32_t((keys[p] >> ebits) & cmask);
-      s = vals[p];
-    } else {
-      s = __dadd_rn(s, vals[p]);
-    }
-  }
-  if (b > a) out_val[w] = s;
+  if (i <= rb) out_rowptr[i] = int32_t(base + pos[roff[i] - off0]);
+}
+
+// tentative prolongator T as CSR: row i holds the single entry (agg[i], 1); *bad counts ids out of range
+__global__ __launch_bounds__(kBlock) void tentative_kernel(int32_t m, const int64_t* __restrict__ agg, int64_t nagg,
+                                                            int32_t* __restrict__ rowptr, int32_t* __restrict__ col,
+                                                            double* __restrict__ val,
+                                                            unsigned long long* __restrict__ bad) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i > m) return;
+  rowptr[i] = i;
+  if (i == m) return;
+  const int64_t a = agg[i];
+  const bool ok = a >= 0 && a < nagg;
+  if (!ok) atomicAdd(bad, 1ull);
+  col[i] = ok ? int32_t(a) : 0;
+  val[i] = 1.0;
 }
 
 // P = T - w D^-1 (A T) on the compressed A T
@@ -446,18 +466,26 @@ static void spgemm(const nss_csr_s& X, const nss_csr_s& Y, hipStream_t st, int64
   for (int32_t i = 0; i < m; ++i) max_xrow = std::max(max_xrow, h_xrow[size_t(i) + 1] - h_xrow[i]);
   const int ebits = bits_for(uint64_t(max_xrow));
 
-  // pass 1: sort each chunk, count the distinct (row, column) pairs per row
-  Dev<int32_t> rowcnt(size_t(m) + 1), out_rowptr(size_t(m) + 1);
-  NSS_HIP(hipMemsetAsync(rowcnt.p, 0, sizeof(int32_t) * (size_t(m) + 1), st));
+  Dev<int32_t> xrows{size_t(std::max<int64_t>(X.nnz, 1))};
+  if (X.nnz > 0) {
+    hipLaunchKernelGGL(row_index_kernel, dim3((m + kBlock / 8 - 1) / (kBlock / 8)), dim3(kBlock), 0, st, m, X.rowptr,
+                       xrows.p);
+    NSS_CHECK_LAUNCH();
+  }
   struct Chunk {
     int32_t ra, rb;
+    int64_t runs = 0;
+    Dev<int32_t> col;
+    Dev<double> val;
   };
   std::vector<Chunk> chunks;
   for (int32_t ra = 0; ra < m;) {
     int32_t rb = ra + 1;
     while (rb < m && h_roff[size_t(rb) + 1] - h_roff[ra] <= cap) ++rb;
-    NSS_REQUIRE(h_roff[rb] - h_roff[ra] < (int64_t(1) << 32), "spgemm: one row block exceeds 2^32 products");
-    chunks.push_back({ra, rb});
+    NSS_REQUIRE(h_roff[rb] - h_roff[ra] < (int64_t(1) << 32) - 1, "spgemm: one row block exceeds 2^32 products");
+    chunks.emplace_back();
+    chunks.back().ra = ra;
+    chunks.back().rb = rb;
     ra = rb;
   }
   int64_t max_products = 0;
@@ -471,50 +499,59 @@ static void spgemm(const nss_csr_s& X, const nss_csr_s& Y, hipStream_t st, int64
   const size_t cap_items = size_t(std::max<int64_t>(max_products, 1));
   Dev<uint64_t> keys_a(cap_items), keys_b(cap_items);
   Dev<double> vals_a(cap_items), vals_b(cap_items);
+  Dev<uint32_t> head(cap_items + 1), pos(cap_items + 1), start(cap_items + 1);
   size_t sort_bytes = 0;
   NSS_HIP(rocprim::radix_sort_pairs(nullptr, sort_bytes, keys_a.p, keys_b.p, vals_a.p, vals_b.p, cap_items, 0, end_bit,
                                     st));
   Dev<char> sort_tmp(sort_bytes);
   const uint64_t cmask = (uint64_t(1) << cbits) - 1;
+  Dev<int32_t> out_rowptr(size_t(m) + 1);
+  NSS_HIP(hipMemsetAsync(out_rowptr.p, 0, sizeof(int32_t) * (size_t(m) + 1), st));
 
-  auto expand_and_sort = [&](const Chunk& c) -> int64_t {
+  int64_t nnz = 0;
+  for (Chunk& c : chunks) {
     const int64_t off0 = h_roff[c.ra], count = h_roff[c.rb] - off0;
-    if (count == 0) return 0;
-    hipLaunchKernelGGL(expand_kernel, dim3((c.rb - c.ra + kBlock / 8 - 1) / (kBlock / 8)), dim3(kBlock), 0, st, c.ra,
-                       c.rb, X.rowptr, X.col, X.val, Y.rowptr, Y.col, Y.val, off.p, off0, cbits, ebits, keys_a.p,
-                       vals_a.p);
+    const int64_t e0 = h_xrow[c.ra], e1 = h_xrow[c.rb];
+    NSS_HIP(hipMemsetAsync(head.p, 0, sizeof(uint32_t) * (size_t(count) + 1), st));
+    if (count > 0) {
+      hipLaunchKernelGGL(expand_kernel, dim3(grid_for(e1 - e0)), dim3(kBlock), 0, st, e0, e1, c.ra, X.rowptr, xrows.p,
+                         X.col, X.val, Y.rowptr, Y.col, Y.val, off.p, off0, cbits, ebits, keys_a.p, vals_a.p);
+      NSS_CHECK_LAUNCH();
+      size_t bytes = sort_bytes;
+      NSS_HIP(rocprim::radix_sort_pairs(sort_tmp.p, bytes, keys_a.p, keys_b.p, vals_a.p, vals_b.p, size_t(count), 0,
+                                        end_bit, st));
+      hipLaunchKernelGGL(head_flag_kernel, dim3(grid_for(count)), dim3(kBlock), 0, st, count, keys_b.p, ebits, head.p);
+      NSS_CHECK_LAUNCH();
+    }
+    exclusive_sum(head.p, pos.p, size_t(count) + 1, st);
+    c.runs = fetch(pos.p + count, st);
+    NSS_REQUIRE(nnz + c.runs < (int64_t(1) << 31), "spgemm: result has more than 2^31 non-zeros");
+    hipLaunchKernelGGL(chunk_rowptr_kernel, dim3(grid_for(int64_t(c.rb - c.ra) + 1)), dim3(kBlock), 0, st, c.ra, c.rb,
+                       roff.p, off0, pos.p, nnz, out_rowptr.p);
     NSS_CHECK_LAUNCH();
-    size_t bytes = sort_bytes;
-    NSS_HIP(rocprim::radix_sort_pairs(sort_tmp.p, bytes, keys_a.p, keys_b.p, vals_a.p, vals_b.p, size_t(count), 0,
-                                      end_bit, st));
-    return count;
-  };
-
-  for (const Chunk& c : chunks) {
-    if (expand_and_sort(c) == 0) continue;
-    hipLaunchKernelGGL(unique_count_kernel, dim3(grid_for(c.rb - c.ra)), dim3(kBlock), 0, st, c.ra, c.rb, roff.p,
-                       h_roff[c.ra], keys_b.p, ebits, rowcnt.p);
-    NSS_CHECK_LAUNCH();
+    if (c.runs > 0) {
+      c.col.alloc(size_t(c.runs));
+      c.val.alloc(size_t(c.runs));
+      hipLaunchKernelGGL(run_start_kernel, dim3(grid_for(count + 1)), dim3(kBlock), 0, st, count, head.p, pos.p,
+                         start.p);
+      hipLaunchKernelGGL(run_sum_kernel, dim3(grid_for(c.runs)), dim3(kBlock), 0, st, c.runs, start.p, keys_b.p,
+                         vals_b.p, cmask, ebits, c.col.p, c.val.p);
+      NSS_CHECK_LAUNCH();
+    }
+    nnz += c.runs;
+    NSS_HIP(hipStreamSynchronize(st));
   }
-  exclusive_sum(rowcnt.p, out_rowptr.p, size_t(m) + 1, st);
-  const int64_t nnz = fetch(out_rowptr.p + m, st);
-  NSS_REQUIRE(nnz < (int64_t(1) << 31), "spgemm: result has more than 2^31 non-zeros");
+  // one chunk: its arrays are the result (re-allocated with the 4 spare entries); several: concatenate
   Dev<int32_t> out_col(size_t(nnz) + 4);
   Dev<double> out_val(size_t(nnz) + 4);
   NSS_HIP(hipMemsetAsync(out_col.p, 0, sizeof(int32_t) * (size_t(nnz) + 4), st));
   NSS_HIP(hipMemsetAsync(out_val.p, 0, sizeof(double) * (size_t(nnz) + 4), st));
-
-  // pass 2: (re-sort when there is more than one chunk) and write the sums
-  for (size_t ci = 0; ci < chunks.size(); ++ci) {
-    const Chunk& c = chunks[ci];
-    if (chunks.size() > 1 || ci > 0) {
-      if (expand_and_sort(c) == 0) continue;
-    } else if (h_roff[c.rb] == h_roff[c.ra]) {
-      continue;
-    }
-    hipLaunchKernelGGL(compress_kernel, dim3(grid_for(c.rb - c.ra)), dim3(kBlock), 0, st, c.ra, c.rb, roff.p,
-                       h_roff[c.ra], keys_b.p, vals_b.p, cmask, ebits, out_rowptr.p, out_col.p, out_val.p);
-    NSS_CHECK_LAUNCH();
+  int64_t at = 0;
+  for (Chunk& c : chunks) {
+    if (c.runs == 0) continue;
+    NSS_HIP(hipMemcpyAsync(out_col.p + at, c.col.p, sizeof(int32_t) * c.runs, hipMemcpyDeviceToDevice, st));
+    NSS_HIP(hipMemcpyAsync(out_val.p + at, c.val.p, sizeof(double) * c.runs, hipMemcpyDeviceToDevice, st));
+    at += c.runs;
   }
   NSS_HIP(hipStreamSynchronize(st));
   result.m = m;
@@ -667,20 +704,14 @@ int nss_amg_prolongator(nss_csr_t a, const int64_t* d_agg, int64_t nagg, double 
     Dev<int32_t> trow(size_t(m) + 1), tcol(size_t(m) + 4);
     Dev<double> tval(size_t(m) + 4);
     {
-      std::vector<int64_t> h_agg(m);
-      NSS_HIP(hipMemcpyAsync(h_agg.data(), d_agg, sizeof(int64_t) * m, hipMemcpyDeviceToHost, st));
-      NSS_HIP(hipStreamSynchronize(st));
-      std::vector<int32_t> h_row(size_t(m) + 1), h_col(size_t(m) + 4, 0);
-      std::vector<double> h_val(size_t(m) + 4, 0.0);
-      for (int32_t i = 0; i <= m; ++i) h_row[i] = i;
-      for (int32_t i = 0; i < m; ++i) {
-        NSS_REQUIRE(h_agg[i] >= 0 && h_agg[i] < nagg, "amg_prolongator: aggregate id out of range");
-        h_col[i] = int32_t(h_agg[i]);
-        h_val[i] = 1.0;
-      }
-      NSS_HIP(hipMemcpy(trow.p, h_row.data(), sizeof(int32_t) * h_row.size(), hipMemcpyHostToDevice));
-      NSS_HIP(hipMemcpy(tcol.p, h_col.data(), sizeof(int32_t) * h_col.size(), hipMemcpyHostToDevice));
-      NSS_HIP(hipMemcpy(tval.p, h_val.data(), sizeof(double) * h_val.size(), hipMemcpyHostToDevice));
+      Dev<unsigned long long> bad(1);
+      NSS_HIP(hipMemsetAsync(bad.p, 0, sizeof(unsigned long long), st));
+      NSS_HIP(hipMemsetAsync(tcol.p, 0, sizeof(int32_t) * (size_t(m) + 4), st));
+      NSS_HIP(hipMemsetAsync(tval.p, 0, sizeof(double) * (size_t(m) + 4), st));
+      hipLaunchKernelGGL(tentative_kernel, dim3(grid_for(int64_t(m) + 1)), dim3(kBlock), 0, st, m, d_agg, nagg, trow.p,
+                         tcol.p, tval.p, bad.p);
+      NSS_CHECK_LAUNCH();
+      NSS_REQUIRE(fetch(bad.p, st) == 0, "amg_prolongator: aggregate id out of range");
     }
     nss_csr_s* T = adopt_csr(m, int32_t(nagg), m, trow, tcol, tval);
     RawCsr p;
