@@ -235,6 +235,49 @@ def test_mypre_a_with_amg_term(numpy_engine):
     assert counts[(True, False)] < counts[(False, False)] and counts[(True, True)] < counts[(False, True)]
 
 
+def test_smoothed_aggregation_restatement_properties(numpy_engine):
+    """oracle/krylov_ref.py::sa_* (the CPU restatement csrc/amg_setup.hip is checked against):
+    aggregate roots are more than two hops apart, every node belongs to exactly one aggregate
+    the strength filter removes weak
+    couplings, the Galerkin hierarchy stays symmetric positive definite and the stall guard stops
+    on a matrix without strong couplings."""
+    import scipy.sparse as sp
+    import hipla
+    from hipla.amg import build_hierarchy
+    from oracle import krylov_ref as kr
+    from staggered_grid import mac_stokes
+    s = mac_stokes(2, 20, 0.01)
+    A = s.A.tocsr()
+    A.sort_indices()
+    pri = np.random.default_rng(0).permutation(A.shape[0]).astype(np.int64) + 1
+    g = kr.sa_strength_graph(A, 0.0)
+    assert g.nnz == A.nnz - A.shape[0]
+    roots = kr.sa_mis2(g, pri)
+    g2 = ((g @ g) + g).tocsr()
+    g2.setdiag(0)
+    g2.eliminate_zeros()
+    r = np.nonzero(roots)[0]
+    assert g2[r][:, r].nnz == 0                                   # independent at distance 2
+    covered = np.asarray((g2[:, r] != 0).sum(axis=1)).ravel() + roots
+    assert covered.min() >= 1                                     # maximal
+    agg, nagg = kr.sa_aggregate(A, 0.0, pri)
+    assert nagg == np.unique(agg).size and agg.min() == 0 and agg.max() == nagg - 1
+    assert np.array_equal(agg[r], np.arange(r.size))              # roots numbered in index order
+    # a threshold above the off-diagonal / diagonal ratio leaves no edge -> singletons
+    assert kr.sa_strength_graph(A, 0.6).nnz == 0
+    assert kr.sa_aggregate(A, 0.6, pri)[1] == A.shape[0]
+    P = kr.sa_prolongator(A, agg, nagg, 2.0 / 3.0)
+    Ac = kr.sa_spgemm(P.T.tocsr(), kr.sa_spgemm(A, P))
+    assert abs(Ac - Ac.T).max() < 1e-12 * abs(Ac).max()
+    assert np.linalg.eigvalsh(Ac.toarray()).min() > 0
+    # hierarchy through the protocol layer: sizes shrink, stall guard on a diagonal matrix
+    levels = build_hierarchy(hipla.SparseMatrix.from_scipy(A), coarse_size=30)
+    sizes = [lv["n"] for lv in levels]
+    assert sizes == sorted(sizes, reverse=True) and len(sizes) >= 3 and sizes[-1] <= 30
+    lone = build_hierarchy(hipla.SparseMatrix.from_scipy(sp.identity(500, format="csr") * 2.0), coarse_size=30)
+    assert len(lone) == 1 and "inv" in lone[0]
+
+
 def test_time_stepping_orchestration(numpy_engine):
     """Scope row N4: CGSolver as an operator, pressure projection, IMEX step and the pseudo time
     stepping branch of SolveInitial, checked against dense host algebra."""
