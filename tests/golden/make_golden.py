@@ -116,8 +116,8 @@ def main():
     ref_v1.EigenValues_Preconditioner = spy(ref_v1.EigenValues_Preconditioner)
     ref_v2.EigenValues_Preconditioner = spy(ref_v2.EigenValues_Preconditioner)
 
-    cases = [(2, 12, "jacobi"), (2, 24, "jacobi"), (2, 24, "bjac"), (2, 48, "bjac"),
-             (3, 6, "jacobi"), (3, 10, "bjac")]
+    cases = [(2, 12, "jacobi"), (2, 12, "bjac"), (2, 24, "jacobi"), (2, 24, "bjac"), (2, 48, "jacobi"),
+             (2, 48, "bjac"), (3, 6, "jacobi"), (3, 6, "bjac"), (3, 10, "jacobi"), (3, 10, "bjac")]
     nu, seed = 0.01, 0
     written = []
 

@@ -39,7 +39,7 @@ def _close_iterations(it, ref, d=None):
 
 
 def test_goldens_present():
-    assert len(CASES) == 18
+    assert len(CASES) == 30          # {2-D n=12,24,48; 3-D n=6,10} x {jacobi, bjac} x {v1, v2, MINRES}
     for q in ("quirk_minres_absolute_guard", "quirk_minres_warm_start", "quirk_bpcg2_zero_rhs",
               "quirk_bpcg2_warm_start", "quirk_bpcg2_abs_err", "quirk_bpcg1_warm_start_maxsteps",
               "cfg1_heat_plumbing"):
