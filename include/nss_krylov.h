@@ -309,6 +309,7 @@ typedef struct nss_minres_s {
   nss_csr_t A, B, BT;
   const double* pre_diag;      /* point-Jacobi preA (n_u) -- or NULL */
   nss_bjac_t pre_bjac;         /* block-Jacobi preA       -- or NULL */
+  nss_amg_t pre_amg;           /* AMG V-cycle             -- or NULL; with pre_diag / pre_bjac: preA = AMG + J */
   const double* minv;          /* preS diagonal (n_p)                */
   double* u[2];
   double* v[3][2];
@@ -331,7 +332,7 @@ NSS_API int nss_minres_poll(const nss_minres_t* s, int32_t* stop, int32_t* k_sto
 
 /* ---- fused Bramble-Pasciak CG, textbook form ------------------------------------------------
  * Replaces the loop body of bramble_pasciak_cg.py:110-143 (6 SpMV per iteration) for
- * C = None, pre_a Jacobi / block-Jacobi, pre_schur diagonal.  Block vectors per component
+ * C = None, pre_a Jacobi / block-Jacobi / AMG / AMG + Jacobi, pre_schur diagonal.  Block vectors per component
  * ([0] velocity n_u, [1] pressure n_p): x = solution, r = residuum, d =
  * full_preconditioned_residuum, a = a_preconditioned_residuum, t1 / t2 = temp_1 / temp_2.
  * scal: double[8] = { rho, <d,t1>, rho_new, alpha, beta, err0, tolerance, - };
@@ -341,6 +342,7 @@ typedef struct nss_bpcg1_s {
   nss_csr_t A, B, BT;
   const double* pre_diag;
   nss_bjac_t pre_bjac;
+  nss_amg_t pre_amg;           /* AMG V-cycle -- or NULL; with pre_diag / pre_bjac: pre_a = AMG + J */
   const double* minv;
   double *x[2], *r[2], *d[2], *a[2], *t1[2], *t2[2];
   double* scal;

@@ -201,7 +201,10 @@ static void bpcg1_check(const nss_bpcg1_t* s) {
   NSS_REQUIRE(s->A && s->B && s->BT, "bpcg1: NULL matrix handle");
   NSS_REQUIRE(s->A->m == s->n_u && s->BT->m == s->n_u && s->B->m == s->n_p, "bpcg1: matrix rows do not match n_u/n_p");
   NSS_REQUIRE(s->A->n == s->n_u && s->B->n == s->n_u && s->BT->n == s->n_p, "bpcg1: matrix columns do not match");
-  NSS_REQUIRE((s->pre_diag != nullptr) != (s->pre_bjac != nullptr), "bpcg1: exactly one of pre_diag / pre_bjac");
+  NSS_REQUIRE(!(s->pre_diag && s->pre_bjac), "bpcg1: pre_diag and pre_bjac are exclusive");
+  NSS_REQUIRE(s->pre_diag || s->pre_bjac || s->pre_amg, "bpcg1: no preconditioner for the velocity block");
+  NSS_REQUIRE(!s->pre_amg || s->pre_amg->levels[0].n == s->n_u, "bpcg1: AMG size mismatch");
+  NSS_REQUIRE(!(s->pre_amg && s->pre_bjac && s->pre_bjac->gs_mat), "bpcg1: AMG + Gauss-Seidel mode is not additive");
   NSS_REQUIRE(!s->pre_bjac || s->pre_bjac->n == s->n_u, "bpcg1: block-Jacobi size mismatch");
   NSS_REQUIRE(s->minv && s->scal && s->ctrl && s->hist && s->partials_a && s->partials_b && s->partials_c,
               "bpcg1: NULL work buffer");
@@ -214,8 +217,17 @@ static void bpcg1_iteration(const nss_bpcg1_t& s, int it, hipStream_t st) {
                      s.partials_a, 0, s.partials_b);
   NSS_CHECK_LAUNCH();
   launch_csr_stream(*s.A, s.d[0], EpiStore1{s.ctrl, s.t1[0]}, st);
-  launch_csr_stream(*s.BT, s.d[1], EpiV1b{s.ctrl, s.t1[0], s.t2[0], s.pre_diag, s.k}, st);
-  if (s.pre_bjac) bjac_apply(*s.pre_bjac, -s.k, s.t1[0], 0.0, s.t2[0], s.ctrl, st);
+  launch_csr_stream(*s.BT, s.d[1], EpiV1b{s.ctrl, s.t1[0], s.t2[0], s.pre_amg ? nullptr : s.pre_diag, s.k}, st);
+  if (s.pre_amg) {                                         // t2 = -k (AMG + J) t1 (t1 holds -K u here)
+    amg_apply(*s.pre_amg, -s.k, s.t1[0], s.t2[0], st);
+    if (s.pre_bjac) bjac_apply(*s.pre_bjac, -s.k, s.t1[0], 1.0, s.t2[0], s.ctrl, st);
+    if (s.pre_diag) {
+      const int rc = nss_diag_apply_f64(s.n_u, s.pre_diag, -s.k, s.t1[0], 1.0, s.t2[0], st);
+      if (rc != 0) throw Error(nss_last_error());
+    }
+  } else if (s.pre_bjac) {
+    bjac_apply(*s.pre_bjac, -s.k, s.t1[0], 0.0, s.t2[0], s.ctrl, st);
+  }
   launch_csr_stream(*s.B, s.d[0], EpiV1c{s.ctrl, s.t1[1], s.t2[1]}, st);
   launch_csr_stream(*s.A, s.t2[0], EpiV3{s.ctrl, s.t1[0], s.d[0], s.partials_a}, st);
   launch_csr_stream(*s.B, s.t2[0], EpiV3{s.ctrl, s.t1[1], s.d[1], s.partials_b}, st);

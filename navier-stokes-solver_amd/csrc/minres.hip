@@ -229,7 +229,10 @@ static void minres_check(const nss_minres_t* s) {
   NSS_REQUIRE(s->A && s->B && s->BT, "minres: NULL matrix handle");
   NSS_REQUIRE(s->A->m == s->n_u && s->BT->m == s->n_u && s->B->m == s->n_p, "minres: matrix rows do not match n_u/n_p");
   NSS_REQUIRE(s->A->n == s->n_u && s->B->n == s->n_u && s->BT->n == s->n_p, "minres: matrix columns do not match n_u/n_p");
-  NSS_REQUIRE((s->pre_diag != nullptr) != (s->pre_bjac != nullptr), "minres: exactly one of pre_diag / pre_bjac");
+  NSS_REQUIRE(!(s->pre_diag && s->pre_bjac), "minres: pre_diag and pre_bjac are exclusive");
+  NSS_REQUIRE(s->pre_diag || s->pre_bjac || s->pre_amg, "minres: no preconditioner for the velocity block");
+  NSS_REQUIRE(!s->pre_amg || s->pre_amg->levels[0].n == s->n_u, "minres: AMG size mismatch");
+  NSS_REQUIRE(!(s->pre_amg && s->pre_bjac && s->pre_bjac->gs_mat), "minres: AMG + Gauss-Seidel mode is not additive");
   NSS_REQUIRE(!s->pre_bjac || s->pre_bjac->n == s->n_u, "minres: block-Jacobi size mismatch");
   NSS_REQUIRE(s->minv && s->scal && s->ctrl && s->hist && s->partials_a && s->partials_b && s->partials_c,
               "minres: NULL work buffer");
@@ -249,12 +252,23 @@ static void minres_iteration(const nss_minres_t& s, int k, hipStream_t st) {
                      s.B->nblk, s.partials_b, s.scal, int(M_DELTA));
   NSS_CHECK_LAUNCH();
   MK4Args a4{s.ctrl, s.scal, s.n_u, s.n_p, k, s.kz[0], s.kz[1], s.v[ic][0], s.v[ic][1], s.v[io][0], s.v[io][1],
-             s.v[in][0], s.v[in][1], s.z[zn][0], s.z[zn][1], s.pre_diag, s.minv, s.partials_c};
+             s.v[in][0], s.v[in][1], s.z[zn][0], s.z[zn][1], s.pre_amg ? nullptr : s.pre_diag, s.minv, s.partials_c};
   hipLaunchKernelGGL(minres_k4_kernel, dim3(m_grid(s)), dim3(kBlock), 0, st, a4);
   NSS_CHECK_LAUNCH();
   int nb2 = 0;
-  if (s.pre_bjac) {
-    bjac_apply(*s.pre_bjac, 1.0, s.v[in][0], 0.0, s.z[zn][0], nullptr, st);
+  if (s.pre_bjac || s.pre_amg) {
+    // z_new[0] = preA v_new[0] outside the element-wise kernel; after the stop these launches only
+    // touch ring slots nobody reads any more
+    if (s.pre_amg) {
+      amg_apply(*s.pre_amg, 1.0, s.v[in][0], s.z[zn][0], st);
+      if (s.pre_bjac) bjac_apply(*s.pre_bjac, 1.0, s.v[in][0], 1.0, s.z[zn][0], nullptr, st);
+      if (s.pre_diag) {
+        const int rc = nss_diag_apply_f64(s.n_u, s.pre_diag, 1.0, s.v[in][0], 1.0, s.z[zn][0], st);
+        if (rc != 0) throw Error(nss_last_error());
+      }
+    } else {
+      bjac_apply(*s.pre_bjac, 1.0, s.v[in][0], 0.0, s.z[zn][0], nullptr, st);
+    }
     nb2 = m_dot_grid(s);
     hipLaunchKernelGGL(minres_dot_kernel, dim3(nb2), dim3(kBlock), 0, st, s.ctrl, k, s.n_u, s.z[zn][0], s.v[in][0],
                        s.partials_a);

@@ -100,6 +100,17 @@ def native_velocity_pre(op):
     return out
 
 
+def _amg_plus_jacobi(op):
+    """(amg, (1.0, diag) | None, (1.0, bjac) | None) when `op` is an unscaled AMG V-cycle, optionally
+    plus a point / block Jacobi (the additive MypreA); (None, None, None) otherwise."""
+    parts = native_velocity_pre(op)
+    if parts is None or parts["amg"] is None or parts["scale"] != 1.0:
+        return None, None, None
+    diag = (1.0, parts["diag"]) if parts["diag"] is not None else None
+    bjac = (1.0, parts["bjac"]) if parts["bjac"] is not None else None
+    return parts["amg"], diag, bjac
+
+
 def _plain(v, n):
     return isinstance(v, Vector) and v.size == n
 
@@ -224,7 +235,7 @@ class Bpcg2Loop:
 
 class MinresState(C.Structure):
     """ctypes mirror of ``nss_minres_t`` (include/nss_krylov.h)."""
-    _fields_ = ([(n, C.c_void_p) for n in ("A", "B", "BT", "pre_diag", "pre_bjac", "minv")]
+    _fields_ = ([(n, C.c_void_p) for n in ("A", "B", "BT", "pre_diag", "pre_bjac", "pre_amg", "minv")]
                 + [("u", C.c_void_p * 2), ("v", (C.c_void_p * 2) * 3), ("w", (C.c_void_p * 2) * 3),
                    ("z", (C.c_void_p * 2) * 2), ("kz", C.c_void_p * 2),
                    ("scal", C.c_void_p), ("ctrl", C.c_void_p), ("hist", C.c_void_p),
@@ -261,19 +272,23 @@ class MinresLoop:
         if (A.width, B.width, BT.height, BT.width) != (n_u, n_u, n_u, n_p):
             return None
         pa_d, pa_b, ps = native_diag(pre[0, 0]), native_bjac(pre[0, 0]), native_diag(pre[1, 1])
-        if ps is None or (pa_d is None and pa_b is None):
+        pa_amg = None
+        if pa_d is None and pa_b is None:
+            pa_amg, pa_d, pa_b = _amg_plus_jacobi(pre[0, 0])
+        if ps is None or (pa_d is None and pa_b is None and pa_amg is None):
             return None
         vecs = [u, kz] + list(v_ring) + list(w_ring) + list(z_ring)
         if len(v_ring) != 3 or len(w_ring) != 3 or len(z_ring) != 2 or not all(_block2(x, n_u, n_p) for x in vecs):
             return None
-        return cls(eng, A, B, BT, pa_d, pa_b, ps, u, v_ring, w_ring, z_ring, kz)
+        return cls(eng, A, B, BT, pa_d, pa_b, ps, u, v_ring, w_ring, z_ring, kz, pa_amg)
 
-    def __init__(self, eng, A, B, BT, pa_d, pa_b, ps, u, v_ring, w_ring, z_ring, kz):
+    def __init__(self, eng, A, B, BT, pa_d, pa_b, ps, u, v_ring, w_ring, z_ring, kz, pa_amg=None):
         torch = eng.torch
         self.eng, self.lib = eng, eng.lib
-        self.keep = [A, B, BT, pa_d, pa_b, ps, u, v_ring, w_ring, z_ring, kz]
+        self.keep = [A, B, BT, pa_d, pa_b, ps, u, v_ring, w_ring, z_ring, kz, pa_amg]
         st = MinresState()
         st.A, st.B, st.BT = A.handle.ptr, B.handle.ptr, BT.handle.ptr
+        st.pre_amg = pa_amg.handle.ptr if pa_amg is not None else None
 
         def scaled(pair):
             scale, op = pair
@@ -282,11 +297,13 @@ class MinresLoop:
         if pa_d is not None:
             self.dinv = scaled(pa_d)
             st.pre_diag, st.pre_bjac = self.dinv.data_ptr(), None
-        else:
+        elif pa_b is not None:
             scale, op = pa_b
             if scale != 1.0:
                 raise ValueError("scaled block-Jacobi is not supported by the fused MINRES loop")
             st.pre_diag, st.pre_bjac = None, op.handle.ptr
+        else:
+            st.pre_diag, st.pre_bjac = None, None
         self.minv = scaled(ps)
         st.minv = self.minv.data_ptr()
         for c in range(2):
@@ -336,7 +353,7 @@ class MinresLoop:
 
 class Bpcg1State(C.Structure):
     """ctypes mirror of ``nss_bpcg1_t`` (include/nss_krylov.h)."""
-    _fields_ = ([(n, C.c_void_p) for n in ("A", "B", "BT", "pre_diag", "pre_bjac", "minv")]
+    _fields_ = ([(n, C.c_void_p) for n in ("A", "B", "BT", "pre_diag", "pre_bjac", "pre_amg", "minv")]
                 + [(n, C.c_void_p * 2) for n in ("x", "r", "d", "a", "t1", "t2")]
                 + [("scal", C.c_void_p), ("ctrl", C.c_void_p), ("hist", C.c_void_p),
                    ("partials_a", C.c_void_p), ("partials_b", C.c_void_p), ("partials_c", C.c_void_p),
@@ -357,25 +374,32 @@ class Bpcg1Loop:
         if a_matrix.width != n_u or b_matrix.width != n_u:
             return None
         pa_d, pa_b, ps = native_diag(pre_a), native_bjac(pre_a), native_diag(pre_s)
-        if ps is None or (pa_d is None and pa_b is None):
+        pa_amg = None
+        if pa_d is None and pa_b is None:
+            pa_amg, pa_d, pa_b = _amg_plus_jacobi(pre_a)
+        if ps is None or (pa_d is None and pa_b is None and pa_amg is None):
             return None
         if any(not _block2(vecs.get(name), n_u, n_p) for name in ("x", "r", "d", "a", "t1", "t2")):
             return None
-        return cls(eng, a_matrix, b_matrix, pa_d, pa_b, ps, k, vecs)
+        return cls(eng, a_matrix, b_matrix, pa_d, pa_b, ps, k, vecs, pa_amg)
 
-    def __init__(self, eng, A, B, pa_d, pa_b, ps, k, vecs):
+    def __init__(self, eng, A, B, pa_d, pa_b, ps, k, vecs, pa_amg=None):
         torch = eng.torch
         self.eng, self.lib = eng, eng.lib
         BT = B.CreateTranspose()
-        self.keep = [A, B, BT, pa_d, pa_b, ps, vecs]
+        self.keep = [A, B, BT, pa_d, pa_b, ps, vecs, pa_amg]
         st = Bpcg1State()
         st.A, st.B, st.BT = A.handle.ptr, B.handle.ptr, BT.handle.ptr
+        st.pre_amg = pa_amg.handle.ptr if pa_amg is not None else None
+        scale = 1.0
         if pa_d is not None:
             scale, op = pa_d
             st.pre_diag, st.pre_bjac = op.d.data_ptr(), None
-        else:
+        elif pa_b is not None:
             scale, op = pa_b
             st.pre_diag, st.pre_bjac = None, op.handle.ptr
+        else:
+            st.pre_diag, st.pre_bjac = None, None
         st.k = float(k) * scale
         mscale, mop = ps
         self.minv = mop.d if mscale == 1.0 else mop.d * mscale

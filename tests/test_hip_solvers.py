@@ -629,6 +629,70 @@ def test_amg_vcycle_and_fused_bpcg_with_amg(hip_engine):
     assert results[20] < 1.5 * results[12] + 10           # iteration count nearly mesh-independent
 
 
+def test_fused_minres_and_bpcg1_with_amg(hip_engine):
+    """preA = AMG and the additive AMG + block Jacobi inside the fused MINRES and BPCG-v1 loops
+    (`pre_amg` of nss_minres_t / nss_bpcg1_t): the fused loop is selected and its history agrees
+    with the statement-by-statement protocol path on the GPU and with the numpy checker engine."""
+    import hipla
+    from hipla import fused
+    from oracle.numpy_engine import NumpyEngine
+    from bramble_pasciak_cg import bramble_pasciak_cg
+    from minres import MinRes
+    s = mac_stokes(3, 12, 0.01)
+    f, g = s.rhs(0)
+    b = np.concatenate([f, g])
+
+    def solve(kind, label, eng):
+        prev = hipla.set_engine(eng)
+        try:
+            A, B = hipla.SparseMatrix.from_scipy(s.A), hipla.SparseMatrix.from_scipy(s.B)
+            V = hipla.SmoothedAggregationAMG(A, coarse_size=300)
+            preA = V if label == "amg" else V + hipla.BlockJacobi(A, s.line_blocks(3))
+            preS = hipla.DiagonalMatrix(1.0 / s.mass)
+            fv, gv = hipla.Vector.from_numpy(f), hipla.Vector.from_numpy(g)
+            with contextlib.redirect_stdout(io.StringIO()):
+                if kind == "minres":
+                    K = hipla.BlockMatrix([[A, B.T], [B, None]])
+                    Cm = hipla.BlockMatrix([[preA, None], [None, preS]])
+                    x, errors = MinRes(mat=K, pre=Cm, rhs=hipla.BlockVector([fv, gv]), maxsteps=2000, tol=1e-9,
+                                       printrates=False)
+                else:
+                    x, errors = bramble_pasciak_cg(A, B, None, preA, preS, fv, gv, tolerance=1e-9, max_steps=2000,
+                                                   print_rates=False)
+            return np.array(errors), x.numpy()
+        finally:
+            hipla.set_engine(prev)
+
+    for kind, loop in (("minres", fused.MinresLoop), ("bpcg1", fused.Bpcg1Loop)):
+        for label in ("amg", "amg+bjac"):
+            res = {}
+            for mode in ("fused", "protocol"):
+                fused.ENABLED = mode == "fused"
+                made = []
+                orig = loop.try_create.__func__
+
+                def spy(cls, *a, _orig=orig, _made=made, **kw):
+                    out = _orig(cls, *a, **kw)
+                    _made.append(out is not None)
+                    return out
+
+                loop.try_create = classmethod(spy)
+                try:
+                    res[mode] = solve(kind, label, hip_engine)
+                finally:
+                    loop.try_create = classmethod(orig)
+                    fused.ENABLED = True
+                assert made == [mode == "fused"], (kind, label, mode, made)
+            res["numpy"] = solve(kind, label, NumpyEngine())
+            n_f, n_p, n_n = (len(res[m][0]) for m in ("fused", "protocol", "numpy"))
+            assert abs(n_f - n_n) <= max(3, int(0.03 * n_n)) and abs(n_f - n_p) <= max(3, int(0.03 * n_p))
+            w = min(25, n_f, n_n, n_p)
+            np.testing.assert_allclose(res["fused"][0][:w], res["numpy"][0][:w], rtol=1e-8)
+            np.testing.assert_allclose(res["fused"][0][:w], res["protocol"][0][:w], rtol=1e-8)
+            assert np.linalg.norm(b - s.saddle_matrix() @ res["fused"][1]) < 1e-6 * np.linalg.norm(b)
+            assert n_f < 250                                   # AMG-preconditioned: far below the Jacobi counts
+
+
 def test_time_stepping_on_gpu(hip_engine):
     """Scope row N4 on the product engine: CGSolver inner solves, Project and DoTimeStep keep the
     velocity discretely divergence-free and agree with the host computation."""
