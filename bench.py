@@ -85,6 +85,49 @@ def event_time_ms(torch, fn, reps):
     return start.elapsed_time(stop) / reps
 
 
+PROBE_OK, PROBE_FELL_BACK = 0, 7
+
+
+def rehearse_native_path(args, rank):
+    """Multi-rank runs only.  The RCCL-through-ctypes communicator and the native partitioned loop
+    cannot be exercised on the single-GPU development box (RCCL refuses two ranks on one device),
+    so before this process touches its GPU every rank starts a CHILD `bench.py` that runs the same
+    code path on a small system (own rendezvous port), with a time limit.  A child that hangs,
+    crashes or falls back makes the parent job use the torch.distributed data path instead --
+    slower, but the job still reports a number.  Returns True when the native path is proven."""
+    import subprocess
+    forced = os.environ.get("NSS_PROBE_FORCE") == "1"     # exercise the child mechanics on any backend (tests)
+    if not forced and (os.environ.get("NSS_COMM", "rccl") != "rccl"
+                       or os.environ.get("NSS_DIST_BACKEND", "nccl") != "nccl"):
+        return False
+    if os.environ.get("NSS_SKIP_REHEARSAL") == "1":
+        return True
+    env = os.environ.copy()
+    env["NSS_PROBE_CHILD"] = "1"
+    env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1 + int(os.environ.get("NSS_PROBE_PORT_OFFSET", "36")))
+    env.pop("TORCHELASTIC_USE_AGENT_STORE", None)        # the child group brings up its own store
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(args.gpus), "--grid", "48", "--steps", "6",
+           "--warmup", "2", "--cpu-iters", "0", "--pre", args.pre if args.pre in ("bjac3", "jacobi") else "bjac3"]
+    limit = float(os.environ.get("NSS_PROBE_TIMEOUT", "240"))
+    t0 = time.perf_counter()
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+    try:
+        _, err = child.communicate(timeout=limit)
+        rc = child.returncode
+    except subprocess.TimeoutExpired:
+        child.kill()
+        _, err = child.communicate()
+        rc = -9
+    ok = rc == PROBE_OK
+    if not ok:
+        tail = err.decode(errors="replace").strip().splitlines()[-6:]
+        print("rank %d: rehearsal of the native multi-GPU path failed (exit %s, %.0f s); using torch.distributed\n  %s"
+              % (rank, rc, time.perf_counter() - t0, "\n  ".join(tail)), file=sys.stderr)
+    else:
+        print("rank %d: native multi-GPU path rehearsed in %.0f s" % (rank, time.perf_counter() - t0), file=sys.stderr)
+    return ok
+
+
 def emit(fd, doc):
     """The ONE JSON line, written to the process's original stdout."""
     os.write(fd, (json.dumps(doc) + "\n").encode())
@@ -107,6 +150,10 @@ def main():
     # NSS_FORCE_DIST=1 sends a 1-rank launch through the partitioned code path (rehearsal of the
     # RCCL bootstrap / native loop on a single GPU)
     partitioned = world > 1 or os.environ.get("NSS_FORCE_DIST") == "1"
+    probe_child = os.environ.get("NSS_PROBE_CHILD") == "1"
+    native_proven = True
+    if partitioned and world > 1 and not probe_child:
+        native_proven = rehearse_native_path(args, rank)          # before this process initialises its GPU
     if partitioned:
         # NSS_DIST_BACKEND=gloo lets several ranks share one GPU for rehearsals (RCCL refuses
         # that); the driver's runs use the default: one rank per GPU over RCCL / xGMI.
@@ -117,6 +164,11 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", device))
         else:
             dist.init_process_group(backend)
+        if world > 1:                                    # every rank must take the same data path
+            agree = torch.tensor([1.0 if native_proven else 0.0], dtype=torch.float64,
+                                 device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+            native_proven = bool(agree.item() == 1.0)
     if args.gpus != world and rank == 0:
         print("note: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
 
@@ -154,7 +206,7 @@ def main():
     if partitioned:
         from distributed import DistributedBpcg2, TorchComm
         comm, comm_kind = None, "torch.distributed/" + backend
-        if backend == "nccl" and os.environ.get("NSS_COMM", "rccl") == "rccl":
+        if backend == "nccl" and os.environ.get("NSS_COMM", "rccl") == "rccl" and native_proven:
             try:                                   # RCCL straight through ctypes on the compute stream
                 from rccl_comm import RcclComm
                 comm = RcclComm(dist, eng)
@@ -174,21 +226,40 @@ def main():
             # against the same iterations over torch.distributed collectives, from the same state
             probe_its = 6
             hists = []
-            for c in (comm, torch_comm):
-                with quiet:
-                    probe = DistributedBpcg2(sysm, f, g, blocks, dist, eng, comm=c)
-                probe.start(tol=0.0, maxsteps=probe_its)
-                probe.iterate(0, probe_its)
-                torch.cuda.synchronize()
-                hists.append(probe.history(probe_its - 1))
-                del probe
-            same = bool(np.all(np.isfinite(hists[0])) and np.allclose(hists[0], hists[1], rtol=1e-9, atol=0.0))
+            try:
+                for c in (comm, torch_comm):
+                    with quiet:
+                        probe = DistributedBpcg2(sysm, f, g, blocks, dist, eng, comm=c)
+                    probe.start(tol=0.0, maxsteps=probe_its)
+                    probe.iterate(0, probe_its)
+                    torch.cuda.synchronize()
+                    hists.append(probe.history(probe_its - 1))
+                    del probe
+                same = bool(np.all(np.isfinite(hists[0])) and np.allclose(hists[0], hists[1], rtol=1e-9, atol=0.0))
+            except Exception as exc:
+                print("rank %d: native partitioned loop raised %r" % (rank, exc), file=sys.stderr)
+                same = False
             flag = torch.tensor([1.0 if same else 0.0], dtype=torch.float64, device="cuda")
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if flag.item() == 0.0:
                 print("rank %d: native partitioned loop disagrees with the torch.distributed path; "
                       "falling back" % rank, file=sys.stderr)
                 comm = None
+        if probe_child:
+            # rehearsal child: report through the exit code whether the native path held up
+            native = comm is not None
+            if native:
+                with quiet:
+                    run = DistributedBpcg2(sysm, f, g, blocks, dist, eng, comm=comm)
+                native = run.native is not None
+                run.start(tol=0.0, maxsteps=total_its)
+                run.iterate(0, total_its)
+                torch.cuda.synchronize()
+                native = native and bool(np.all(np.isfinite(run.history(total_its - 1))))
+            dist.barrier()
+            dist.destroy_process_group()
+            sys.stderr.flush()
+            os._exit(PROBE_OK if native else PROBE_FELL_BACK)
         if comm is None:
             comm, comm_kind = torch_comm, "torch.distributed/" + backend
         with quiet:
