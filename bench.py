@@ -35,8 +35,9 @@ def parse_args():
     ap.add_argument("--grid", dest="n", type=int, default=136, help="MAC grid cells per direction (136 -> 1.0e7 DoF)")
     ap.add_argument("--dim", type=int, default=3)
     ap.add_argument("--nu", type=float, default=0.01, help="1/Re")
-    ap.add_argument("--pre", default="bjac3", choices=["bjac3", "jacobi", "bgs3", "bgs3p"],
-                    help="preA: block Jacobi bs=3 (headline), point Jacobi, symmetric block Gauss-Seidel bs=3")
+    ap.add_argument("--pre", default="bjac3", choices=["bjac3", "jacobi", "bgs3", "bgs3p", "amg"],
+                    help="preA: block Jacobi bs=3 (headline), point Jacobi, symmetric block Gauss-Seidel bs=3, "
+                         "smoothed-aggregation AMG V(1,1)")
     ap.add_argument("--inflate", type=int, default=1,
                     help="HDG-like stress variant: Kronecker-inflate the operator with bs x bs blocks "
                          "(12 -> ~84 nnz per row as the reference's order-2 3-D spaces); preA = facet blocks")
@@ -304,6 +305,8 @@ def main():
     B = hipla.SparseMatrix.from_scipy(sysm.B)
     if args.pre in ("bgs3", "bgs3p"):
         preA = hipla.BlockGaussSeidel(A, blocks, colors=gs_colors)
+    elif args.pre == "amg":
+        preA = hipla.SmoothedAggregationAMG(A)
     else:
         preA = hipla.BlockJacobi(A, blocks) if blocks is not None else hipla.JacobiPreconditioner(A)
     preM = hipla.DiagonalMatrix(1.0 / sysm.mass)
@@ -354,7 +357,15 @@ def main():
     # per-iteration algorithmic bytes (DESIGN.md section "bytes per iteration")
     n_u, n_p = sysm.n_u, sysm.n_p
     mat_bytes = sum(12 * i["nnz"] + 4 * (i["rows"] + 1) for i in (a_info, b_info, bt_info))
-    pre_bytes = preA.handle.algorithmic_bytes() - 16 * n_u if blocks is not None else 8 * n_u
+    if args.pre == "amg":      # per level: two SpMVs with A_l (residual, post-smoothing), one each with P_l, R_l
+        spmv_bytes = lambda i: 12 * i["nnz"] + 4 * (i["rows"] + 1) + 8 * (i["rows"] + i["cols"])
+        pre_bytes = 0
+        for lv in preA.levels:
+            pre_bytes += spmv_bytes(lv["inv"].handle.info()) if "inv" in lv else (
+                2 * spmv_bytes(lv["A"].handle.info()) + spmv_bytes(lv["P"].handle.info())
+                + spmv_bytes(lv["R"].handle.info()) + 8 * 6 * lv["n"])
+    else:
+        pre_bytes = preA.handle.algorithmic_bytes() - 16 * n_u if blocks is not None else 8 * n_u
     if args.pre in ("bgs3", "bgs3p"):      # two sweeps, each walks the CSR rows of A once and applies the blocks once
         pre_bytes = 2 * (pre_bytes + 12 * a_info["nnz"] + 4 * n_u + 24 * n_u)
     vec_bytes = 8 * (26 * n_u + 15 * n_p)
@@ -367,8 +378,8 @@ def main():
     if args.cpu_iters != 0:
         from oracle import krylov_ref as kr
         cpu_iters = args.cpu_iters if args.cpu_iters > 0 else max(3, min(40, int(2.0e9 / max(sysm.A.nnz, 1))))
-        if args.pre in ("bgs3", "bgs3p"):
-            raise SystemExit("--pre bgs3: the oracle's sequential sweep is a Python loop; use --cpu-iters 0")
+        if args.pre in ("bgs3", "bgs3p", "amg"):
+            raise SystemExit("--pre %s: no timed CPU leg for this preconditioner; use --cpu-iters 0" % args.pre)
         pa = kr.block_jacobi(sysm.A, blocks) if blocks is not None else kr.jacobi(sysm.A)
         timing = {}
         it_c, _, _, hist_c, err0_c = kr.bpcg_v2(sysm.A, sysm.B, pa, kr.diag_inverse(sysm.mass), f, g, ses.k,
