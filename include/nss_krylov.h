@@ -204,6 +204,13 @@ typedef struct nss_bpcg2_s {
   double *partials_a, *partials_b, *partials_c; /* sizes: nss_bpcg2_workspace() */
   double k;                    /* scale factor: preA = k * preA_unscaled (:118-122) */
   int32_t n_u, n_p;
+  /* statically condensed form (`blfA.condense`, :11-18, :84-103) -- all four NULL otherwise.  A is
+   * then the explicit product (I - H^T)(S + A_ii)(I - H) and the preconditioner apply of K1 becomes
+   * harmonic_extension(): f = t0 + H^T t0;  t1 = k preA_unscaled f;  t1 += H t1;  t1 += A_ii^-1 f.
+   * The rows of H that hold entries (interior dofs) must be disjoint from its columns (coupling
+   * dofs): `t1 += H t1` runs in place. */
+  nss_csr_t cond_HT, cond_H, cond_inner;   /* harmonic_extension_trans, harmonic_extension, inner_solve */
+  double* cond_f;                          /* n_u work vector */
 } nss_bpcg2_t;
 
 enum {

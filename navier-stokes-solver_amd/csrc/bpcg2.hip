@@ -88,6 +88,42 @@ struct EpiK2 {
   }
 };
 
+// condensed form: f = t0 + H^T t0
+struct EpiLift {
+  const int32_t* __restrict__ ctrl;
+  const double* __restrict__ t0;
+  double* __restrict__ f;
+  __device__ bool skip() const { return ctrl[C_DONE] != 0; }
+  struct Pre { double t0 = 0.0; };
+  __device__ Pre fetch(int r) const { return Pre{t0[r]}; }
+  __device__ void row(int r, double ax, const Pre& p) const { f[r] = p.t0 + ax; }
+  __device__ void finish(int, double*) const {}
+};
+
+// condensed form: y += H y in place.  Only rows that receive something are written: H maps
+// coupling dofs (its columns) to interior dofs (its non-empty rows), the two sets are disjoint, so
+// no lane writes an entry another lane gathers.
+struct EpiExtendInPlace {
+  const int32_t* __restrict__ ctrl;
+  double* __restrict__ y;
+  __device__ bool skip() const { return ctrl[C_DONE] != 0; }
+  __device__ void row(int r, double ax) const {
+    if (ax != 0.0) y[r] += ax;
+  }
+  __device__ void finish(int, double*) const {}
+};
+
+// y += A x with the solver's done flag
+struct EpiAddGuarded {
+  const int32_t* __restrict__ ctrl;
+  double* __restrict__ y;
+  __device__ bool skip() const { return ctrl[C_DONE] != 0; }
+  struct Pre { double y = 0.0; };
+  __device__ Pre fetch(int r) const { return Pre{y[r]}; }
+  __device__ void row(int r, double ax, const Pre& p) const { y[r] = p.y + ax; }
+  __device__ void finish(int, double*) const {}
+};
+
 struct EpiK3 {
   const int32_t* __restrict__ ctrl;
   const double* __restrict__ s1;
@@ -242,6 +278,12 @@ void bpcg2_check_state(const nss_bpcg2_t* s) {
   NSS_REQUIRE(!s->pre_bjac || s->pre_bjac->n == s->n_u, "bpcg2: block-Jacobi size mismatch");
   NSS_REQUIRE(s->minv && s->scal && s->ctrl && s->hist && s->partials_a && s->partials_b && s->partials_c,
               "bpcg2: NULL work buffer");
+  const bool cond = s->cond_HT || s->cond_H || s->cond_inner || s->cond_f;
+  if (cond) {
+    NSS_REQUIRE(s->cond_HT && s->cond_H && s->cond_inner && s->cond_f, "bpcg2: condensed form needs H^T, H, A_ii^-1 and a work vector");
+    for (const nss_csr_s* m : {s->cond_HT, s->cond_H, s->cond_inner})
+      NSS_REQUIRE(m->m == s->n_u && m->n == s->n_u, "bpcg2: condensed operators must be n_u x n_u");
+  }
   NSS_REQUIRE(s->u0 && s->u1 && s->d0 && s->d1 && s->w0 && s->w1 && s->s0 && s->s1 && s->z0 && s->q && s->t0 &&
                   s->t1 && s->t2 && s->t3 && s->t4,
               "bpcg2: NULL vector");
@@ -253,8 +295,8 @@ void bpcg2_spmv_phase(const nss_bpcg2_t& s, int which, int it, hipStream_t st, i
   switch (which) {
     case NSS_BPCG2_K1: {
       // the point-Jacobi apply rides in the epilogue unless an AMG term comes first
-      EpiK1 e{s.ctrl, s.scal, s.q, s.z0, s.t2, s.s0, s.w0, s.t0, s.t1, s.pre_amg ? nullptr : s.pre_diag, s.k,
-              it == 0 ? 1 : 0};
+      EpiK1 e{s.ctrl, s.scal, s.q, s.z0, s.t2, s.s0, s.w0, s.t0, s.t1,
+              (s.pre_amg || s.cond_HT) ? nullptr : s.pre_diag, s.k, it == 0 ? 1 : 0};
       launch_csr_stream(*s.BT, s.s1, e, st, b0, b1);
       break;
     }
@@ -276,16 +318,28 @@ void bpcg2_spmv_phase(const nss_bpcg2_t& s, int which, int it, hipStream_t st, i
 // t1 = k * preA_unscaled t0 for everything that is not fused into K1's epilogue:
 // [AMG V-cycle] + [block Jacobi / block Gauss-Seidel | point Jacobi]  (additive MypreA, :383)
 void bpcg2_k1_finish(const nss_bpcg2_t& s, hipStream_t st) {
-  if (s.pre_amg) {
-    amg_apply(*s.pre_amg, s.k, s.t0, s.t1, st);
-    if (s.pre_bjac) bjac_apply(*s.pre_bjac, s.k, s.t0, 1.0, s.t1, s.ctrl, st);
-    if (s.pre_diag) {
-      const int rc = nss_diag_apply_f64(s.n_u, s.pre_diag, s.k, s.t0, 1.0, s.t1, st);
-      if (rc != 0) throw Error(nss_last_error());
-    }
-    return;
+  const double* src = s.t0;
+  if (s.cond_HT) {                                   // harmonic_extension(): lift the residual first
+    launch_csr_stream(*s.cond_HT, s.t0, EpiLift{s.ctrl, s.t0, s.cond_f}, st);
+    src = s.cond_f;
   }
-  if (s.pre_bjac) bjac_apply_guarded(*s.pre_bjac, s.k, s.t0, s.t1, s.ctrl, st);
+  auto diag = [&](double beta) {
+    const int rc = nss_diag_apply_f64(s.n_u, s.pre_diag, s.k, src, beta, s.t1, st);
+    if (rc != 0) throw Error(nss_last_error());
+  };
+  if (s.pre_amg) {
+    amg_apply(*s.pre_amg, s.k, src, s.t1, st);
+    if (s.pre_bjac) bjac_apply(*s.pre_bjac, s.k, src, 1.0, s.t1, s.ctrl, st);
+    if (s.pre_diag) diag(1.0);
+  } else if (s.pre_bjac) {
+    bjac_apply_guarded(*s.pre_bjac, s.k, src, s.t1, s.ctrl, st);
+  } else if (s.cond_HT) {
+    diag(0.0);                                       // uncondensed: rides in K1's epilogue
+  }
+  if (s.cond_HT) {
+    launch_csr_stream(*s.cond_H, s.t1, EpiExtendInPlace{s.ctrl, s.t1}, st);         // t1 += H t1
+    launch_csr_stream(*s.cond_inner, s.cond_f, EpiAddGuarded{s.ctrl, s.t1}, st);    // t1 += A_ii^-1 f
+  }
 }
 
 void bpcg2_phase(const nss_bpcg2_t& s, int which, int it, hipStream_t st) {

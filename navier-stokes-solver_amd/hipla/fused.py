@@ -31,7 +31,8 @@ class Bpcg2State(C.Structure):
                                              "t0", "t1", "t2", "t3", "t4")]
                 + [("scal", C.c_void_p), ("ctrl", C.c_void_p), ("hist", C.c_void_p),
                    ("partials_a", C.c_void_p), ("partials_b", C.c_void_p), ("partials_c", C.c_void_p),
-                   ("k", C.c_double), ("n_u", C.c_int32), ("n_p", C.c_int32)])
+                   ("k", C.c_double), ("n_u", C.c_int32), ("n_p", C.c_int32)]
+                + [(n, C.c_void_p) for n in ("cond_HT", "cond_H", "cond_inner", "cond_f")])
 
 
 class HaloStruct(C.Structure):
@@ -111,6 +112,14 @@ def _amg_plus_jacobi(op):
     return parts["amg"], diag, bjac
 
 
+def _extension_is_in_place_safe(H):
+    """`t1 += H t1` runs in place on the device: the rows of H that hold entries (interior dofs) must
+    not appear among its columns (coupling dofs)."""
+    rowptr, col, _ = H.host_csr()
+    rows_with_entries = np.nonzero(np.diff(rowptr))[0]
+    return not np.intersect1d(rows_with_entries, np.unique(col), assume_unique=True).size
+
+
 def _plain(v, n):
     return isinstance(v, Vector) and v.size == n
 
@@ -119,10 +128,11 @@ class Bpcg2Loop:
     """Device-resident iteration of solvers/bramblepasciak_new.py:200-249."""
 
     @classmethod
-    def try_create(cls, matA, matB, matBT, preA_unscaled, k, preM, vecs, distributed=False):
+    def try_create(cls, matA, matB, matBT, preA_unscaled, k, preM, vecs, distributed=False, condensed=None):
         """`distributed`: the matrices are the local row blocks of a partitioned run -- their
         column spaces carry halo entries behind the owned ones and t1 / t4 / s1 are the owned
-        views of halo-extended buffers (same base pointer)."""
+        views of halo-extended buffers (same base pointer).  `condensed`: dict(HT, H, inner) of
+        `SparseMatrix` for a statically condensed form (matA is then the explicit product)."""
         if not (isinstance(matA, SparseMatrix) and isinstance(matB, SparseMatrix) and isinstance(matBT, SparseMatrix)):
             return None
         eng = matA.engine
@@ -143,13 +153,23 @@ class Bpcg2Loop:
                  "t2": n_u, "t4": n_u, "u1": n_p, "d1": n_p, "w1": n_p, "s1": n_p, "t3": n_p}
         if any(not _plain(vecs.get(name), n) for name, n in sizes.items()):
             return None
-        return cls(eng, matA, matB, matBT, pa, k, pm, vecs)
+        if condensed is not None:
+            if distributed or any(not isinstance(condensed.get(key), SparseMatrix) or condensed[key].height != n_u
+                                  or condensed[key].width != n_u for key in ("HT", "H", "inner")):
+                return None
+            if not _extension_is_in_place_safe(condensed["H"]):
+                return None
+        return cls(eng, matA, matB, matBT, pa, k, pm, vecs, condensed)
 
-    def __init__(self, eng, matA, matB, matBT, pa, k, pm, vecs):
+    def __init__(self, eng, matA, matB, matBT, pa, k, pm, vecs, condensed=None):
         torch = eng.torch
         self.eng, self.lib = eng, eng.lib
-        self.keep = [matA, matB, matBT, vecs, pa, pm]       # keep device memory alive
+        self.keep = [matA, matB, matBT, vecs, pa, pm, condensed]       # keep device memory alive
         st = Bpcg2State()
+        if condensed is not None:
+            self.cond_f = eng.zeros(matA.height)
+            st.cond_HT, st.cond_H = condensed["HT"].handle.ptr, condensed["H"].handle.ptr
+            st.cond_inner, st.cond_f = condensed["inner"].handle.ptr, self.cond_f.data_ptr()
         st.A, st.B, st.BT = matA.handle.ptr, matB.handle.ptr, matBT.handle.ptr
         st.pre_diag = pa["diag"].d.data_ptr() if pa["diag"] is not None else None
         st.pre_bjac = pa["bjac"].handle.ptr if pa["bjac"] is not None else None

@@ -64,6 +64,29 @@ class _CondensedA(BaseMatrix):
     CreateVector = CreateColVector
 
 
+def _explicit_condensed_matrix(blfA):
+    """``(I - H^T)(S + A_ii)(I - H)`` as one CSR matrix (two sparse products on the device,
+    ``nss_csr_spgemm``), so that the fused loop multiplies with it in a single SpMV instead of the
+    five operator applies of ``myAmatrix`` (:84-103).  None when the operands are not native."""
+    import scipy.sparse as sp
+    from hipla.matrix import SparseMatrix
+    parts = [getattr(blfA, name, None) for name in ("mat", "inner_matrix", "harmonic_extension",
+                                                    "harmonic_extension_trans", "inner_solve")]
+    if not all(isinstance(m, SparseMatrix) for m in parts):
+        return None
+    S, Aii, H, HT, _ = parts
+    eng = S.engine
+    if not hasattr(eng, "csr_spgemm") or len({m.height for m in parts} | {m.width for m in parts}) != 1:
+        return None
+    n = S.height
+    eye = sp.identity(n, format="csr")
+    left = SparseMatrix.from_scipy((eye - HT.to_scipy()).tocsr(), engine=eng)
+    mid = SparseMatrix.from_scipy((S.to_scipy() + Aii.to_scipy()).tocsr(), engine=eng)
+    right = SparseMatrix.from_scipy((eye - H.to_scipy()).tocsr(), engine=eng)
+    inner = eng.csr_spgemm(left.handle, mid.handle)
+    return SparseMatrix.from_handle(eng.csr_spgemm(inner, right.handle), eng)
+
+
 class BpcgSession:
     """Everything the reference computes before its loop (solvers/bramblepasciak_new.py:105-198):
     scale factor, transformed right-hand side, initial defect ``d``, preconditioned residual
@@ -143,11 +166,17 @@ class BpcgSession:
 
         self.matBT = matB.CreateTranspose()              # explicit B^T CSR (:198), cached on the matrix
         self.fused = None
-        if not blfA.condense and matC is None:
-            self.fused = Bpcg2Loop.try_create(
-                matA, matB, self.matBT, preA_unscaled, k, preM,
-                dict(u0=u[0], u1=u[1], d0=d[0], d1=d[1], w0=w[0], w1=w[1], s0=s[0], s1=s[1], z0=z[0],
-                     q=self.As0, t0=t0, t1=t1, t2=t2, t3=t3, t4=t4))
+        vecs = dict(u0=u[0], u1=u[1], d0=d[0], d1=d[1], w0=w[0], w1=w[1], s0=s[0], s1=s[1], z0=z[0],
+                    q=self.As0, t0=t0, t1=t1, t2=t2, t3=t3, t4=t4)
+        if matC is None and not blfA.condense:
+            self.fused = Bpcg2Loop.try_create(matA, matB, self.matBT, preA_unscaled, k, preM, vecs)
+        elif matC is None:
+            explicit = _explicit_condensed_matrix(blfA)
+            if explicit is not None:
+                self.fused = Bpcg2Loop.try_create(
+                    explicit, matB, self.matBT, preA_unscaled, k, preM, vecs,
+                    condensed=dict(HT=blfA.harmonic_extension_trans, H=blfA.harmonic_extension,
+                                   inner=blfA.inner_solve))
 
     def first_direction(self):
         """A s0 and z0 of iteration 0 (:202-203); the fused loop starts from these."""

@@ -532,30 +532,74 @@ def test_fused_loops_with_block_gauss_seidel_preconditioner(hip_engine):
 
 
 def test_static_condensation_path_on_gpu(hip_engine):
-    """Scope row N2 on the product engine: `blfA.condense = True` drives harmonic_extension's
-    condensed branch and the composite operator (I - H^T)(S + A_ii)(I - H) through the protocol
-    (SpMV / lincomb kernels), and the solve agrees with the uncondensed fused loop."""
+    """Scope row N2 on the product engine: `blfA.condense = True`.  The fused loop multiplies with
+    the explicit product (I - H^T)(S + A_ii)(I - H) (device SpGEMM) and applies
+    harmonic_extension() as its preconditioner step; the statement-by-statement protocol path
+    (composite operator, as the reference evaluates it) and the numpy checker engine give the same
+    history, and the solve agrees with the uncondensed one."""
     import hipla
+    from hipla import fused
+    from oracle.numpy_engine import NumpyEngine
     from discretizations import AssembledForm, CondensedForm
-    from solvers.bramblepasciak_new import BramblePasciakCG
+    from solvers.bramblepasciak_new import BpcgSession, BramblePasciakCG
     s = mac_stokes(3, 8, 0.01)
-    blfA, blfB = CondensedForm(s), AssembledForm(hipla.SparseMatrix.from_scipy(s.B))
     f, g = s.rhs(0)
-    preM = hipla.DiagonalMatrix(1.0 / s.mass)
-    sol = hipla.BlockVector([hipla.Vector(s.n_u), hipla.Vector(s.n_p)])
-    with contextlib.redirect_stdout(io.StringIO()):
-        it, _ = BramblePasciakCG(blfA, blfB, None, hipla.Vector.from_numpy(f), hipla.Vector.from_numpy(g),
-                                 blfA.jacobi(), preM, sol, tol=1e-9, maxsteps=5000)
+    b = np.concatenate([f, g])
+
+    def run(eng, pre_kind):
+        prev = hipla.set_engine(eng)
+        try:
+            blfA, blfB = CondensedForm(s), AssembledForm(hipla.SparseMatrix.from_scipy(s.B))
+            preM = hipla.DiagonalMatrix(1.0 / s.mass)
+            if pre_kind == "jacobi":
+                preA = blfA.jacobi()
+            else:                                                # blocks of coupling dofs only (S is zero elsewhere)
+                idx = s.line_blocks(3).copy()
+                idx[(idx >= 0) & blfA.interior[np.maximum(idx, 0)]] = -1
+                idx = -np.sort(-idx, axis=0)                     # padding last
+                preA = hipla.BlockJacobi(blfA.mat, np.ascontiguousarray(idx[:, (idx >= 0).any(axis=0)]))
+            if eng is hip_engine and fused.ENABLED:
+                with contextlib.redirect_stdout(io.StringIO()):
+                    ses = BpcgSession(blfA, blfB, None, hipla.Vector.from_numpy(f), hipla.Vector.from_numpy(g), preA,
+                                      preM)
+                assert ses.fused is not None                     # condensed form takes the device-resident loop
+                expl = ses.fused.keep[0].to_scipy()
+                assert abs(expl - s.A).max() <= 1e-12 * abs(s.A).max()
+            sol = hipla.BlockVector([hipla.Vector(s.n_u), hipla.Vector(s.n_p)])
+            out = io.StringIO()
+            with contextlib.redirect_stdout(out):
+                it, _ = BramblePasciakCG(blfA, blfB, None, hipla.Vector.from_numpy(f), hipla.Vector.from_numpy(g),
+                                         preA, preM, sol, tol=1e-9, maxsteps=5000)
+            hist = np.array([float(m) for m in re.findall(r"it =\s+\d+\s+err =\s+(\S+)", out.getvalue())])
+            return it, hist, sol.numpy()
+        finally:
+            hipla.set_engine(prev)
+
+    for pre_kind in ("jacobi", "bjac"):
+        res = {"fused": run(hip_engine, pre_kind)}
+        fused.ENABLED = False
+        try:
+            res["protocol"] = run(hip_engine, pre_kind)
+        finally:
+            fused.ENABLED = True
+        res["numpy"] = run(NumpyEngine(), pre_kind)
+        it_f, hist_f, x = res["fused"]
+        for other in ("protocol", "numpy"):
+            it_o, hist_o, x_o = res[other]
+            w = min(30, len(hist_f), len(hist_o))
+            np.testing.assert_allclose(hist_f[:w], hist_o[:w], rtol=1e-8)
+            assert abs(it_f - it_o) <= max(3, int(0.03 * it_o))
+            assert np.linalg.norm(x - x_o) < 1e-5 * np.linalg.norm(x_o)
+        assert np.linalg.norm(b - s.saddle_matrix() @ x) < 1e-5 * np.linalg.norm(b)
+        assert 5 < it_f < 5000
     A = hipla.SparseMatrix.from_scipy(s.A)
     ref = hipla.BlockVector([hipla.Vector(s.n_u), hipla.Vector(s.n_p)])
     with contextlib.redirect_stdout(io.StringIO()):
-        BramblePasciakCG(AssembledForm(A), blfB, None, hipla.Vector.from_numpy(f), hipla.Vector.from_numpy(g),
-                         hipla.JacobiPreconditioner(A), preM, ref, tol=1e-9, maxsteps=5000)
-    x, xr = sol.numpy(), ref.numpy()
-    b = np.concatenate([f, g])
-    assert np.linalg.norm(b - s.saddle_matrix() @ x) < 1e-5 * np.linalg.norm(b)
+        BramblePasciakCG(AssembledForm(A), AssembledForm(hipla.SparseMatrix.from_scipy(s.B)), None,
+                         hipla.Vector.from_numpy(f), hipla.Vector.from_numpy(g), hipla.JacobiPreconditioner(A),
+                         hipla.DiagonalMatrix(1.0 / s.mass), ref, tol=1e-9, maxsteps=5000)
+    xr = ref.numpy()
     assert np.linalg.norm(x[:s.n_u] - xr[:s.n_u]) < 1e-5 * np.linalg.norm(xr[:s.n_u])
-    assert 5 < it < 5000
 
 
 def test_heat_config1_driver(hip_engine):

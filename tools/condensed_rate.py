@@ -1,0 +1,61 @@
+"""Iteration rate of the statically condensed BPCG path (scope row N2; fused and statement by
+statement) next to the fused uncondensed loop:  python tools/condensed_rate.py [grid]"""
+import contextlib
+import io
+import os
+import re
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "navier-stokes-solver_amd"))
+
+import numpy as np
+
+import hipla
+from discretizations import CondensedForm
+from solvers.bramblepasciak_new import BramblePasciakCG
+from staggered_grid import mac_stokes
+
+
+class Form:
+    def __init__(self, mat):
+        self.mat, self.condense = mat, False
+
+
+def main():
+    grid = int(sys.argv[1]) if len(sys.argv) > 1 else 96
+    s = mac_stokes(3, grid, 0.01)
+    f, g = s.rhs(0)
+    eng = hipla.get_engine()
+    B = hipla.SparseMatrix.from_scipy(s.B)
+    preS = hipla.DiagonalMatrix(1.0 / s.mass)
+    rows = []
+    from hipla import fused
+    for label in ("uncondensed, fused loop", "condensed, fused loop (explicit product + harmonic_extension step)",
+                  "condensed, protocol statements"):
+        fused.ENABLED = not label.endswith("statements")
+        if label.startswith("uncondensed"):
+            A = hipla.SparseMatrix.from_scipy(s.A)
+            blfA, preA = Form(A), hipla.JacobiPreconditioner(A)
+        else:
+            blfA = CondensedForm(s)
+            preA = blfA.jacobi()
+        sol = hipla.BlockVector([hipla.Vector(s.n_u), hipla.Vector(s.n_p)])
+        out = io.StringIO()
+        eng.synchronize()
+        with contextlib.redirect_stdout(out):
+            it, seconds = BramblePasciakCG(blfA, Form(B), None, hipla.Vector.from_numpy(f), hipla.Vector.from_numpy(g),
+                                           preA, preS, sol, tol=1e-6, maxsteps=400)
+        eng.synchronize()
+        x = sol.numpy()
+        res = np.linalg.norm(np.concatenate([f, g]) - s.saddle_matrix() @ x) / np.linalg.norm(np.concatenate([f, g]))
+        rows.append((label, it, seconds, 1e3 * seconds / max(it, 1), res))
+    print("3-D MAC Stokes n=%d, %d DoF, BPCG v2, point Jacobi, 400 iterations max" % (grid, s.ndof))
+    print("| path | iterations | loop s | ms / iteration | true residual |\n|---|---|---|---|---|")
+    for r in rows:
+        print("| %s | %d | %.3f | %.3f | %.1e |" % r)
+
+
+if __name__ == "__main__":
+    main()
