@@ -1,5 +1,6 @@
-import sys, time, io, contextlib
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/navier-stokes-solver_amd")
+import os, sys, time, io, contextlib
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "navier-stokes-solver_amd"))
 import numpy as np, torch, hipla
 from templates.NavierStokesSIMPLE_iterative import NavierStokes, SyntheticMesh
 for dim, h, order in ((3, 1/40, 1), (2, 1/128, 2)):
