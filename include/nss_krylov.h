@@ -255,13 +255,15 @@ typedef struct nss_halo_s {
   double* sendbuf;             /* DEVICE double[n_pack]                                          */
   double* ext;                 /* DEVICE operand buffer [owned | ghosts]                         */
   const int32_t* h_send_peer;  /* HOST  int32[n_send]                                            */
-  const int64_t* h_send_off;   /* HOST  int64[n_send]: offsets into sendbuf                      */
+  const int64_t* h_send_off;   /* HOST  int64[n_send]: offsets into sendbuf (direct: into ext)   */
   const int64_t* h_send_cnt;   /* HOST  int64[n_send]                                            */
   const int32_t* h_recv_peer;  /* HOST  int32[n_recv]                                            */
   const int64_t* h_recv_off;   /* HOST  int64[n_recv]: offsets into ext (>= n_owned)             */
   const int64_t* h_recv_cnt;   /* HOST  int64[n_recv]                                            */
   int32_t n_pack, n_send, n_recv;
   int32_t int_begin, int_end;  /* interior row blocks of the consuming matrix                   */
+  int32_t direct;              /* 1: every destination gets one contiguous run of the owned entries,
+                                  sent straight out of ext (n_pack = 0, no pack kernel)          */
 } nss_halo_t;
 
 typedef struct nss_dist_s* nss_dist_t;

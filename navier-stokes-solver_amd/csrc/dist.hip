@@ -53,6 +53,16 @@ static void check_halo(const nss_halo_t* h, const nss_csr_s& mat, const char* na
   NSS_REQUIRE(h->ext != nullptr, std::string(name) + ": NULL operand buffer");
   NSS_REQUIRE(h->n_pack >= 0 && h->n_send >= 0 && h->n_recv >= 0, std::string(name) + ": negative count");
   NSS_REQUIRE(h->n_pack == 0 || (h->send_idx && h->sendbuf), std::string(name) + ": NULL pack buffers");
+  if (h->direct) {   // segments are sent straight out of the operand: no pack, offsets into ext
+    NSS_REQUIRE(h->n_pack == 0, std::string(name) + ": direct sends take no pack list");
+    for (int i = 0; i < h->n_send; ++i)
+      NSS_REQUIRE(h->h_send_cnt[i] > 0 && h->h_send_off[i] >= 0 && h->h_send_off[i] + h->h_send_cnt[i] <= mat.n,
+                  std::string(name) + ": send segment outside the operand");
+    for (int i = 0; i < h->n_recv; ++i)
+      NSS_REQUIRE(h->h_recv_cnt[i] > 0 && h->h_recv_off[i] + h->h_recv_cnt[i] <= mat.n,
+                  std::string(name) + ": receive segment outside the operand");
+    return;
+  }
   NSS_REQUIRE(h->int_begin >= 0 && h->int_begin <= h->int_end && h->int_end <= mat.nblk,
               std::string(name) + ": interior row-block range out of bounds");
   int64_t packed = 0;
@@ -69,10 +79,11 @@ static void check_halo(const nss_halo_t* h, const nss_csr_s& mat, const char* na
 // pack + grouped send/recv of one operand on stream `st`
 static void exchange(const nss_dist_s& d, const nss_halo_t& h, hipStream_t st) {
   if (h.n_send == 0 && h.n_recv == 0) return;
-  gather_launch(h.n_pack, h.send_idx, h.ext, h.sendbuf, st);
+  const double* src = h.direct ? h.ext : h.sendbuf;
+  if (!h.direct) gather_launch(h.n_pack, h.send_idx, h.ext, h.sendbuf, st);
   nccl_check(d, d.GroupStart(), "ncclGroupStart");
   for (int i = 0; i < h.n_send; ++i)
-    nccl_check(d, d.Send(h.sendbuf + h.h_send_off[i], size_t(h.h_send_cnt[i]), kNcclFloat64, h.h_send_peer[i], d.comm, st),
+    nccl_check(d, d.Send(src + h.h_send_off[i], size_t(h.h_send_cnt[i]), kNcclFloat64, h.h_send_peer[i], d.comm, st),
                "ncclSend");
   for (int i = 0; i < h.n_recv; ++i)
     nccl_check(d, d.Recv(h.ext + h.h_recv_off[i], size_t(h.h_recv_cnt[i]), kNcclFloat64, h.h_recv_peer[i], d.comm, st),
@@ -85,13 +96,20 @@ static void spmv_with_halo(const nss_bpcg2_t& s, const nss_dist_s& d, const nss_
                            int it, const nss_csr_s& mat, int overlap_mode, hipStream_t cs) {
   const bool talks = d.nranks > 1 && (h.n_send > 0 || h.n_recv > 0);
   const bool overlap = overlap_mode != 0;
-  if (!talks && overlap_mode != 2) {   // mode 2: keep the split / stream / event path (tests)
+  if (!talks && overlap_mode < 2) {   // modes 2, 3: keep the split path without peers (tests, measurements)
     bpcg2_spmv_phase(s, which, it, cs, 0, -1);
     return;
   }
   if (!overlap) {
     exchange(d, h, cs);
     bpcg2_spmv_phase(s, which, it, cs, 0, -1);
+    return;
+  }
+  if (overlap_mode == 3) {             // measurement only: the split launches without the second stream
+    exchange(d, h, cs);
+    bpcg2_spmv_phase(s, which, it, cs, h.int_begin, h.int_end);
+    bpcg2_spmv_phase(s, which, it, cs, 0, h.int_begin);
+    bpcg2_spmv_phase(s, which, it, cs, h.int_end, mat.nblk);
     return;
   }
   NSS_HIP(hipEventRecord(d.ev_ready[slot], cs));

@@ -19,6 +19,8 @@ The reference is single-process (no MPI / NCCL anywhere); t
 is new.  Everything here is host logic over the engine interface, so the same code runs
 on the numpy checker engine in the gloo tests."""
 
+import os
+
 import numpy as np
 import scipy.sparse as sp
 
@@ -45,12 +47,30 @@ def localize_rows(mat, row_range, col_offsets, rank):
     cols = loc.indices.astype(np.int64)
     owned = (cols >= c0) & (cols < c1)
     ghosts = np.unique(cols[~owned])            # global ids ascending == sorted by owner, then id
+    ghosts = densify_ghosts(ghosts, col_offsets)
     new = np.empty_like(cols)
     new[owned] = cols[owned] - c0
     new[~owned] = (c1 - c0) + np.searchsorted(ghosts, cols[~owned])
     out = sp.csr_matrix((loc.data, new.astype(np.int32), loc.indptr), shape=(r1 - r0, (c1 - c0) + ghosts.size))
     out.sort_indices()
     return out, ghosts
+
+
+def densify_ghosts(ghosts, col_offsets, max_waste=2.0):
+    """Per owner, replace the set of wanted ids by the contiguous range that covers it when that
+    range is at most `max_waste` times larger (slab neighbours want most of one or two grid planes):
+    the owner can then send straight out of its vector -- no pack kernel -- and the ghost tail is
+    still sorted by (owner, id).  The extra entries are received and never referenced."""
+    ghosts = np.asarray(ghosts, dtype=np.int64)
+    if ghosts.size == 0:
+        return ghosts
+    owner = np.searchsorted(np.asarray(col_offsets, dtype=np.int64), ghosts, side="right") - 1
+    out = []
+    for q in np.unique(owner):
+        ids = ghosts[owner == q]
+        span = int(ids[-1] - ids[0] + 1)
+        out.append(np.arange(ids[0], ids[-1] + 1, dtype=np.int64) if span <= max_waste * ids.size else ids)
+    return np.concatenate(out)
 
 
 class HaloPlan:
@@ -65,6 +85,8 @@ class HaloPlan:
         self.recv_counts = np.bincount(owner, minlength=nranks).astype(np.int64)
         self.send_counts = np.zeros(nranks, dtype=np.int64)
         self.send_idx = np.zeros(0, dtype=np.int32)
+        self.send_runs = {}          # destination -> first local index, when its entries are one contiguous run
+        self.direct = False          # every destination is served by one contiguous run of the owned entries
 
     def requests(self):
         """ghost ids wanted from each owner (what travels in the set-up all-gather)."""
@@ -82,7 +104,10 @@ class HaloPlan:
                 raise ValueError("rank %d asked rank %d for entries it does not own" % (q, self.rank))
             self.send_counts[q] = ids.size
             idx.append((ids - c0).astype(np.int32))
+            if ids.size and int(ids[-1] - ids[0]) + 1 == ids.size and np.all(np.diff(ids) == 1):
+                self.send_runs[q] = int(ids[0] - c0)
         self.send_idx = np.concatenate(idx) if idx else np.zeros(0, dtype=np.int32)
+        self.direct = all(q in self.send_runs for q in range(self.nranks) if self.send_counts[q])
         return self
 
 
@@ -252,10 +277,11 @@ class DistSparseMatrix(BaseMatrix):
         plan = self.plan
         h = HaloStruct()
         keep = {}
+        direct = bool(plan.direct) and bool(plan.send_idx.size)
         sp, so, sc, off = [], [], [], 0
         for q, c in enumerate(plan.send_counts):
-            if c:
-                sp.append(q), so.append(off), sc.append(int(c))
+            if c:                     # direct: offset into the operand itself; else into the packed send buffer
+                sp.append(q), so.append(plan.send_runs[q] if direct else off), sc.append(int(c))
             off += int(c)
         rp, ro, rc, off = [], [], [], plan.n_owned
         for q, c in enumerate(plan.recv_counts):
@@ -266,7 +292,8 @@ class DistSparseMatrix(BaseMatrix):
                                ("h_recv_peer", rp, np.int32), ("h_recv_off", ro, np.int64), ("h_recv_cnt", rc, np.int64)):
             arr = keep[name] = np.ascontiguousarray(vals, dtype=dt)
             setattr(h, name, arr.ctypes.data if arr.size else None)
-        h.n_pack, h.n_send, h.n_recv = int(plan.send_idx.size), len(sp), len(rp)
+        h.n_pack, h.n_send, h.n_recv = (0 if direct else int(plan.send_idx.size)), len(sp), len(rp)
+        h.direct = 1 if direct else 0
         h.send_idx = self._send_idx.data_ptr() if plan.send_idx.size else None
         h.sendbuf = self._sendbuf.data_ptr() if plan.send_idx.size else None
         h.ext = hv.ext.data_ptr()
@@ -434,7 +461,11 @@ class DistributedBpcg2:
             raise RuntimeError("fused distributed BPCG loop needs the HIP engine and native operands")
         self.halo = {"s1": (ops.BT, self.s1), "t1": (ops.A, self.t1), "t4": (ops.B, self.t4)}
         self.native = None
-        self.overlap = True
+        # 0: exchange, then one launch per SpMV, all on the compute stream.  1: exchange on a second
+        # stream while the interior row blocks are multiplied.  Measured on one GPU at 1/8 of the
+        # headline size (tools/partition_overhead.py): the split launches + cross-stream events of
+        # mode 1 cost 98 us per iteration -- more than the three small exchanges they hide.
+        self.overlap = int(os.environ.get("NSS_OVERLAP", "0"))
         comm_handle = getattr(self.comm, "comm", None)         # RcclComm: an ncclComm_t
         if comm_handle is not None and hasattr(self.loop.lib, "nss_bpcg2_iterate_dist"):
             self.enable_native(comm_handle)

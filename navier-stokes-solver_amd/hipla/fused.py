@@ -41,7 +41,7 @@ class HaloStruct(C.Structure):
                 ("h_send_peer", C.c_void_p), ("h_send_off", C.c_void_p), ("h_send_cnt", C.c_void_p),
                 ("h_recv_peer", C.c_void_p), ("h_recv_off", C.c_void_p), ("h_recv_cnt", C.c_void_p),
                 ("n_pack", C.c_int32), ("n_send", C.c_int32), ("n_recv", C.c_int32),
-                ("int_begin", C.c_int32), ("int_end", C.c_int32)]
+                ("int_begin", C.c_int32), ("int_end", C.c_int32), ("direct", C.c_int32)]
 
 
 PHASE = {"K1": 1, "K2": 2, "K3": 3, "SUM1": 4, "ALPHA": 5, "K4": 6, "SUM2": 7, "BETA": 8, "K5": 9}

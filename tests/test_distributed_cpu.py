@@ -128,3 +128,44 @@ def test_halo_plan_bookkeeping():
         ext = np.concatenate([x[vel[r]:vel[r + 1]], x[ghosts]])
         np.testing.assert_allclose(loc @ ext, (s.A @ x)[vel[r]:vel[r + 1]], rtol=1e-14, atol=1e-14)
     assert list(even_offsets(10, 3)) == [0, 3, 7, 10]
+
+
+def test_halo_plans_of_slab_partitions_send_contiguous_runs(numpy_engine):
+    """Slab neighbours want (most of) one or two grid planes: after `densify_ghosts` every
+    destination is served by ONE contiguous run of the owned entries, so the native loop sends
+    straight out of the operand (nss_halo_t.direct) and needs no pack kernel.  Checked for every
+    rank of 2-, 3- and 8-way partitions without communication."""
+    from distributed import DistSparseMatrix, densify_ghosts
+    from staggered_grid import mac_stokes
+    s = mac_stokes(3, 16, 0.01)
+    for nranks in (2, 3, 8):
+        vel, prs = s.partition(nranks)
+        for rank in range(nranks):
+            class FakeComm:
+                size = nranks
+
+                def gather_requests(self, mine, compute):
+                    return [compute(q) for q in range(nranks)]
+
+            FakeComm.rank = rank
+            for mat, rows, cols in ((s.A, vel, vel), (s.B, prs, vel), (s.B.T.tocsr(), vel, prs)):
+                dm = DistSparseMatrix(mat, rows, cols, FakeComm(), numpy_engine)
+                plan = dm.plan
+                assert plan.direct
+                ext = np.arange(plan.n_owned + plan.n_ghost, dtype=np.float64)
+                at = 0
+                for q in range(nranks):
+                    c = int(plan.send_counts[q])
+                    if c:
+                        run = plan.send_runs[q]
+                        assert 0 <= run and run + c <= plan.n_owned
+                        np.testing.assert_array_equal(ext[run:run + c], ext[plan.send_idx[at:at + c]])
+                    at += c
+                # the ghost tail is still sorted by (owner, id) and covers what the rows reference
+                assert np.all(np.diff(plan.ghosts) > 0)
+                assert dm.local_scipy.indices.max() < plan.n_owned + plan.n_ghost
+    # a scattered request stays a list (no densification beyond 2x)
+    g = densify_ghosts(np.array([100, 150, 199]), np.array([0, 100, 200]))
+    np.testing.assert_array_equal(g, [100, 150, 199])
+    g = densify_ghosts(np.array([100, 101, 103]), np.array([0, 100, 200]))
+    np.testing.assert_array_equal(g, [100, 101, 102, 103])

@@ -142,6 +142,15 @@ def test_interior_row_blocks_of_a_partitioned_matrix(hip_engine):
         assert 0 <= b0 < b1 <= rb.size - 1
         inner = loc[rb[b0]:rb[b1]]
         assert inner.indices.max() < dm.n_cols_owned                      # interior: owned columns only
+        # the native halo descriptor sends one contiguous run per neighbour straight from the operand
+        h = dm.native_halo(dm.operand())
+        import ctypes
+        assert h.direct == 1 and h.n_pack == 0 and 1 <= h.n_send <= 2 and 1 <= h.n_recv <= 2
+        offs = np.ctypeslib.as_array(ctypes.cast(h.h_send_off, ctypes.POINTER(ctypes.c_int64)), shape=(h.n_send,))
+        cnts = np.ctypeslib.as_array(ctypes.cast(h.h_send_cnt, ctypes.POINTER(ctypes.c_int64)), shape=(h.n_send,))
+        assert np.all(offs >= 0) and np.all(offs + cnts <= dm.n_cols_owned)
+        if h.n_send == 2:
+            assert offs[0] == 0 and offs[1] + cnts[1] == dm.n_cols_owned  # first / last planes of the slab
         assert dm.plan.n_ghost > 0 and (b1 - b0) > 0.5 * (rb.size - 1)    # most of the slab is interior
         h = dm.native_halo(dm.operand())
         assert (h.int_begin, h.int_end) == (b0, b1) and h.n_recv >= 1 and h.n_send >= 1
