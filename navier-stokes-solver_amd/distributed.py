@@ -185,7 +185,7 @@ class HaloVector(Vector):
     def __init__(self, dmat):
         eng = dmat.engine
         self.ext = eng.zeros(dmat.plan.n_owned + dmat.plan.n_ghost)
-        super().__init__(buf=eng.view(self.ext, 0, dmat.plan.n_owned), engine=eng)
+        super().__init__(buf=eng.view(self.ext, 0, dmat.plan.n_owned), engine=eng, comm=dmat.comm)
         self.plan = dmat.plan
 
 
@@ -231,10 +231,10 @@ class DistSparseMatrix(BaseMatrix):
         return self.n_cols_owned
 
     def CreateColVector(self):
-        return Vector(self.n_rows, engine=self.engine)
+        return Vector(self.n_rows, engine=self.engine, comm=self.comm)
 
     def CreateRowVector(self):
-        return Vector(self.n_cols_owned, engine=self.engine)
+        return Vector(self.n_cols_owned, engine=self.engine, comm=self.comm)
 
     def operand(self):
         return HaloVector(self)
@@ -345,6 +345,8 @@ class DistInner:
         self.comm = comm
 
     def __call__(self, a, b):
+        if getattr(a, "comm", None) is not None:       # slabs that know their communicator reduce themselves
+            return InnerProduct(a, b)
         return self.comm.allreduce_scalar(InnerProduct(a, b))
 
 
@@ -396,6 +398,17 @@ class DistributedStokes:
     def local_slices(self):
         r = self.comm.rank
         return slice(int(self.vel[r]), int(self.vel[r + 1])), slice(int(self.prs[r]), int(self.prs[r + 1]))
+
+    def vectors(self, f_global, g_global):
+        """This rank's slabs of a global (velocity, pressure) pair as vectors that know the
+        communicator: `InnerProduct` / `Norm` of them -- and of every vector the solvers create from
+        them with `CreateVector()` -- are global, so `MinRes`, `bramble_pasciak_cg`,
+        `BramblePasciakCG` and `CGSolver` run unchanged on the partitioned operands."""
+        us, ps = self.local_slices()
+        fv = Vector.from_numpy(np.asarray(f_global)[us], engine=self.engine)
+        gv = Vector.from_numpy(np.asarray(g_global)[ps], engine=self.engine)
+        fv.comm = gv.comm = self.comm
+        return fv, gv
 
     def halo_doubles(self):
         return {"A_operand": self.A.plan.n_ghost, "B_operand": self.B.plan.n_ghost,

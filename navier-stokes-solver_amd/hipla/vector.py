@@ -188,7 +188,9 @@ class BaseVector:
 class Vector(BaseVector):
     """Plain fp64 vector in engine memory.  ``Vector(n)`` allocates n zeros."""
 
-    def __init__(self, n=None, *, buf=None, engine=None):
+    def __init__(self, n=None, *, buf=None, engine=None, comm=None):
+        """`comm`: set on the slab of a row-partitioned vector (distributed.py); inner products of
+        such vectors are summed over the ranks, and vectors created from them inherit it."""
         self.engine = engine if engine is not None else get_engine()
         if buf is None:
             if n is None:
@@ -196,6 +198,7 @@ class Vector(BaseVector):
             buf = self.engine.zeros(int(n))
         self.buf = buf
         self.size = self.engine.length(buf)
+        self.comm = comm
 
     # -- construction helpers ----------------------------------------------
     @classmethod
@@ -219,7 +222,7 @@ class Vector(BaseVector):
         self.engine.upload(arr, self.buf)
 
     def CreateVector(self):
-        return Vector(self.size, engine=self.engine)
+        return Vector(self.size, engine=self.engine, comm=self.comm)
 
     def Copy(self):
         v = self.CreateVector()
@@ -252,7 +255,7 @@ class Vector(BaseVector):
             a, b, st = key.indices(self.size)
             if st != 1:
                 raise IndexError("only contiguous ranges are supported")
-            return Vector(buf=self.engine.view(self.buf, a, b), engine=self.engine)
+            return Vector(buf=self.engine.view(self.buf, a, b), engine=self.engine, comm=self.comm)
         i = int(key)
         if i < 0:
             i += self.size
@@ -375,6 +378,10 @@ class BlockVector(BaseVector):
         return self.components[0].engine
 
     @property
+    def comm(self):
+        return getattr(self.components[0], "comm", None)
+
+    @property
     def size(self):
         return sum(len(c) for c in self.components)
 
@@ -491,7 +498,16 @@ class BlockVector(BaseVector):
 def InnerProduct(a, b):
     """Euclidean inner product -> Python float (reference: minres.py:71,98,103;
     bramble_pasciak_cg.py:105,130,137; solvers/bramblepasciak_new.py:185,222,235).
-    Block vectors: sum of the component dots, component 0 first."""
+    Block vectors: sum of the component dots, component 0 first.  Slabs of row-partitioned vectors
+    (``comm`` set): the local value is summed over the ranks (one all-reduce of a double)."""
+    local = _local_inner(a, b)
+    comm = getattr(a, "comm", None)
+    if comm is not None and comm.size > 1:
+        return comm.allreduce_scalar(local)
+    return local
+
+
+def _local_inner(a, b):
     if isinstance(a, BlockVector) or isinstance(b, BlockVector):
         if not (isinstance(a, BlockVector) and isinstance(b, BlockVector)) or a.nblocks != b.nblocks:
             raise TypeError("InnerProduct of mismatching block layouts")
@@ -500,7 +516,7 @@ def InnerProduct(a, b):
             return eng.dot_multi([(x.buf, y.buf) for x, y in zip(a.components, b.components)])
         total = 0.0
         for x, y in zip(a.components, b.components):
-            total += InnerProduct(x, y)
+            total += _local_inner(x, y)
         return total
     if a.size != b.size:
         raise ValueError("InnerProduct size mismatch: %d vs %d" % (a.size, b.size))

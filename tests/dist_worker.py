@@ -73,19 +73,20 @@ def run(rank, world, mode, init_file, out_dir, dim, n, pre, tol, maxsteps):
         # ---- MINRES on distributed operands ---------------------------------------------------------
         K = hipla.BlockMatrix([[ops.A, ops.B.T], [ops.B, None]])
         Cm = hipla.BlockMatrix([[ops.preA, None], [None, ops.preM]])
-        import hipla.vector as hv
-        saved = hv.InnerProduct
-        import minres as minres_mod
-        minres_mod.InnerProduct = ops.inner
-        try:
-            with contextlib.redirect_stdout(io.StringIO()):
-                um, errs = MinRes(mat=K, pre=Cm, rhs=hipla.BlockVector([hipla.Vector.from_numpy(f[us]),
-                                                                       hipla.Vector.from_numpy(g[ps])]),
-                                  maxsteps=maxsteps, tol=tol, printrates=False)
-        finally:
-            minres_mod.InnerProduct = saved
+        fv, gv = ops.vectors(f, g)                  # slabs that know the communicator: global inner products
+        with contextlib.redirect_stdout(io.StringIO()):
+            um, errs = MinRes(mat=K, pre=Cm, rhs=hipla.BlockVector([fv, gv]), maxsteps=maxsteps, tol=tol,
+                              printrates=False)
         res["minres_errors"] = np.array(errs)
         res["minres_u"] = um[0].numpy()
+        # ---- BPCG v1 on distributed operands (scale factor from the distributed Lanczos) --------------
+        from bramble_pasciak_cg import bramble_pasciak_cg
+        fv, gv = ops.vectors(f, g)
+        with contextlib.redirect_stdout(io.StringIO()):
+            x1, errs1 = bramble_pasciak_cg(ops.A, ops.B, None, ops.preA, ops.preM, fv, gv, tolerance=tol,
+                                           max_steps=maxsteps, print_rates=False)
+        res["bpcg1_errors"] = np.array(errs1)
+        res["bpcg1_u"] = x1[0].numpy()
     else:
         run_ = DistributedBpcg2(sysm, f, g, blocks, dist, eng, comm=comm)
         it, conv = run_.solve(tol=tol, maxsteps=maxsteps, poll_every=8)

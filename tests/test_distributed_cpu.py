@@ -64,8 +64,13 @@ def single_rank_reference(dim, n, pre, tol, maxsteps, numpy_engine):
     with contextlib.redirect_stdout(io.StringIO()):
         um, errs = MinRes(mat=K, pre=Cm, rhs=hipla.BlockVector([hipla.Vector.from_numpy(f), hipla.Vector.from_numpy(g)]),
                           maxsteps=maxsteps, tol=tol, printrates=False)
+    from bramble_pasciak_cg import bramble_pasciak_cg
+    with contextlib.redirect_stdout(io.StringIO()):
+        x1, errs1 = bramble_pasciak_cg(A, B, None, preA, preM, hipla.Vector.from_numpy(f), hipla.Vector.from_numpy(g),
+                                       tolerance=tol, max_steps=maxsteps, print_rates=False)
     return s, dict(it=it, hist=hist, k=ses.k, err0=ses.err0, u=sol[0].numpy(), p=sol[1].numpy(),
-                   minres_errors=np.array(errs), minres_u=um[0].numpy())
+                   minres_errors=np.array(errs), minres_u=um[0].numpy(), bpcg1_errors=np.array(errs1),
+                   bpcg1_u=x1[0].numpy())
 
 
 @pytest.mark.parametrize("world,dim,n,pre", [(2, 3, 8, "bjac"), (3, 2, 20, "jacobi")])
@@ -91,7 +96,12 @@ def test_gloo_row_partitioned_solve_matches_single_rank(numpy_engine, world, dim
         assert abs(int(d["it"]) - ref["it"]) <= max(3, int(0.03 * ref["it"]))
         np.testing.assert_allclose(d["minres_errors"][:40], ref["minres_errors"][:40], rtol=1e-8)
         assert abs(len(d["minres_errors"]) - len(ref["minres_errors"])) <= max(3, int(0.03 * len(ref["minres_errors"])))
+        # BPCG v1 through the protocol on slabs that know their communicator (no solver changes)
+        np.testing.assert_allclose(d["bpcg1_errors"][:30], ref["bpcg1_errors"][:30], rtol=1e-8)
+        assert abs(len(d["bpcg1_errors"]) - len(ref["bpcg1_errors"])) <= max(3, int(0.03 * len(ref["bpcg1_errors"])))
     assert sum(int(d["halo"][1]) for d in ranks) > 0 and sum(int(d["halo"][2]) for d in ranks) > 0
+    u1 = np.concatenate([d["bpcg1_u"] for d in ranks])
+    assert np.linalg.norm(u1 - ref["bpcg1_u"]) < 1e-5 * np.linalg.norm(ref["bpcg1_u"])
     u = np.concatenate([d["u"] for d in ranks])
     p = np.concatenate([d["p"] for d in ranks])
     assert np.linalg.norm(u - ref["u"]) < 1e-5 * np.linalg.norm(ref["u"])
