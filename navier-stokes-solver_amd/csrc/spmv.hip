@@ -6,6 +6,11 @@
 
 namespace nss {
 
+#ifndef NSS_PLAN_FILL_CHIP
+#define NSS_PLAN_FILL_CHIP 1
+#endif
+constexpr int kMinRowBlocks = 2048;   // 256 CUs x 8 resident workgroups
+
 void plan_row_blocks(int32_t m, int64_t nnz, const int32_t* rowptr, int32_t* rg_out, std::vector<int32_t>& blk,
                      const int32_t* cuts, int ncuts) {
   const double mean = m > 0 ? double(nnz) / double(m) : 0.0;
@@ -21,6 +26,11 @@ void plan_row_blocks(int32_t m, int64_t nnz, const int32_t* rowptr, int32_t* rg_
   if (rg == 1) {
     passes = mean > 0.0 ? int(double(kChunk) / (mean * rows_per_pass)) : kMaxRowsPerBlock / rows_per_pass;
     passes = std::max(1, passes);
+#if NSS_PLAN_FILL_CHIP
+    // small matrices (a slab of a partitioned system, the small configs): rather more, shorter row
+    // blocks than fewer than ~8 workgroups per CU
+    while (passes > 1 && int64_t(m) / (int64_t(passes) * rows_per_pass) < kMinRowBlocks) --passes;
+#endif
   }
   const int row_cap = std::min(kMaxRowsPerBlock, passes * rows_per_pass);
   blk.clear();
