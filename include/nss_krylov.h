@@ -95,6 +95,11 @@ NSS_API int nss_csr_transpose(nss_csr_t a, nss_csr_t* out);
  * in passes of at most max_products_per_pass products (<= 0: library default, 2^27). */
 NSS_API int nss_csr_spgemm(nss_csr_t x, nss_csr_t y, int64_t max_products_per_pass, nss_csr_t* out,
                            nss_stream_t stream);
+/* bytes per column index the SpMV kernel streams: 2 when the columns of every row block of the launch
+ * plan fall into at most 16 aligned windows of 4096 columns (stored as 4 bits of window number + 12
+ * bits of offset, decoded through 16 per-block window bases), else 4.  The values and the order of
+ * the products are the same either way. */
+NSS_API int nss_csr_index_width(nss_csr_t a, int32_t* bytes);
 /* copy the CSR arrays back to HOST buffers (rows+1 / nnz / nnz entries; sizes from nss_csr_info) */
 NSS_API int nss_csr_download(nss_csr_t a, int32_t* h_rowptr, int32_t* h_col, double* h_val);
 NSS_API int nss_csr_destroy(nss_csr_t a);

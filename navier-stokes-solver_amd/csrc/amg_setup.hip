@@ -399,6 +399,12 @@ nss_csr_s* adopt_csr(int32_t m, int32_t n, int64_t nnz, Dev<int32_t>& rowptr, De
   A->col = col.take();
   A->val = val.take();
   A->rowblk = rowblk.take();
+  try {
+    compress_columns(*A, nullptr);
+  } catch (...) {
+    nss_csr_destroy(A);
+    throw;
+  }
   return A;
 }
 

@@ -45,11 +45,15 @@ namespace nss {
 constexpr int kChunk = 2048;            // products staged per workgroup: 16 KiB of LDS
 constexpr int kMaxRowsPerBlock = 2048;  // bound for blocks of empty / very short rows
 constexpr int kXcds = 8;
+constexpr int kWindows = 16;          // column windows per row block of the 16-bit index stream
+constexpr int kWindowBits = 12;      // 4096 columns per window
 
 struct CsrView {
   const int32_t* __restrict__ rowblk;
   const int32_t* __restrict__ rowptr;
   const int32_t* __restrict__ col;
+  const uint16_t* __restrict__ col16;   // (window << 12 | offset) per entry, or NULL (see nss_csr_s)
+  const int32_t* __restrict__ blkbase;  // kWindows window bases per row block
   const double* __restrict__ val;
   int32_t blk0;     // first row block of this launch (sub-range launches: interior / boundary)
   int32_t nblk;     // row blocks in this launch
@@ -67,15 +71,27 @@ struct nss_csr_s {
   int32_t* rowblk = nullptr;
   int32_t nblk = 0;
   int32_t rg = 1;
+  // Compressed column stream: when the columns of every row block fall into at most 16 aligned
+  // windows of 4096 columns (grid operators: a row block touches its own grid plane and the two
+  // neighbouring ones -- a few narrow clusters far apart) the kernel streams 2 bytes per entry,
+  // 4 bits of window number + 12 bits of offset, decoded through the block's 16 window bases
+  // (held in LDS), instead of the 4-byte index: 2 bytes per non-zero less HBM traffic, same
+  // products in the same order.  `col` is kept for the set-up kernels and rows longer than a chunk.
+  uint16_t* col16 = nullptr;
+  int32_t* blkbase = nullptr;
   // launch view of the row blocks [b0, b1)
   nss::CsrView view(int b0, int b1) const {
-    return nss::CsrView{rowblk, rowptr, col, val, b0, b1 - b0, (b1 - b0 + nss::kXcds - 1) / nss::kXcds};
+    return nss::CsrView{rowblk, rowptr, col, col16, blkbase, val, b0, b1 - b0,
+                        (b1 - b0 + nss::kXcds - 1) / nss::kXcds};
   }
   // one workgroup per row block, padded to a multiple of the XCD count
   static int grid(int count) { return ((count + nss::kXcds - 1) / nss::kXcds) * nss::kXcds; }
 };
 
 namespace nss {
+
+// Build col16 / blkbase of a matrix whose device arrays and launch plan are complete (spmv.hip).
+void compress_columns(nss_csr_s& A, hipStream_t st);
 
 // Launch plan of a CSR matrix: lanes per row (*rg_out) and the row-block boundaries (spmv.hip).
 void plan_row_blocks(int32_t m, int64_t nnz, const int32_t* rowptr, int32_t* rg_out, std::vector<int32_t>& blk,
@@ -103,10 +119,11 @@ struct EpiPre<E, std::void_t<typename E::Pre>> {
   static __device__ void row(E& e, int r, double ax, const type& p) { e.row(r, ax, p); }
 };
 
-template <int RG, class Epi>
+template <int RG, class Epi, bool C16 = false>
 __global__ __launch_bounds__(kBlock) void csr_stream_kernel(CsrView a, const double* __restrict__ x, Epi epi) {
   __shared__ double prod[kChunk];
   __shared__ double red[kBlock / kWave];
+  __shared__ int32_t window[kWindows];
   if (epi.skip()) return;
   const int tid = threadIdx.x;
   // XCD-aware map: workgroups with equal (blockIdx & 7) share an XCD; XCD i owns the i-th
@@ -159,17 +176,28 @@ __global__ __launch_bounds__(kBlock) void csr_stream_kernel(CsrView a, const dou
       constexpr int kPer = kChunk / kBlock;
       int32_t c[kPer];
       double v[kPer];
+      uint16_t c16[kPer];
+      if (C16) {
+        if (tid < kWindows) window[tid] = a.blkbase[b * kWindows + tid];
+      }
 #pragma unroll
       for (int k = 0; k < kPer; ++k) {
         const int i = tid + k * kBlock;
         const bool live = i < cnt;
 #if NSS_STREAM_NT
-        c[k] = live ? __builtin_nontemporal_load(&a.col[p0 + i]) : 0;
+        if (C16) c16[k] = live ? __builtin_nontemporal_load(&a.col16[p0 + i]) : uint16_t(0);
+        else c[k] = live ? __builtin_nontemporal_load(&a.col[p0 + i]) : 0;
         v[k] = live ? __builtin_nontemporal_load(&a.val[p0 + i]) : 0.0;
 #else
-        c[k] = live ? a.col[p0 + i] : 0;
+        if (C16) c16[k] = live ? a.col16[p0 + i] : uint16_t(0);
+        else c[k] = live ? a.col[p0 + i] : 0;
         v[k] = live ? a.val[p0 + i] : 0.0;
 #endif
+      }
+      if (C16) {
+        __syncthreads();                                   // window bases in LDS
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) c[k] = window[c16[k] >> kWindowBits] + int32_t(c16[k] & ((1 << kWindowBits) - 1));
       }
       double xv[kPer];
 #pragma unroll
@@ -227,15 +255,19 @@ inline void launch_csr_stream(const nss_csr_s& A, const double* x, const Epi& ep
   if (A.m == 0 || b1 <= b0) return;
   const CsrView v = A.view(b0, b1);
   const dim3 grid(nss_csr_s::grid(b1 - b0)), block(kBlock);
+#define NSS_LAUNCH_RG(N)                                                                      \
+  case N:                                                                                      \
+    if (A.col16) hipLaunchKernelGGL((csr_stream_kernel<N, Epi, true>), grid, block, 0, st, v, x, epi);   \
+    else hipLaunchKernelGGL((csr_stream_kernel<N, Epi, false>), grid, block, 0, st, v, x, epi);          \
+    break;
   switch (A.rg) {
-    case 1: hipLaunchKernelGGL((csr_stream_kernel<1, Epi>), grid, block, 0, st, v, x, epi); break;
-    case 2: hipLaunchKernelGGL((csr_stream_kernel<2, Epi>), grid, block, 0, st, v, x, epi); break;
-    case 4: hipLaunchKernelGGL((csr_stream_kernel<4, Epi>), grid, block, 0, st, v, x, epi); break;
-    case 8: hipLaunchKernelGGL((csr_stream_kernel<8, Epi>), grid, block, 0, st, v, x, epi); break;
-    case 16: hipLaunchKernelGGL((csr_stream_kernel<16, Epi>), grid, block, 0, st, v, x, epi); break;
-    case 32: hipLaunchKernelGGL((csr_stream_kernel<32, Epi>), grid, block, 0, st, v, x, epi); break;
-    default: hipLaunchKernelGGL((csr_stream_kernel<64, Epi>), grid, block, 0, st, v, x, epi); break;
+    NSS_LAUNCH_RG(1) NSS_LAUNCH_RG(2) NSS_LAUNCH_RG(4) NSS_LAUNCH_RG(8) NSS_LAUNCH_RG(16) NSS_LAUNCH_RG(32)
+    default:
+      if (A.col16) hipLaunchKernelGGL((csr_stream_kernel<64, Epi, true>), grid, block, 0, st, v, x, epi);
+      else hipLaunchKernelGGL((csr_stream_kernel<64, Epi, false>), grid, block, 0, st, v, x, epi);
+      break;
   }
+#undef NSS_LAUNCH_RG
   NSS_CHECK_LAUNCH();
 }
 

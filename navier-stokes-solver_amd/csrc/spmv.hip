@@ -2,6 +2,7 @@
 #include "csr_stream.h"
 
 #include <algorithm>
+#include <climits>
 #include <vector>
 
 namespace nss {
@@ -51,6 +52,106 @@ void plan_row_blocks(int32_t m, int64_t nnz, const int32_t* rowptr, int32_t* rg_
     if (r == start) ++r;  // a single row longer than the chunk gets a block of its own
     blk.push_back(r);
   }
+}
+
+// ---- 16-bit column offsets -----------------------------------------------------------------------
+#ifndef NSS_COL16
+#define NSS_COL16 1
+#endif
+
+// one workgroup per row block: the distinct 4096-column windows its entries fall into (lane 0, a
+// linear table of at most kWindows; consecutive entries mostly repeat the window).  More than
+// kWindows raises *wide; row blocks that are one over-long row are skipped (the kernel reads their
+// 4-byte indices).
+__global__ __launch_bounds__(kBlock) void col_windows_kernel(int32_t nblk, const int32_t* __restrict__ rowblk,
+                                                              const int32_t* __restrict__ rowptr,
+                                                              const int32_t* __restrict__ col,
+                                                              int32_t* __restrict__ base, int32_t* __restrict__ wide) {
+  const int b = blockIdx.x * kBlock + threadIdx.x;      // one lane per row block
+  if (b >= nblk) return;
+  const int p0 = rowptr[rowblk[b]], p1 = rowptr[rowblk[b + 1]];
+  int32_t tab[kWindows];
+  int cnt = 0;
+  if (p1 - p0 <= kChunk) {
+    int32_t last = -1;
+    for (int p = p0; p < p1; ++p) {
+      const int32_t w = col[p] >> kWindowBits;
+      if (w == last) continue;
+      last = w;
+      bool found = false;
+      for (int k = 0; k < cnt; ++k) found = found || tab[k] == w;
+      if (found) continue;
+      if (cnt == kWindows) {
+        atomicOr(wide, 1);
+        break;
+      }
+      tab[cnt++] = w;
+    }
+  }
+  for (int k = 0; k < kWindows; ++k) base[b * kWindows + k] = k < cnt ? tab[k] << kWindowBits : 0;
+}
+
+__global__ __launch_bounds__(kBlock) void col_pack16_kernel(int32_t nblk, const int32_t* __restrict__ rowblk,
+                                                             const int32_t* __restrict__ rowptr,
+                                                             const int32_t* __restrict__ col,
+                                                             const int32_t* __restrict__ base,
+                                                             uint16_t* __restrict__ col16) {
+  __shared__ int32_t window[kWindows];
+  const int b = blockIdx.x;
+  if (b >= nblk) return;
+  if (threadIdx.x < kWindows) window[threadIdx.x] = base[b * kWindows + threadIdx.x];
+  __syncthreads();
+  const int p0 = rowptr[rowblk[b]], p1 = rowptr[rowblk[b + 1]];
+  if (p1 - p0 > kChunk) return;
+  for (int p = p0 + threadIdx.x; p < p1; p += kBlock) {
+    const int32_t c = col[p];
+    const int32_t w = (c >> kWindowBits) << kWindowBits;
+    int k = 0;
+    while (k < kWindows - 1 && window[k] != w) ++k;
+    col16[p] = uint16_t((k << kWindowBits) | (c & ((1 << kWindowBits) - 1)));
+  }
+}
+
+void compress_columns(nss_csr_s& A, hipStream_t st) {
+#if NSS_COL16
+  if (A.nnz == 0 || A.nblk == 0) return;
+  int32_t* base = nullptr;
+  int32_t* wide = nullptr;
+  uint16_t* c16 = nullptr;
+  try {
+    NSS_HIP(hipMalloc(&base, sizeof(int32_t) * size_t(A.nblk) * kWindows));
+    NSS_HIP(hipMalloc(&wide, sizeof(int32_t)));
+    NSS_HIP(hipMemsetAsync(wide, 0, sizeof(int32_t), st));
+    hipLaunchKernelGGL(col_windows_kernel, dim3((A.nblk + kBlock - 1) / kBlock), dim3(kBlock), 0, st, A.nblk, A.rowblk,
+                       A.rowptr, A.col, base, wide);
+    NSS_CHECK_LAUNCH();
+    int32_t h_wide = 0;
+    NSS_HIP(hipMemcpyAsync(&h_wide, wide, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    NSS_HIP(hipStreamSynchronize(st));
+    if (h_wide == 0) {
+      NSS_HIP(hipMalloc(&c16, sizeof(uint16_t) * (size_t(A.nnz) + 8)));
+      NSS_HIP(hipMemsetAsync(c16, 0, sizeof(uint16_t) * (size_t(A.nnz) + 8), st));
+      hipLaunchKernelGGL(col_pack16_kernel, dim3(A.nblk), dim3(kBlock), 0, st, A.nblk, A.rowblk, A.rowptr, A.col, base,
+                         c16);
+      NSS_CHECK_LAUNCH();
+      NSS_HIP(hipStreamSynchronize(st));
+      A.col16 = c16;
+      A.blkbase = base;
+      c16 = nullptr;
+      base = nullptr;
+    }
+  } catch (...) {
+    (void)hipFree(base);
+    (void)hipFree(wide);
+    (void)hipFree(c16);
+    throw;
+  }
+  (void)hipFree(base);
+  (void)hipFree(wide);
+#else
+  (void)A;
+  (void)st;
+#endif
 }
 
 __global__ __launch_bounds__(kBlock) void csr_diag_kernel(int32_t m, const int32_t* __restrict__ rowptr,
@@ -111,6 +212,7 @@ int nss_csr_create_cuts(int32_t nrows, int32_t ncols, int64_t nnz, const int32_t
         NSS_HIP(hipMemcpy(A->val, h_val, sizeof(double) * nnz, hipMemcpyHostToDevice));
       }
       NSS_HIP(hipMemcpy(A->rowblk, blk.data(), sizeof(int32_t) * blk.size(), hipMemcpyHostToDevice));
+      compress_columns(*A, nullptr);
     } catch (...) {
       nss_csr_destroy(A);
       throw;
@@ -126,6 +228,8 @@ int nss_csr_destroy(nss_csr_t a) {
     (void)hipFree(a->col);
     (void)hipFree(a->val);
     (void)hipFree(a->rowblk);
+    (void)hipFree(a->col16);
+    (void)hipFree(a->blkbase);
     delete a;
   });
 }
@@ -135,6 +239,13 @@ int nss_csr_spmv_f64(nss_csr_t a, double alpha, const double* x, double beta, do
     NSS_REQUIRE(a != nullptr, "csr_spmv: NULL matrix");
     NSS_REQUIRE(x != y, "csr_spmv: x must not alias y");
     launch_csr_stream(*a, x, EpiAxpby{alpha, beta, y}, as_stream(stream));
+  });
+}
+
+int nss_csr_index_width(nss_csr_t a, int32_t* bytes) {
+  return guarded([&] {
+    NSS_REQUIRE(a != nullptr && bytes != nullptr, "csr_index_width: NULL argument");
+    *bytes = a->col16 ? 2 : 4;
   });
 }
 

@@ -44,6 +44,7 @@ def _signatures():
         "nss_csr_transpose": (C.c_int, [vp, C.POINTER(vp)]),
         "nss_csr_spgemm": (C.c_int, [vp, vp, i64, C.POINTER(vp), vp]),
         "nss_csr_download": (C.c_int, [vp, vp, vp, vp]),
+        "nss_csr_index_width": (C.c_int, [vp, c_i32_p]),
         "nss_reciprocal_f64": (C.c_int, [i64, vp, vp, vp]),
         "nss_amg_aggregate": (C.c_int, [vp, dbl, vp, vp, c_i64_p, vp]),
         "nss_amg_prolongator": (C.c_int, [vp, vp, i64, dbl, C.POINTER(vp), vp]),
@@ -124,8 +125,10 @@ class _CsrHandle:
         m, n, nb, rg = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
         nnz, nbytes = C.c_int64(), C.c_int64()
         self.engine._check(lib.nss_csr_info(self.ptr, m, n, nnz, nb, rg, nbytes))
+        width = C.c_int32()
+        self.engine._check(lib.nss_csr_index_width(self.ptr, width))
         return {"rows": m.value, "cols": n.value, "nnz": nnz.value, "row_blocks": nb.value,
-                "lanes_per_row": rg.value, "algorithmic_bytes": nbytes.value}
+                "lanes_per_row": rg.value, "algorithmic_bytes": nbytes.value, "index_bytes": width.value}
 
     def __del__(self):
         try:

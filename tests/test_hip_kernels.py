@@ -151,6 +151,42 @@ def test_spmv_ragged_empty_and_long_rows(hip_engine):
     _spmv_check(hip_engine, sp.identity(20000, format="csr"))
 
 
+def test_spmv_16_bit_column_offsets(hip_engine):
+    """Operators whose row blocks touch at most 16 windows of 4096 columns stream 2-byte indices
+    (4-bit window + 12-bit offset, nss_csr_index_width), scattered ones the 4-byte indices; the
+    products are the same either way."""
+    import hipla
+    s = mac_stokes(3, 32)                              # n_u = 95 232 > 2^16: the bases matter
+    for mat in (s.A, s.B, s.B.T.tocsr()):
+        M = _spmv_check(hip_engine, mat, seed=3)
+        assert M.handle.info()["index_bytes"] == 2
+        _spmv_check(hip_engine, mat, seed=4, alpha=-1.5, beta=0.5)
+    assert hipla.SparseMatrix.from_scipy(s.B).CreateTranspose().handle.info()["index_bytes"] == 2   # device-built
+    rng = np.random.default_rng(7)
+    m, n = 4000, 300000
+    lens = rng.integers(1, 12, size=m)
+    rows = np.repeat(np.arange(m), lens)
+    cols = np.concatenate([rng.choice(n, size=k, replace=False) for k in lens])
+    wide = sp.csr_matrix((rng.standard_normal(rows.size), (rows, cols)), shape=(m, n))
+    M = _spmv_check(hip_engine, wide)
+    assert M.handle.info()["index_bytes"] == 4
+    # exactly at the limit: 16 column windows of 4096 per row block fit, 17 do not
+    for windows, width in ((16, 2), (17, 4)):
+        cols = np.arange(windows) * 4096 + 5
+        edge = sp.csr_matrix((np.arange(1.0, windows + 1), (np.zeros(windows, dtype=int), cols)), shape=(1, 80000))
+        M = _spmv_check(hip_engine, edge)
+        assert M.handle.info()["index_bytes"] == width
+    # a row longer than one LDS chunk does not count against the windows (it reads 4-byte indices)
+    lens = np.full(600, 5)
+    lens[300] = 3000
+    rows = np.repeat(np.arange(600), lens)
+    cols = np.concatenate([np.sort(rng.choice(200000, size=3000, replace=False)) if k == 3000
+                           else 1000 + r + np.arange(5) for r, k in enumerate(lens)])
+    mixed = sp.csr_matrix((rng.standard_normal(rows.size), (rows, cols)), shape=(600, 200000))
+    M = _spmv_check(hip_engine, mixed)
+    assert M.handle.info()["index_bytes"] == 2
+
+
 def test_spmv_cfg1_heat_matrix(hip_engine):
     M = diffusion_2d(64)
     assert M.shape == (4096, 4096) and M.nnz == 20224
