@@ -402,7 +402,9 @@ def main():
                                "BPCG v2 (solvers/bramblepasciak_new.py), %s preA, lumped-mass preM, Re=%g"
                                % (args.dim, args.n, sysm.ndof, args.pre, 1.0 / args.nu),
                    "n_u": n_u, "n_p": n_p, "nnz_A": a_info["nnz"], "nnz_B": b_info["nnz"],
-                   "scale_factor_k": ses.k, "device": info["arch"], "cu_count": info["cu_count"]},
+                   "scale_factor_k": ses.k, "device": info["arch"], "cu_count": info["cu_count"],
+                   "column_index_bytes": {"A": a_info["index_bytes"], "B": b_info["index_bytes"],
+                                          "BT": bt_info["index_bytes"]}},
         "roofline": {"bound": "hbm", "kernel": "csr_stream_kernel<1, EpiK2> (A SpMV + fused t4 / <s0,v0>)",
                      "achieved": k2_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k2_gbs / HBM_PEAK_GBS,
                      "traffic": traffic["bytes"] if traffic else None,
