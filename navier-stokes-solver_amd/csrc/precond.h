@@ -10,6 +10,8 @@ struct nss_bjac_s {
   int64_t n = 0;
   int32_t* idx = nullptr;      // [bs][nblocks], -1 = padding
   double* inv = nullptr;       // [bs*bs][nblocks]
+  double* inv_sym = nullptr;   // [bs*(bs+1)/2][nblocks]: upper triangles, when every inverse block is
+                               // symmetric (A symmetric): the apply kernel then reads ~half the bytes
   int32_t* covered = nullptr;  // dofs that belong to no block (count: n_uncovered)
   int32_t n_uncovered = 0;
   // multicolour Gauss-Seidel mode (nss_bjac_set_colors): blocks are stored colour-major

@@ -11,6 +11,10 @@
 #include <string>
 #include <vector>
 
+#ifndef NSS_BJAC_SYM
+#define NSS_BJAC_SYM 1
+#endif
+
 namespace nss {
 
 // One lane per block: gather the dense block from CSR rows, Gauss-Jordan with partial
@@ -69,6 +73,64 @@ __global__ __launch_bounds__(kBlock) void bjac_setup_kernel(int32_t bs, int32_t 
   if (bad) atomicAdd(singular, 1);
   for (int r = 0; r < bs; ++r)
     for (int c = 0; c < bs; ++c) inv[(size_t(r) * bs + c) * nb + b] = bad ? 0.0 : m[r][bs + c];
+}
+
+// upper triangles of the inverse blocks (averaged with the mirrored entry); *asym counts blocks
+// whose inverse is not symmetric to 1e-12
+__global__ __launch_bounds__(kBlock) void bjac_pack_sym_kernel(int bs, int32_t nb, const double* __restrict__ inv,
+                                                                double* __restrict__ packed,
+                                                                int32_t* __restrict__ asym) {
+  const int b = blockIdx.x * kBlock + threadIdx.x;
+  if (b >= nb) return;
+  bool bad = false;
+  int t = 0;
+  for (int r = 0; r < bs; ++r)
+    for (int c = r; c < bs; ++c, ++t) {
+      const double u = inv[(size_t(r) * bs + c) * nb + b], l = inv[(size_t(c) * bs + r) * nb + b];
+      if (fabs(u - l) > 1e-12 * fmax(fabs(u), fabs(l))) bad = true;
+      if (packed) packed[size_t(t) * nb + b] = 0.5 * (u + l);
+    }
+  if (bad) atomicAdd(asym, 1);
+}
+
+// symmetric inverse blocks: every stored entry is read once and used for both triangles
+template <int BS>
+__global__ __launch_bounds__(kBlock) void bjac_apply_sym_kernel(int32_t nb, const int32_t* __restrict__ idx,
+                                                                 const double* __restrict__ packed, double alpha,
+                                                                 const double* __restrict__ x, double beta,
+                                                                 double* __restrict__ y,
+                                                                 const int32_t* __restrict__ done) {
+  if (done && done[0] != 0) return;
+  const int stride = gridDim.x * kBlock;
+  for (int b = blockIdx.x * kBlock + threadIdx.x; b < nb; b += stride) {
+    int32_t dof[BS];
+    double xv[BS], s[BS];
+#pragma unroll
+    for (int c = 0; c < BS; ++c) dof[c] = idx[size_t(c) * nb + b];
+#pragma unroll
+    for (int c = 0; c < BS; ++c) {
+      xv[c] = dof[c] >= 0 ? x[dof[c]] : 0.0;
+      s[c] = 0.0;
+    }
+    int t = 0;
+#pragma unroll
+    for (int r = 0; r < BS; ++r) {
+#pragma unroll
+      for (int c = r; c < BS; ++c, ++t) {
+        const double m = packed[size_t(t) * nb + b];
+        s[r] = fma(m, xv[c], s[r]);
+        if (c > r) s[c] = fma(m, xv[r], s[c]);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < BS; ++r) {
+      if (dof[r] >= 0) {
+        double v = alpha * s[r];
+        if (beta != 0.0) v = fma(beta, y[dof[r]], v);
+        y[dof[r]] = v;
+      }
+    }
+  }
 }
 
 template <int BS>
@@ -194,8 +256,12 @@ template <int BS>
 static void launch_bjac(const nss_bjac_s& j, double alpha, const double* x, double beta, double* y,
                         const int32_t* done, hipStream_t st) {
   const int grid = stream_grid(j.nblocks, kBlock);
-  hipLaunchKernelGGL((bjac_apply_kernel<BS>), dim3(grid), dim3(kBlock), 0, st, j.nblocks, j.idx, j.inv, alpha, x,
-                     beta, y, done);
+  if (j.inv_sym)
+    hipLaunchKernelGGL((bjac_apply_sym_kernel<BS>), dim3(grid), dim3(kBlock), 0, st, j.nblocks, j.idx, j.inv_sym, alpha,
+                       x, beta, y, done);
+  else
+    hipLaunchKernelGGL((bjac_apply_kernel<BS>), dim3(grid), dim3(kBlock), 0, st, j.nblocks, j.idx, j.inv, alpha, x,
+                       beta, y, done);
 }
 
 void bjac_apply(const nss_bjac_s& j, double alpha, const double* x, double beta, double* y, const int32_t* done,
@@ -268,6 +334,24 @@ int nss_bjac_create(nss_csr_t a, int32_t bs, int32_t nblocks, const int32_t* h_i
       (void)hipFree(singular);
       singular = nullptr;
       if (nsing > 0) throw Error("bjac_create: " + std::to_string(nsing) + " singular diagonal block(s)");
+#if NSS_BJAC_SYM
+      if (bs > 1) {   // symmetric inverses (A symmetric): keep the packed upper triangles for the apply kernel
+        NSS_HIP(hipMalloc(&singular, sizeof(int32_t)));
+        NSS_HIP(hipMemset(singular, 0, sizeof(int32_t)));
+        NSS_HIP(hipMalloc(&j->inv_sym, sizeof(double) * size_t(bs) * (bs + 1) / 2 * nblocks));
+        hipLaunchKernelGGL(bjac_pack_sym_kernel, dim3((nblocks + kBlock - 1) / kBlock), dim3(kBlock), 0, nullptr, bs,
+                           nblocks, j->inv, j->inv_sym, singular);
+        NSS_CHECK_LAUNCH();
+        int32_t nasym = 0;
+        NSS_HIP(hipMemcpy(&nasym, singular, sizeof(int32_t), hipMemcpyDeviceToHost));
+        (void)hipFree(singular);
+        singular = nullptr;
+        if (nasym > 0) {
+          (void)hipFree(j->inv_sym);
+          j->inv_sym = nullptr;
+        }
+      }
+#endif
     } catch (...) {
       (void)hipFree(singular);
       nss_bjac_destroy(j);
@@ -282,6 +366,7 @@ int nss_bjac_destroy(nss_bjac_t j) {
     if (!j) return;
     (void)hipFree(j->idx);
     (void)hipFree(j->inv);
+    (void)hipFree(j->inv_sym);
     (void)hipFree(j->covered);
     (void)hipFree(j->rowdof);
     (void)hipFree(j->ridx);

@@ -228,6 +228,11 @@ def test_block_jacobi(hip_engine, bs):
     y.set_from(y0)
     y.data += (-0.5) * J * hipla.Vector.from_numpy(x)
     assert relerr(y.numpy(), y0 - 0.5 * ref) < 1e-12
+    # a non-symmetric matrix keeps the full inverse blocks (the symmetric ones are stored packed)
+    skew = (s.A + 0.3 * sp.triu(s.A, 1)).tocsr()
+    J2 = hipla.BlockJacobi(hipla.SparseMatrix.from_scipy(skew), idx)
+    y.data = J2 * hipla.Vector.from_numpy(x)
+    assert relerr(y.numpy(), kr.block_jacobi(skew, idx)(x)) < 1e-12
 
 
 def test_block_jacobi_lists_uncovered_dofs_and_errors(hip_engine):
