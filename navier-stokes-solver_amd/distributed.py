@@ -355,11 +355,76 @@ class Form:
         self.mat, self.condense = mat, False
 
 
+class DistributedAMG(BaseMatrix):
+    """Smoothed-aggregation V(1,1)-cycle on a row-partitioned operator with *replicated coarse
+    levels*: the finest level (smoothing, residual, restriction, prolongation) works on the slab with
+    halo exchanges, the restricted residual is all-reduced (one coarse vector, ~9 % of the fine
+    size) and every rank runs levels 1.. of the cycle redundantly on its own GPU.  Two halo
+    exchanges and one all-reduce per cycle instead of a halo exchange per level and per SpMV -- the
+    coarse levels are latency-bound at 8 GPUs either way, and replicating them keeps the hierarchy
+    identical to the single-GPU one (`hipla.amg.build_hierarchy` on the global matrix, built on
+    every rank).  Applies to slab vectors; use it as `preA` of the solvers on `DistSparseMatrix`
+    operands (protocol path)."""
+
+    def __init__(self, global_csr, dist_A, **amg_options):
+        super().__init__()
+        from hipla.amg import build_hierarchy
+        self.A = dist_A
+        self.comm, self.engine = dist_A.comm, dist_A.engine
+        eng, r = self.engine, dist_A.comm.rank
+        glob = SparseMatrix.from_scipy(global_csr, engine=eng)
+        self.omega = float(amg_options.get("omega", 2.0 / 3.0))
+        levels = build_hierarchy(glob, **amg_options)
+        if len(levels) < 2:
+            raise ValueError("DistributedAMG: the hierarchy has a single level")
+        self.level_sizes = [lv["n"] for lv in levels]
+        r0, r1 = int(dist_A.row_offsets[r]), int(dist_A.row_offsets[r + 1])
+        P, R = levels[0]["P"].to_scipy(), levels[0]["R"].to_scipy()
+        self.P_loc = SparseMatrix.from_scipy(sp.csr_matrix(P[r0:r1, :]), engine=eng)        # owned rows
+        self.R_loc = SparseMatrix.from_scipy(sp.csr_matrix(R[:, r0:r1]), engine=eng)        # owned columns
+        self.dinv = DiagonalMatrix(self.omega / global_csr.diagonal()[r0:r1], engine=eng)   # w D^-1 on the slab
+        self.coarse_levels = levels[1:]
+        self.coarse = eng.amg_create(self.coarse_levels, self.omega)
+        nc = levels[1]["n"]
+        self.rc, self.ec = Vector(nc, engine=eng), Vector(nc, engine=eng)
+        self.x0, self.res = dist_A.CreateRowVector(), dist_A.CreateColVector()
+        self.n = r1 - r0
+
+    def Height(self):
+        return self.n
+
+    def Width(self):
+        return self.n
+
+    def CreateColVector(self):
+        return self.A.CreateColVector()
+
+    CreateRowVector = CreateColVector
+
+    def Mult(self, b, y):
+        x0, res, rc, ec = self.x0, self.res, self.rc, self.ec
+        x0.data = self.dinv * b                             # pre-smoothing from zero
+        res.data = b - self.A * x0                          # halo exchange 1
+        rc.data = self.R_loc * res                          # this slab's share of the coarse residual
+        self.comm.allreduce_sum(rc.buf)
+        self.engine.amg_apply(self.coarse, 1.0, rc.buf, ec.buf)     # levels 1.. on every rank
+        x0.data += self.P_loc * ec
+        res.data = b - self.A * x0                          # halo exchange 2
+        y.data = x0 + self.dinv * res                       # post-smoothing
+
+    MultTrans = Mult
+
+    @property
+    def T(self):
+        return self
+
+
 class DistributedStokes:
     """The operands of the Stokes solve on this rank: A, B, B^T as `DistSparseMatrix`,
-    block-Jacobi / Jacobi preA and lumped-mass preM restricted to the slab."""
+    block-Jacobi / Jacobi preA (or, `pre="amg"`, the `DistributedAMG` cycle) and lumped-mass preM
+    restricted to the slab."""
 
-    def __init__(self, sysm, blocks, comm, engine=None, partition=None):
+    def __init__(self, sysm, blocks, comm, engine=None, partition=None, pre=None):
         self.comm = comm
         self.engine = engine if engine is not None else get_engine()
         r, size = comm.rank, comm.size
@@ -391,6 +456,8 @@ class DistributedStokes:
         else:
             from hipla import JacobiPreconditioner
             self.preA = JacobiPreconditioner(self.A_diag)
+        if pre == "amg":
+            self.preA = DistributedAMG(sysm.A, self.A)
         p0, p1 = int(self.prs[r]), int(self.prs[r + 1])
         self.preM = DiagonalMatrix(1.0 / sysm.mass[p0:p1], engine=self.engine)
         self.inner = DistInner(comm)

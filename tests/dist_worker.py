@@ -93,6 +93,27 @@ def run(rank, world, mode, init_file, out_dir, dim, n, pre, tol, maxsteps):
         res["hist"] = run_.history(it)
         res["it"], res["k"], res["err0"] = it, run_.k, run_.err0
         res["u"], res["p"] = run_.sol[0].numpy(), run_.sol[1].numpy()
+    # ---- distributed AMG (replicated coarse levels) as preA, BPCG v2 through the protocol ------------
+    if pre == "bjac":
+        from distributed import DistributedAMG
+        from solvers.bramblepasciak_new import BramblePasciakCG
+        amg = DistributedAMG(sysm.A, ops.A, coarse_size=60)
+        res["amg_levels"] = np.array(amg.level_sizes)
+        xa = np.random.default_rng(9).standard_normal(sysm.n_u)
+        va = hipla.Vector.from_numpy(xa[us])
+        ya = hipla.Vector(ops.n_u)
+        ya.data = amg * va
+        res["amg_apply"] = ya.numpy()
+        fv, gv = ops.vectors(f, g)
+        sol = hipla.BlockVector([fv.CreateVector(), gv.CreateVector()])
+        out = io.StringIO()
+        with contextlib.redirect_stdout(out):
+            it_a, _ = BramblePasciakCG(Form(ops.A), Form(ops.B), None, fv, gv, amg, ops.preM, sol, tol=tol,
+                                       maxsteps=maxsteps)
+        import re as _re
+        res["amg_hist"] = np.array([float(m) for m in _re.findall(r"it =\s+\d+\s+err =\s+(\S+)", out.getvalue())])
+        res["amg_it"] = it_a
+        res["amg_u"] = sol[0].numpy()
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), **res)
     dist.barrier()
     dist.destroy_process_group()

@@ -68,9 +68,23 @@ def single_rank_reference(dim, n, pre, tol, maxsteps, numpy_engine):
     with contextlib.redirect_stdout(io.StringIO()):
         x1, errs1 = bramble_pasciak_cg(A, B, None, preA, preM, hipla.Vector.from_numpy(f), hipla.Vector.from_numpy(g),
                                        tolerance=tol, max_steps=maxsteps, print_rates=False)
+    amg_ref = {}
+    if pre == "bjac":                                  # single-process AMG solve: what DistributedAMG must reproduce
+        from solvers.bramblepasciak_new import BramblePasciakCG
+        V = hipla.SmoothedAggregationAMG(A, coarse_size=60)
+        xa = np.random.default_rng(9).standard_normal(s.n_u)
+        ya = hipla.Vector(s.n_u)
+        ya.data = V * hipla.Vector.from_numpy(xa)
+        sol_a = hipla.BlockVector([hipla.Vector(s.n_u), hipla.Vector(s.n_p)])
+        out = io.StringIO()
+        with contextlib.redirect_stdout(out):
+            it_a, _ = BramblePasciakCG(Form(A), Form(B), None, hipla.Vector.from_numpy(f), hipla.Vector.from_numpy(g), V,
+                                       preM, sol_a, tol=tol, maxsteps=maxsteps)
+        amg_ref = dict(amg_levels=np.array(V.level_sizes), amg_apply=ya.numpy(), amg_it=it_a, amg_u=sol_a[0].numpy(),
+                       amg_hist=np.array([float(m) for m in re.findall(r"it =\s+\d+\s+err =\s+(\S+)", out.getvalue())]))
     return s, dict(it=it, hist=hist, k=ses.k, err0=ses.err0, u=sol[0].numpy(), p=sol[1].numpy(),
                    minres_errors=np.array(errs), minres_u=um[0].numpy(), bpcg1_errors=np.array(errs1),
-                   bpcg1_u=x1[0].numpy())
+                   bpcg1_u=x1[0].numpy(), **amg_ref)
 
 
 @pytest.mark.parametrize("world,dim,n,pre", [(2, 3, 8, "bjac"), (3, 2, 20, "jacobi")])
@@ -100,6 +114,16 @@ def test_gloo_row_partitioned_solve_matches_single_rank(numpy_engine, world, dim
         np.testing.assert_allclose(d["bpcg1_errors"][:30], ref["bpcg1_errors"][:30], rtol=1e-8)
         assert abs(len(d["bpcg1_errors"]) - len(ref["bpcg1_errors"])) <= max(3, int(0.03 * len(ref["bpcg1_errors"])))
     assert sum(int(d["halo"][1]) for d in ranks) > 0 and sum(int(d["halo"][2]) for d in ranks) > 0
+    if pre == "bjac":      # distributed AMG with replicated coarse levels == the single-process V-cycle
+        np.testing.assert_array_equal(ranks[0]["amg_levels"], ref["amg_levels"])
+        ya = np.concatenate([d["amg_apply"] for d in ranks])
+        assert np.linalg.norm(ya - ref["amg_apply"]) < 1e-12 * np.linalg.norm(ref["amg_apply"])
+        w = min(25, len(ref["amg_hist"]), len(ranks[0]["amg_hist"]))
+        np.testing.assert_allclose(ranks[0]["amg_hist"][:w], ref["amg_hist"][:w], rtol=1e-8)
+        assert abs(int(ranks[0]["amg_it"]) - ref["amg_it"]) <= max(3, int(0.03 * ref["amg_it"]))
+        ua = np.concatenate([d["amg_u"] for d in ranks])
+        assert np.linalg.norm(ua - ref["amg_u"]) < 1e-5 * np.linalg.norm(ref["amg_u"])
+        assert ref["amg_it"] < ref["it"] / 2                # and it pays: far fewer iterations than block Jacobi
     u1 = np.concatenate([d["bpcg1_u"] for d in ranks])
     assert np.linalg.norm(u1 - ref["bpcg1_u"]) < 1e-5 * np.linalg.norm(ref["bpcg1_u"])
     u = np.concatenate([d["u"] for d in ranks])

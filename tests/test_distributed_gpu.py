@@ -57,6 +57,37 @@ def test_fused_distributed_loop_matches_single_gpu(hip_engine, world, dim, n, pr
     assert np.linalg.norm(u - ref["u"]) < 1e-5 * np.linalg.norm(ref["u"])
     p0, pr = p - p.mean(), ref["p"] - ref["p"].mean()
     assert np.linalg.norm(p0 - pr) < 1e-4 * np.linalg.norm(pr)
+    if pre == "bjac":
+        # DistributedAMG (finest level on the slabs, coarse levels replicated on every rank) on the
+        # product engine: same hierarchy, same V-cycle and same BPCG history as one GPU
+        import hipla
+        from solvers.bramblepasciak_new import BramblePasciakCG
+        import re
+        A, B = hipla.SparseMatrix.from_scipy(s.A), hipla.SparseMatrix.from_scipy(s.B)
+        V = hipla.SmoothedAggregationAMG(A, coarse_size=60)
+        assert list(ranks[0]["amg_levels"]) == V.level_sizes
+        xa = np.random.default_rng(9).standard_normal(s.n_u)
+        ya = hipla.Vector(s.n_u)
+        ya.data = V * hipla.Vector.from_numpy(xa)
+        got = np.concatenate([d["amg_apply"] for d in ranks])
+        assert np.linalg.norm(got - ya.numpy()) < 1e-12 * np.linalg.norm(ya.numpy())
+
+        class Form:
+            def __init__(self, mat):
+                self.mat, self.condense = mat, False
+
+        f, g = s.rhs(0)
+        sol = hipla.BlockVector([hipla.Vector(s.n_u), hipla.Vector(s.n_p)])
+        out = io.StringIO()
+        with contextlib.redirect_stdout(out):
+            it_a, _ = BramblePasciakCG(Form(A), Form(B), None, hipla.Vector.from_numpy(f), hipla.Vector.from_numpy(g), V,
+                                       hipla.DiagonalMatrix(1.0 / s.mass), sol, tol=tol, maxsteps=maxsteps)
+        hist = np.array([float(m) for m in re.findall(r"it =\s+\d+\s+err =\s+(\S+)", out.getvalue())])
+        w = min(25, len(hist), len(ranks[0]["amg_hist"]))
+        np.testing.assert_allclose(ranks[0]["amg_hist"][:w], hist[:w], rtol=1e-8)
+        assert abs(int(ranks[0]["amg_it"]) - it_a) <= max(3, int(0.03 * it_a))
+        ua = np.concatenate([d["amg_u"] for d in ranks])
+        assert np.linalg.norm(ua - sol[0].numpy()) < 1e-5 * np.linalg.norm(sol[0].numpy())
 
 
 def test_rccl_ctypes_communicator_single_rank(hip_engine, tmp_path):
