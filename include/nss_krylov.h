@@ -193,7 +193,10 @@ NSS_API int nss_amg_apply_f64(nss_amg_t a, double bscale, const double* b, doubl
  * have A's / B's column count (n_u plus halo entries in a row-partitioned run); n_p for
  * u1,d1,w1,t3 ; s1 is the operand of B^T (B^T's column count).
  * scal: double[16] = { wd (even it), as_s, wdn, alpha, beta, err0, tol, rel_err(0/1), wd (odd it) };
- * ctrl: int32[4]  = { done, it_final, last_it, breakdown };  hist: double[maxsteps]. */
+ * ctrl: int32[8]  = { done, it_final, last_it, breakdown, pending, -, -, - }; `pending` = it + 1 while
+ * the velocity part of `u += alpha s` of iteration it waits for K1 of the next iteration (it reads s0
+ * anyway); nss_bpcg2_poll applies and clears it, so read the solution after a poll.
+ * hist: double[maxsteps]. */
 typedef struct nss_bpcg2_s {
   nss_csr_t A, B, BT;          /* A: n_u rows; B: n_p rows; BT: n_u rows (explicit transpose, :198) */
   const double* pre_diag;      /* point-Jacobi preA (inverse diagonal, n_u)  -- or NULL          */
@@ -224,7 +227,7 @@ enum {
   NSS_BPCG2_K3 = 3,    /* t3 = B t4, partials <s1, t3>                                                */
   NSS_BPCG2_SUM1 = 4,  /* scal[as_s] = local sum of the K2/K3 partials                               */
   NSS_BPCG2_ALPHA = 5, /* no-op: alpha = wd / as_s is evaluated inside K4                              */
-  NSS_BPCG2_K4 = 6,    /* alpha; u += a s, d -= a v, w -= a C^-1 v, partials <w, d>                  */
+  NSS_BPCG2_K4 = 6,    /* alpha; u1 += a s1 (u0: deferred to K1 / poll), d -= a v, w -= a C^-1 v, <w, d> */
   NSS_BPCG2_SUM2 = 7,  /* scal[wdn] = local sum of the K4 partials                                   */
   NSS_BPCG2_BETA = 8,  /* no-op: folded into K5                                                      */
   NSS_BPCG2_K5 = 9     /* beta = wdn / wd, s1 = beta s1 + w1, hist[it] = sqrt|wd|, stop test          */

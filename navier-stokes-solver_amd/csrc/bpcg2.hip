@@ -32,11 +32,17 @@ enum { S_WD = 0, S_AS = 1, S_WDN = 2, S_ALPHA = 3, S_BETA = 4, S_ERR0 = 5, S_TOL
 // wd of iteration `it` lives in slot S_WD (it even) or S_WD_ODD (it odd): K5 of iteration it writes
 // the slot of it+1 while its other lanes still read the slot of it.
 __device__ __forceinline__ int wd_slot(int it) { return (it & 1) ? S_WD_ODD : S_WD; }
-enum { C_DONE = 0, C_IT_FINAL = 1, C_LAST_IT = 2, C_BREAKDOWN = 3 };
+enum { C_DONE = 0, C_IT_FINAL = 1, C_LAST_IT = 2, C_BREAKDOWN = 3, C_PENDING = 4 };
+// C_PENDING: the velocity part of `u += alpha s` (:228) of iteration it is not done by K4 but by K1 of
+// iteration it + 1, which reads s0 anyway (one pass over n_u less per iteration).  K4 leaves
+// C_PENDING = it + 1; K1(it + 1) applies the update iff it finds its own iteration number there;
+// nss_bpcg2_poll applies what is still pending (loop frozen by the stop test, or maxsteps reached) and
+// clears the word, so the solution is complete whenever the host looks at it.
 
 struct EpiK1 {
   const int32_t* __restrict__ ctrl;
   const double* __restrict__ scal;
+  double* __restrict__ u0;
   double* __restrict__ q;
   double* __restrict__ z0;
   const double* __restrict__ t2;
@@ -46,17 +52,18 @@ struct EpiK1 {
   double* __restrict__ t1;
   const double* __restrict__ dinv;  // nullptr when preA is block-Jacobi
   double k;
-  int first;
+  int it;
   __device__ bool skip() const { return ctrl[C_DONE] != 0; }
   __device__ void row(int r, double bts) const {
     double qv = q[r];
-    if (!first) {
+    if (it != 0) {
       const double alpha = scal[S_ALPHA], beta = scal[S_BETA];
-      const double zo = z0[r], t2v = t2[r];
+      const double zo = z0[r], t2v = t2[r], so = s0[r];
+      if (ctrl[C_PENDING] == it) u0[r] = fma(alpha, so, u0[r]);   // deferred u += alpha s of iteration it - 1
       qv = fma(-alpha, t2v, fma(beta, qv, zo));
       z0[r] = fma(-alpha, t2v, zo);
       q[r] = qv;
-      s0[r] = fma(beta, s0[r], w0[r]);
+      s0[r] = fma(beta, so, w0[r]);
     }
     const double t = qv + bts;
     t0[r] = t;
@@ -211,16 +218,19 @@ __global__ __launch_bounds__(kBlock) void bpcg2_k4_kernel(K4Args a) {
       a.ctrl[C_BREAKDOWN] = 1;
       a.ctrl[C_IT_FINAL] = a.it;
       a.ctrl[C_DONE] = 1;
+      a.ctrl[C_PENDING] = 0;
     }
     return;
   }
   const double alpha = a.scal[wd_slot(a.it)] / as_s;
-  if (blockIdx.x == 0 && threadIdx.x == 0) a.scal[S_ALPHA] = alpha;   // K1 of the next iteration
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    a.scal[S_ALPHA] = alpha;          // K1 of the next iteration
+    a.ctrl[C_PENDING] = a.it + 1;     // ... which also applies u0 += alpha s0
+  }
   const int stride = gridDim.x * kBlock;
   double acc = 0.0;
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < a.n_u; i += stride) {
-    const double sv = a.s0[i], t0v = a.t0[i], t1v = a.t1[i], t2v = a.t2[i];
-    a.u0[i] = fma(alpha, sv, a.u0[i]);
+    const double t0v = a.t0[i], t1v = a.t1[i], t2v = a.t2[i];
     const double dn = fma(-alpha, t2v - t0v, a.d0[i]);
     const double wn = fma(-alpha, t1v, a.w0[i]);
     a.d0[i] = dn;
@@ -265,6 +275,18 @@ __global__ __launch_bounds__(kBlock) void bpcg2_k5_kernel(int32_t* __restrict__ 
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < n_p; i += stride) s1[i] = fma(beta, s1[i], w1[i]);
 }
 
+// what K1 of the next iteration would have done, for a loop that ends here
+__global__ __launch_bounds__(kBlock) void bpcg2_flush_kernel(const int32_t* __restrict__ ctrl,
+                                                              const double* __restrict__ scal, int32_t n_u,
+                                                              const double* __restrict__ s0, double* __restrict__ u0) {
+  if (ctrl[C_PENDING] == 0) return;
+  const double alpha = scal[S_ALPHA];
+  const int stride = gridDim.x * kBlock;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n_u; i += stride) u0[i] = fma(alpha, s0[i], u0[i]);
+}
+
+__global__ void bpcg2_flush_done_kernel(int32_t* __restrict__ ctrl) { ctrl[C_PENDING] = 0; }
+
 static int k4_grid(const nss_bpcg2_t& s) { return stream_grid(int64_t(s.n_u) + s.n_p, kBlock * 4); }
 
 void bpcg2_check_state(const nss_bpcg2_t* s) {
@@ -295,8 +317,8 @@ void bpcg2_spmv_phase(const nss_bpcg2_t& s, int which, int it, hipStream_t st, i
   switch (which) {
     case NSS_BPCG2_K1: {
       // the point-Jacobi apply rides in the epilogue unless an AMG term comes first
-      EpiK1 e{s.ctrl, s.scal, s.q, s.z0, s.t2, s.s0, s.w0, s.t0, s.t1,
-              (s.pre_amg || s.cond_HT) ? nullptr : s.pre_diag, s.k, it == 0 ? 1 : 0};
+      EpiK1 e{s.ctrl, s.scal, s.u0, s.q, s.z0, s.t2, s.s0, s.w0, s.t0, s.t1,
+              (s.pre_amg || s.cond_HT) ? nullptr : s.pre_diag, s.k, it};
       launch_csr_stream(*s.BT, s.s1, e, st, b0, b1);
       break;
     }
@@ -425,6 +447,12 @@ int nss_bpcg2_iterate(const nss_bpcg2_t* s, int32_t it_begin, int32_t it_end, ns
 int nss_bpcg2_poll(const nss_bpcg2_t* s, int32_t* done, int32_t* it_final, int32_t* last_it, nss_stream_t stream) {
   return guarded([&] {
     NSS_REQUIRE(s && s->ctrl, "bpcg2_poll: NULL state");
+    if (s->u0 && s->s0 && s->scal && s->n_u > 0) {       // complete the solution (see C_PENDING)
+      hipLaunchKernelGGL(bpcg2_flush_kernel, dim3(stream_grid(s->n_u, kBlock * 4)), dim3(kBlock), 0, as_stream(stream),
+                         s->ctrl, s->scal, s->n_u, s->s0, s->u0);
+      hipLaunchKernelGGL(bpcg2_flush_done_kernel, dim3(1), dim3(1), 0, as_stream(stream), s->ctrl);
+      NSS_CHECK_LAUNCH();
+    }
     int32_t h[4] = {0, 0, 0, 0};
     NSS_HIP(hipMemcpyAsync(h, s->ctrl, sizeof(int32_t) * 4, hipMemcpyDeviceToHost, as_stream(stream)));
     NSS_HIP(hipStreamSynchronize(as_stream(stream)));

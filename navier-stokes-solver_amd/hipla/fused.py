@@ -189,7 +189,7 @@ class Bpcg2Loop:
         self.partials = [eng.zeros(max(1, v.value)) for v in (na, nb, nc)]
         st.partials_a, st.partials_b, st.partials_c = (p.data_ptr() for p in self.partials)
         self.scal = eng.zeros(16)
-        self.ctrl = torch.zeros(4, dtype=torch.int32, device=eng.device)
+        self.ctrl = torch.zeros(8, dtype=torch.int32, device=eng.device)
         st.scal, st.ctrl = self.scal.data_ptr(), self.ctrl.data_ptr()
         self.hist = None
         self.state = st
