@@ -100,6 +100,9 @@ NSS_API int nss_csr_spgemm(nss_csr_t x, nss_csr_t y, int64_t max_products_per_pa
  * bits of offset, decoded through 16 per-block window bases), else 4.  The values and the order of
  * the products are the same either way. */
 NSS_API int nss_csr_index_width(nss_csr_t a, int32_t* bytes);
+/* the set-up entry points (nss_csr_spgemm, nss_csr_transpose, nss_amg_*) keep their multi-GB
+ * temporaries in a pool between calls; this returns the unused ones to the driver */
+NSS_API int nss_scratch_trim(void);
 /* copy the CSR arrays back to HOST buffers (rows+1 / nnz / nnz entries; sizes from nss_csr_info) */
 NSS_API int nss_csr_download(nss_csr_t a, int32_t* h_rowptr, int32_t* h_col, double* h_val);
 NSS_API int nss_csr_destroy(nss_csr_t a);

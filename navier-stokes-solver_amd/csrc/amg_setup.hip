@@ -31,15 +31,59 @@ namespace nss {
 
 namespace {
 
+// Scratch pool: the expand / sort / compress passes need multi-GB temporaries, and hipMalloc /
+// hipFree of such blocks cost far more than the kernels that use them (cfg5: 4.7 of 5.9 s of the
+// hierarchy build were allocation calls).  Temporaries therefore come from a grow-only list of
+// cached blocks that lives until nss_scratch_trim(); results that are handed to a CSR handle are
+// plain hipMalloc allocations of exactly their size.
+struct ScratchPool {
+  struct Block {
+    void* p;
+    size_t bytes;
+    bool used;
+  };
+  std::vector<Block> blocks;
+  void* get(size_t bytes) {
+    Block* best = nullptr;
+    for (Block& b : blocks)
+      if (!b.used && b.bytes >= bytes && (!best || b.bytes < best->bytes)) best = &b;
+    if (best && best->bytes <= 4 * bytes + (size_t(1) << 20)) {
+      best->used = true;
+      return best->p;
+    }
+    void* p = nullptr;
+    NSS_HIP(hipMalloc(&p, bytes));
+    blocks.push_back({p, bytes, true});
+    return p;
+  }
+  void put(void* p) {
+    for (Block& b : blocks)
+      if (b.p == p) b.used = false;
+  }
+  void trim() {
+    std::vector<Block> keep;
+    for (Block& b : blocks) {
+      if (b.used) keep.push_back(b);
+      else (void)hipFree(b.p);
+    }
+    blocks.swap(keep);
+  }
+};
+inline ScratchPool& pool() {
+  static ScratchPool p;
+  return p;
+}
+
 template <class T>
-struct Dev {  // owning device array
+struct Dev {  // owning device array; `result` arrays can be handed to a CSR handle with take()
   T* p = nullptr;
   size_t n = 0;
+  bool result = false;
   Dev() = default;
-  explicit Dev(size_t count) { alloc(count); }
+  explicit Dev(size_t count, bool is_result = false) : result(is_result) { alloc(count); }
   Dev(const Dev&) = delete;
   Dev& operator=(const Dev&) = delete;
-  Dev(Dev&& o) noexcept : p(o.p), n(o.n) {
+  Dev(Dev&& o) noexcept : p(o.p), n(o.n), result(o.result) {
     o.p = nullptr;
     o.n = 0;
   }
@@ -47,14 +91,19 @@ struct Dev {  // owning device array
   void alloc(size_t count) {
     release();
     n = count;
-    if (count) NSS_HIP(hipMalloc(&p, sizeof(T) * count));
+    if (!count) return;
+    if (result) NSS_HIP(hipMalloc(&p, sizeof(T) * count));
+    else p = static_cast<T*>(pool().get(sizeof(T) * count));
   }
   void release() {
-    if (p) (void)hipFree(p);
+    if (p) {
+      if (result) (void)hipFree(p);
+      else pool().put(p);
+    }
     p = nullptr;
     n = 0;
   }
-  T* take() {
+  T* take() {   // only for result arrays
     T* q = p;
     p = nullptr;
     n = 0;
@@ -387,7 +436,7 @@ nss_csr_s* adopt_csr(int32_t m, int32_t n, int64_t nnz, Dev<int32_t>& rowptr, De
   std::vector<int32_t> blk;
   int32_t rg = 1;
   plan_row_blocks(m, nnz, h_rowptr.data(), &rg, blk, nullptr, 0);
-  Dev<int32_t> rowblk(blk.size());
+  Dev<int32_t> rowblk(blk.size(), true);
   NSS_HIP(hipMemcpy(rowblk.p, blk.data(), sizeof(int32_t) * blk.size(), hipMemcpyHostToDevice));
   nss_csr_s* A = new nss_csr_s;
   A->m = m;
@@ -411,8 +460,8 @@ nss_csr_s* adopt_csr(int32_t m, int32_t n, int64_t nnz, Dev<int32_t>& rowptr, De
 struct RawCsr {
   int32_t m = 0, n = 0;
   int64_t nnz = 0;
-  Dev<int32_t> rowptr, col;
-  Dev<double> val;
+  Dev<int32_t> rowptr{0, true}, col{0, true};
+  Dev<double> val{0, true};
   nss_csr_s* adopt() { return adopt_csr(m, n, nnz, rowptr, col, val); }
 };
 
@@ -426,8 +475,8 @@ static void drop_zeros(RawCsr& c, hipStream_t st) {
   exclusive_sum(flag.p, pos.p, size_t(c.nnz) + 1, st);
   const int64_t kept = fetch(pos.p + c.nnz, st);
   if (kept == c.nnz) return;
-  Dev<int32_t> rowptr(size_t(c.m) + 1), col(size_t(kept) + 4);
-  Dev<double> val(size_t(kept) + 4);
+  Dev<int32_t> rowptr(size_t(c.m) + 1, true), col(size_t(kept) + 4, true);
+  Dev<double> val(size_t(kept) + 4, true);
   NSS_HIP(hipMemsetAsync(col.p, 0, sizeof(int32_t) * (size_t(kept) + 4), st));
   NSS_HIP(hipMemsetAsync(val.p, 0, sizeof(double) * (size_t(kept) + 4), st));
   hipLaunchKernelGGL(compact_kernel, dim3(grid_for(c.nnz)), dim3(kBlock), 0, st, c.nnz, flag.p, pos.p, c.col.p,
@@ -511,7 +560,7 @@ static void spgemm(const nss_csr_s& X, const nss_csr_s& Y, hipStream_t st, int64
                                     st));
   Dev<char> sort_tmp(sort_bytes);
   const uint64_t cmask = (uint64_t(1) << cbits) - 1;
-  Dev<int32_t> out_rowptr(size_t(m) + 1);
+  Dev<int32_t> out_rowptr(size_t(m) + 1, true);
   NSS_HIP(hipMemsetAsync(out_rowptr.p, 0, sizeof(int32_t) * (size_t(m) + 1), st));
 
   int64_t nnz = 0;
@@ -548,8 +597,8 @@ static void spgemm(const nss_csr_s& X, const nss_csr_s& Y, hipStream_t st, int64
     NSS_HIP(hipStreamSynchronize(st));
   }
   // one chunk: its arrays are the result (re-allocated with the 4 spare entries); several: concatenate
-  Dev<int32_t> out_col(size_t(nnz) + 4);
-  Dev<double> out_val(size_t(nnz) + 4);
+  Dev<int32_t> out_col(size_t(nnz) + 4, true);
+  Dev<double> out_val(size_t(nnz) + 4, true);
   NSS_HIP(hipMemsetAsync(out_col.p, 0, sizeof(int32_t) * (size_t(nnz) + 4), st));
   NSS_HIP(hipMemsetAsync(out_val.p, 0, sizeof(double) * (size_t(nnz) + 4), st));
   int64_t at = 0;
@@ -572,10 +621,10 @@ static nss_csr_s* transpose(const nss_csr_s& A, hipStream_t st) {
   const int32_t m = A.m, n = A.n;
   const int64_t nnz = A.nnz;
   NSS_REQUIRE(nnz < (int64_t(1) << 32), "transpose: too many non-zeros");
-  Dev<int32_t> cnt(size_t(n) + 1), trow(size_t(n) + 1);
+  Dev<int32_t> cnt(size_t(n) + 1), trow(size_t(n) + 1, true);
   NSS_HIP(hipMemsetAsync(cnt.p, 0, sizeof(int32_t) * (size_t(n) + 1), st));
-  Dev<int32_t> tcol(size_t(nnz) + 4);
-  Dev<double> tval(size_t(nnz) + 4);
+  Dev<int32_t> tcol(size_t(nnz) + 4, true);
+  Dev<double> tval(size_t(nnz) + 4, true);
   NSS_HIP(hipMemsetAsync(tcol.p, 0, sizeof(int32_t) * (size_t(nnz) + 4), st));
   NSS_HIP(hipMemsetAsync(tval.p, 0, sizeof(double) * (size_t(nnz) + 4), st));
   if (nnz > 0) {
@@ -627,6 +676,13 @@ int nss_csr_spgemm(nss_csr_t x, nss_csr_t y, int64_t max_products_per_pass, nss_
     spgemm(*x, *y, as_stream(stream), cap, c);
     drop_zeros(c, as_stream(stream));
     *out = c.adopt();
+  });
+}
+
+int nss_scratch_trim(void) {
+  return guarded([&] {
+    NSS_HIP(hipDeviceSynchronize());
+    pool().trim();
   });
 }
 
@@ -707,8 +763,8 @@ int nss_amg_prolongator(nss_csr_t a, const int64_t* d_agg, int64_t nagg, double 
     hipStream_t st = as_stream(stream);
     const int32_t m = a->m;
     // tentative prolongator T as a CSR matrix: row i has the single entry (agg[i], 1)
-    Dev<int32_t> trow(size_t(m) + 1), tcol(size_t(m) + 4);
-    Dev<double> tval(size_t(m) + 4);
+    Dev<int32_t> trow(size_t(m) + 1, true), tcol(size_t(m) + 4, true);
+    Dev<double> tval(size_t(m) + 4, true);
     {
       Dev<unsigned long long> bad(1);
       NSS_HIP(hipMemsetAsync(bad.p, 0, sizeof(unsigned long long), st));

@@ -45,6 +45,7 @@ def _signatures():
         "nss_csr_spgemm": (C.c_int, [vp, vp, i64, C.POINTER(vp), vp]),
         "nss_csr_download": (C.c_int, [vp, vp, vp, vp]),
         "nss_csr_index_width": (C.c_int, [vp, c_i32_p]),
+        "nss_scratch_trim": (C.c_int, []),
         "nss_reciprocal_f64": (C.c_int, [i64, vp, vp, vp]),
         "nss_amg_aggregate": (C.c_int, [vp, dbl, vp, vp, c_i64_p, vp]),
         "nss_amg_prolongator": (C.c_int, [vp, vp, i64, dbl, C.POINTER(vp), vp]),
@@ -356,6 +357,10 @@ class HipEngine:
 
     def index_to_host(self, buf):
         return buf.cpu().numpy()
+
+    def scratch_trim(self):
+        """Give the pooled set-up temporaries back to the driver."""
+        self._check(self.lib.nss_scratch_trim())
 
     def csr_spmv(self, h, alpha, x, beta, y):
         if x.shape[0] != h.n or y.shape[0] != h.m:
