@@ -737,6 +737,72 @@ def test_fused_minres_and_bpcg1_with_amg(hip_engine):
             assert n_f < 250                                   # AMG-preconditioned: far below the Jacobi counts
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_fused_loops_on_unstructured_saddle_systems(hip_engine, seed):
+    """Nothing in the fused loops knows about the MAC grid: random sparse SPD `A` with scattered
+    columns, random full-row-rank `B`, ragged rows and empty rows in
+    B^T; BPCG v2, BPCG v1 and MINRES against the oracle restatements on the same operands."""
+    import scipy.sparse as sp
+    import hipla
+    from oracle import krylov_ref as kr
+    from bramble_pasciak_cg import bramble_pasciak_cg
+    from minres import MinRes
+    from solvers.bramblepasciak_new import BramblePasciakCG
+    rng = np.random.default_rng(100 + seed)
+    n_u, n_p = 2500 + 300 * seed, 600 + 50 * seed
+    G = sp.random(n_u, n_u, density=4.0 / n_u, random_state=np.random.RandomState(seed), data_rvs=rng.standard_normal)
+    A = (G @ G.T + sp.diags(1.0 + rng.random(n_u))).tocsr()
+    A.sort_indices()
+    B = sp.random(n_p, n_u, density=5.0 / n_u, random_state=np.random.RandomState(seed + 7),
+                  data_rvs=rng.standard_normal).tolil()
+    for r in range(n_p):                                   # full row rank: a private column per row
+        B[r, r * (n_u // n_p)] = 2.0 + rng.random()
+    B = B.tocsr()
+    B.sort_indices()
+    assert np.diff(B.T.tocsr().indptr).min() == 0          # B^T has empty rows
+    f, g = rng.standard_normal(n_u), rng.standard_normal(n_p)
+    mass = 0.5 + rng.random(n_p)
+    Ad, Bd = hipla.SparseMatrix.from_scipy(A), hipla.SparseMatrix.from_scipy(B)
+    preA, preS = hipla.JacobiPreconditioner(Ad), hipla.DiagonalMatrix(1.0 / mass)
+    pa, ps = kr.jacobi(A), kr.diag_inverse(mass)
+    K = sp.bmat([[A, B.T], [B, None]], format="csr")
+    b = np.concatenate([f, g])
+    tol, maxsteps = 1e-9, 4000
+
+    # BPCG v2
+    sol = hipla.BlockVector([hipla.Vector(n_u), hipla.Vector(n_p)])
+    out = io.StringIO()
+    with contextlib.redirect_stdout(out):
+        it, _ = BramblePasciakCG(Form(Ad), Form(Bd), None, hipla.Vector.from_numpy(f), hipla.Vector.from_numpy(g), preA,
+                                 preS, sol, tol=tol, maxsteps=maxsteps)
+    hist = np.array([float(m) for m in re.findall(r"it =\s+\d+\s+err =\s+(\S+)", out.getvalue())])
+    from solvers.bramblepasciak_new import BpcgSession
+    with contextlib.redirect_stdout(io.StringIO()):
+        ses = BpcgSession(Form(Ad), Form(Bd), None, hipla.Vector.from_numpy(f), hipla.Vector.from_numpy(g), preA, preS)
+    assert ses.fused is not None
+    it_o, u_o, p_o, hist_o = kr.bpcg_v2(A, B, pa, ps, f, g, ses.k, tol=tol, maxsteps=maxsteps)[:4]
+    w = min(25, len(hist), len(hist_o))
+    np.testing.assert_allclose(hist[:w], hist_o[:w], rtol=1e-8)
+    assert abs(it - it_o) <= max(3, int(0.03 * it_o))
+    assert np.linalg.norm(b - K @ sol.numpy()) < 1e-6 * np.linalg.norm(b)
+
+    # BPCG v1 and MINRES: converge to the same solution as the oracle, same iteration counts
+    with contextlib.redirect_stdout(io.StringIO()):
+        x1, errs1 = bramble_pasciak_cg(Ad, Bd, None, preA, preS, hipla.Vector.from_numpy(f), hipla.Vector.from_numpy(g),
+                                       tolerance=tol, max_steps=maxsteps, print_rates=False)
+        um, errsm = MinRes(mat=hipla.BlockMatrix([[Ad, Bd.T], [Bd, None]]),
+                           pre=hipla.BlockMatrix([[preA, None], [None, preS]]),
+                           rhs=hipla.BlockVector([hipla.Vector.from_numpy(f), hipla.Vector.from_numpy(g)]),
+                           maxsteps=maxsteps, tol=tol, printrates=False)
+    assert errs1[-1] < tol and len(errs1) < maxsteps       # (v1 estimates its own scale factor: no oracle history)
+    for x in (x1.numpy(), um.numpy()):
+        assert np.linalg.norm(b - K @ x) < 1e-6 * np.linalg.norm(b)
+        assert np.linalg.norm(x - sol.numpy()) < 1e-5 * np.linalg.norm(sol.numpy())
+    errs_o = kr.minres(A, B, pa, ps, f, g, maxsteps=maxsteps, tol=tol)[2]
+    w = min(25, len(errsm), len(errs_o))
+    np.testing.assert_allclose(np.array(errsm)[:w], np.array(errs_o)[:w], rtol=1e-8)
+
+
 def test_time_stepping_on_gpu(hip_engine):
     """Scope row N4 on the product engine: CGSolver inner solves, Project and DoTimeStep keep the
     velocity discretely divergence-free and agree with the host computation."""
