@@ -207,6 +207,7 @@ def main():
     if partitioned:
         from distributed import DistributedBpcg2, TorchComm
         comm, comm_kind = None, "torch.distributed/" + backend
+        crosscheck_ms = {}
         if backend == "nccl" and os.environ.get("NSS_COMM", "rccl") == "rccl" and native_proven:
             try:                                   # RCCL straight through ctypes on the compute stream
                 from rccl_comm import RcclComm
@@ -225,16 +226,21 @@ def main():
         if comm is not None:
             # cross-check: a few iterations of the native loop (RCCL + halo overlap issued from C)
             # against the same iterations over torch.distributed collectives, from the same state
-            probe_its = 6
+            probe_its, timed_its = 6, 40
             hists = []
             try:
-                for c in (comm, torch_comm):
+                for label, c in (("native", comm), ("torch", torch_comm)):
                     with quiet:
                         probe = DistributedBpcg2(sysm, f, g, blocks, dist, eng, comm=c)
-                    probe.start(tol=0.0, maxsteps=probe_its)
+                    probe.start(tol=0.0, maxsteps=probe_its + timed_its)
                     probe.iterate(0, probe_its)
                     torch.cuda.synchronize()
                     hists.append(probe.history(probe_its - 1))
+                    dist.barrier()                       # diagnostics: what one iteration costs on either path
+                    t_probe = time.perf_counter()
+                    probe.iterate(probe_its, probe_its + timed_its)
+                    torch.cuda.synchronize()
+                    crosscheck_ms[label] = 1e3 * (time.perf_counter() - t_probe) / timed_its
                     del probe
                 same = bool(np.all(np.isfinite(hists[0])) and np.allclose(hists[0], hists[1], rtol=1e-9, atol=0.0))
             except Exception as exc:
@@ -266,7 +272,8 @@ def main():
         with quiet:
             run = DistributedBpcg2(sysm, f, g, blocks, dist, eng, comm=comm)
         if run.native is not None:
-            comm_kind += " + native loop (interior/boundary overlap)"
+            comm_kind += " + native loop (%s)" % ("exchange overlapped with the interior rows" if run.overlap
+                                                  else "exchange, then SpMV, on one stream")
         run.start(tol=0.0, maxsteps=total_its)
         run.iterate(0, W)
         torch.cuda.synchronize()
@@ -295,6 +302,7 @@ def main():
                                        % (args.n, sysm.ndof, args.pre, world),
                            "n_u": sysm.n_u, "n_p": sysm.n_p, "nnz_A": int(sysm.A.nnz), "nnz_B": int(sysm.B.nnz)},
                 "valid": ok, "halo_doubles_per_rank": run.halo_summary(), "comm": comm_kind,
+                "ms_per_iteration_by_path_rank0": crosscheck_ms or None, "native_path_rehearsed": bool(native_proven),
             }
             emit(result_fd, out)
         dist.destroy_process_group()
