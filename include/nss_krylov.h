@@ -222,6 +222,15 @@ typedef struct nss_bpcg2_s {
    * dofs): `t1 += H t1` runs in place. */
   nss_csr_t cond_HT, cond_H, cond_inner;   /* harmonic_extension_trans, harmonic_extension, inner_solve */
   double* cond_f;                          /* n_u work vector */
+  /* row-partitioned runs: ghost copies of s0 / w0 on the ghost columns of B's operand, updated
+   * redundantly with the same recurrences as the owned entries (w0_g -= alpha t1_g in K4, s0_g =
+   * beta s0_g + w0_g in K5), so that t4_g = t1_g - s0_g (end of K2) needs no halo exchange of its own:
+   * two exchanges per iteration instead of three.  ghost_map[i] = position of ghost i in the t1 operand
+   * buffer (whose ghost list must contain B's); the ghost tail of t4 follows its n_u owned entries.
+   * ghost_mode == 0: off (t4 is exchanged). */
+  int32_t ghost_mode, ghost_n;
+  const int32_t* ghost_map;
+  double *ghost_s0, *ghost_w0;
 } nss_bpcg2_t;
 
 enum {

@@ -80,6 +80,10 @@ struct EpiK2 {
   double* __restrict__ t2;
   double* __restrict__ t4;
   double* __restrict__ partials;
+  int32_t ghost_n;                          // partitioned runs: t4 on B's ghost columns (see nss_bpcg2_t)
+  const int32_t* __restrict__ ghost_map;
+  const double* __restrict__ ghost_s0;
+  double* __restrict__ ghost_t4;
   double acc = 0.0;
   __device__ bool skip() const { return ctrl[C_DONE] != 0; }
   struct Pre { double s0 = 0.0, t1 = 0.0, t0 = 0.0; };
@@ -92,6 +96,8 @@ struct EpiK2 {
   __device__ void finish(int b, double* lds) {
     const double s = block_sum(acc, lds);
     if (threadIdx.x == 0 && b >= 0) partials[b] = s;
+    const int stride = gridDim.x * kBlock;   // t1's ghosts arrived before this launch
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < ghost_n; i += stride) ghost_t4[i] = t1[ghost_map[i]] - ghost_s0[i];
   }
 };
 
@@ -204,6 +210,9 @@ struct K4Args {
   double *u0, *d0, *w0, *u1, *d1, *w1;
   const double *s0, *t0, *t1, *t2, *s1, *t3, *minv;
   double* partials;
+  int32_t ghost_n;
+  const int32_t* ghost_map;
+  double* ghost_w0;
 };
 
 __global__ __launch_bounds__(kBlock) void bpcg2_k4_kernel(K4Args a) {
@@ -246,6 +255,8 @@ __global__ __launch_bounds__(kBlock) void bpcg2_k4_kernel(K4Args a) {
     a.w1[i] = wn;
     acc = fma(wn, dn, acc);
   }
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < a.ghost_n; i += stride)   // ghost copies: same recurrence
+    a.ghost_w0[i] = fma(-alpha, a.t1[a.ghost_map[i]], a.ghost_w0[i]);
   const double s = block_sum(acc, lds);
   if (threadIdx.x == 0) a.partials[blockIdx.x] = s;
 }
@@ -255,7 +266,9 @@ __global__ __launch_bounds__(kBlock) void bpcg2_k4_kernel(K4Args a) {
 // freshly set `done` flag may skip the s1 update of this last iteration: s is not returned.
 __global__ __launch_bounds__(kBlock) void bpcg2_k5_kernel(int32_t* __restrict__ ctrl, double* __restrict__ scal,
                                                            double* __restrict__ hist, int32_t it, int32_t n_p,
-                                                           double* __restrict__ s1, const double* __restrict__ w1) {
+                                                           double* __restrict__ s1, const double* __restrict__ w1,
+                                                           int32_t ghost_n, double* __restrict__ ghost_s0,
+                                                           const double* __restrict__ ghost_w0) {
   if (ctrl[C_DONE] != 0) return;
   const double wd = scal[wd_slot(it)], wdn = scal[S_WDN];
   const double beta = wdn / wd;
@@ -273,6 +286,8 @@ __global__ __launch_bounds__(kBlock) void bpcg2_k5_kernel(int32_t* __restrict__ 
   }
   const int stride = gridDim.x * kBlock;
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < n_p; i += stride) s1[i] = fma(beta, s1[i], w1[i]);
+  // ghost copies of s0: what K1 of the next iteration does to the owned entries with this beta
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < ghost_n; i += stride) ghost_s0[i] = fma(beta, ghost_s0[i], ghost_w0[i]);
 }
 
 // what K1 of the next iteration would have done, for a loop that ends here
@@ -300,6 +315,9 @@ void bpcg2_check_state(const nss_bpcg2_t* s) {
   NSS_REQUIRE(!s->pre_bjac || s->pre_bjac->n == s->n_u, "bpcg2: block-Jacobi size mismatch");
   NSS_REQUIRE(s->minv && s->scal && s->ctrl && s->hist && s->partials_a && s->partials_b && s->partials_c,
               "bpcg2: NULL work buffer");
+  NSS_REQUIRE(!s->ghost_mode || s->ghost_n == 0 || (s->ghost_map && s->ghost_s0 && s->ghost_w0),
+              "bpcg2: ghost mode without ghost arrays");
+  NSS_REQUIRE(s->ghost_n >= 0, "bpcg2: negative ghost count");
   const bool cond = s->cond_HT || s->cond_H || s->cond_inner || s->cond_f;
   if (cond) {
     NSS_REQUIRE(s->cond_HT && s->cond_H && s->cond_inner && s->cond_f, "bpcg2: condensed form needs H^T, H, A_ii^-1 and a work vector");
@@ -323,7 +341,8 @@ void bpcg2_spmv_phase(const nss_bpcg2_t& s, int which, int it, hipStream_t st, i
       break;
     }
     case NSS_BPCG2_K2: {
-      EpiK2 e{s.ctrl, s.t0, s.t1, s.s0, s.t2, s.t4, s.partials_a};
+      EpiK2 e{s.ctrl, s.t0, s.t1, s.s0, s.t2, s.t4, s.partials_a, s.ghost_mode ? s.ghost_n : 0, s.ghost_map,
+              s.ghost_s0, s.t4 + s.n_u};
       launch_csr_stream(*s.A, s.t1, e, st, b0, b1);
       break;
     }
@@ -383,7 +402,8 @@ void bpcg2_phase(const nss_bpcg2_t& s, int which, int it, hipStream_t st) {
       break;
     case NSS_BPCG2_K4: {
       K4Args a{s.ctrl, s.scal, s.n_u, s.n_p, it, s.u0, s.d0, s.w0, s.u1, s.d1, s.w1,
-               s.s0, s.t0, s.t1, s.t2, s.s1, s.t3, s.minv, s.partials_c};
+               s.s0, s.t0, s.t1, s.t2, s.s1, s.t3, s.minv, s.partials_c, s.ghost_mode ? s.ghost_n : 0, s.ghost_map,
+               s.ghost_w0};
       hipLaunchKernelGGL(bpcg2_k4_kernel, dim3(k4_grid(s)), dim3(kBlock), 0, st, a);
       NSS_CHECK_LAUNCH();
       break;
@@ -397,7 +417,7 @@ void bpcg2_phase(const nss_bpcg2_t& s, int which, int it, hipStream_t st) {
       break;
     case NSS_BPCG2_K5:
       hipLaunchKernelGGL(bpcg2_k5_kernel, dim3(stream_grid(s.n_p, kBlock * 4)), dim3(kBlock), 0, st, s.ctrl, s.scal,
-                         s.hist, it, s.n_p, s.s1, s.w1);
+                         s.hist, it, s.n_p, s.s1, s.w1, s.ghost_mode ? s.ghost_n : 0, s.ghost_s0, s.ghost_w0);
       NSS_CHECK_LAUNCH();
       break;
     default:

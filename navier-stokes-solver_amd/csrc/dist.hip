@@ -1,6 +1,6 @@
 // Row-partitioned BPCG iteration with the communication issued natively.
 //
-// Why native: driving three halo exchanges and two all-reduces per iteration from Python costs
+// Why native: driving the halo exchanges and the two all-reduces of an iteration from Python costs
 // ~100 us of host time per iteration; with 8 GPUs the device side of an iteration of the
 // 1e7-DoF system is ~150 us, so the loop has to be issued from C.  RCCL is resolved at run time
 // from the librccl already loaded in the process (dlopen/dlsym: no link-time dependency; the
@@ -9,7 +9,7 @@
 // Per iteration (compute stream C, communication stream X, events):
 //   X: wait(C) . pack(s1) . group{send,recv} ;  C: K1 interior . wait(X) . K1 boundary . [block-Jacobi]
 //   X: wait(C) . pack(t1) . group{send,recv} ;  C: K2 interior . wait(X) . K2 boundary
-//   X: wait(C) . pack(t4) . group{send,recv} ;  C: K3 interior . wait(X) . K3 boundary
+//   X: wait(C) . pack(t4) . group{send,recv} ;  C: K3 interior . wait(X) . K3 boundary   (ghost mode: no exchange)
 //   C: SUM1 . allreduce(as_s) . K4 . SUM2 . allreduce(wdn) . K5
 // Interior row blocks touch no ghost column, so they overlap the exchange; xGMI is
 // point-to-point and only slab neighbours talk.  With overlap == 0 everything runs on C.
@@ -200,7 +200,8 @@ int nss_bpcg2_iterate_dist(const nss_bpcg2_t* s, nss_dist_t d, const nss_halo_t*
       spmv_with_halo(*s, *d, *halo_s1, 0, NSS_BPCG2_K1, it, *s->BT, ov, cs);
       bpcg2_k1_finish(*s, cs);
       spmv_with_halo(*s, *d, *halo_t1, 1, NSS_BPCG2_K2, it, *s->A, ov, cs);
-      spmv_with_halo(*s, *d, *halo_t4, 2, NSS_BPCG2_K3, it, *s->B, ov, cs);
+      if (s->ghost_mode) bpcg2_spmv_phase(*s, NSS_BPCG2_K3, it, cs, 0, -1);   // t4's ghosts were computed in K2
+      else spmv_with_halo(*s, *d, *halo_t4, 2, NSS_BPCG2_K3, it, *s->B, ov, cs);
       bpcg2_phase(*s, NSS_BPCG2_SUM1, it, cs);
       allreduce_slot(*s, *d, S_AS_SLOT, cs);
       bpcg2_phase(*s, NSS_BPCG2_K4, it, cs);       // alpha inside

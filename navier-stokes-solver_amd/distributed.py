@@ -36,10 +36,11 @@ def even_offsets(n, nranks):
     return np.round(np.arange(nranks + 1) * n / nranks).astype(np.int64)
 
 
-def localize_rows(mat, row_range, col_offsets, rank):
+def localize_rows(mat, row_range, col_offsets, rank, extra_ghosts=None):
     """Cut rows [r0, r1) out of the global CSR `mat` and renumber its columns for `rank`:
     owned columns -> [0, n_owned), ghost columns -> n_owned + position in the ghost list,
-    which is sorted by (owner rank, global index).  Returns (local csr, ghost global ids)."""
+    which is sorted by (owner rank, global index).  `extra_ghosts`: global ids to receive as well
+    although no row references them.  Returns (local csr, ghost global ids)."""
     r0, r1 = int(row_range[0]), int(row_range[1])
     c0, c1 = int(col_offsets[rank]), int(col_offsets[rank + 1])
     loc = sp.csr_matrix(mat[r0:r1, :])
@@ -47,6 +48,8 @@ def localize_rows(mat, row_range, col_offsets, rank):
     cols = loc.indices.astype(np.int64)
     owned = (cols >= c0) & (cols < c1)
     ghosts = np.unique(cols[~owned])            # global ids ascending == sorted by owner, then id
+    if extra_ghosts is not None and len(extra_ghosts):
+        ghosts = np.union1d(ghosts, np.asarray(extra_ghosts, dtype=np.int64))
     ghosts = densify_ghosts(ghosts, col_offsets)
     new = np.empty_like(cols)
     new[owned] = cols[owned] - c0
@@ -196,7 +199,7 @@ class DistSparseMatrix(BaseMatrix):
     are `HaloVector`s of this matrix are exchanged in place; any other vector is first
     copied into the matrix's private operand buffer."""
 
-    def __init__(self, global_csr, row_offsets, col_offsets, comm, engine=None):
+    def __init__(self, global_csr, row_offsets, col_offsets, comm, engine=None, extra_ghosts=None):
         super().__init__()
         self.comm = comm
         self.engine = engine if engine is not None else get_engine()
@@ -207,7 +210,8 @@ class DistSparseMatrix(BaseMatrix):
         self.n_rows = int(self.row_offsets[r + 1] - self.row_offsets[r])
         self.n_cols_owned = int(self.col_offsets[r + 1] - self.col_offsets[r])
         self.global_shape = global_csr.shape
-        loc, ghosts = localize_rows(global_csr, (self.row_offsets[r], self.row_offsets[r + 1]), self.col_offsets, r)
+        loc, ghosts = localize_rows(global_csr, (self.row_offsets[r], self.row_offsets[r + 1]), self.col_offsets, r,
+                                    extra_ghosts)
         self.local_scipy = loc
         self.local = SparseMatrix.from_scipy(loc, engine=self.engine)
         self.plan = HaloPlan(r, comm.size, self.n_cols_owned, ghosts, self.col_offsets)
@@ -433,8 +437,10 @@ class DistributedStokes:
         self.n_u, self.n_p = int(self.vel[r + 1] - self.vel[r]), int(self.prs[r + 1] - self.prs[r])
         BT = sysm.B.T.tocsr()
         BT.sort_indices()
-        self.A = DistSparseMatrix(sysm.A, self.vel, self.vel, comm, self.engine)
         self.B = DistSparseMatrix(sysm.B, self.prs, self.vel, comm, self.engine)
+        # A's operand also receives the ghost columns of B's operand: the fused loop then derives the
+        # ghosts of t4 = t1 - s0 locally instead of exchanging them (nss_bpcg2_t.ghost_mode)
+        self.A = DistSparseMatrix(sysm.A, self.vel, self.vel, comm, self.engine, extra_ghosts=self.B.plan.ghosts)
         self.BT = DistSparseMatrix(BT, self.vel, self.prs, comm, self.engine)
         self.B.attach_transpose(self.BT)
         v0, v1 = int(self.vel[r]), int(self.vel[r + 1])
@@ -485,7 +491,7 @@ class DistributedStokes:
 class DistributedBpcg2:
     """Row-partitioned Bramble-Pasciak CG (v2) on this rank: set-up through the operator
     protocol with distributed operands (halo + all_reduce inside ``Mult`` / inner product),
-    iteration through the fused device phases (``nss_bpcg2_phase``) with the three halo
+    iteration through the fused device phases (``nss_bpcg2_phase``) with the two halo
     exchanges and two all-reduces in between."""
 
     # (kind, argument): device phases between two communication points go down in one C call
@@ -540,6 +546,7 @@ class DistributedBpcg2:
         if self.loop is None:
             raise RuntimeError("fused distributed BPCG loop needs the HIP engine and native operands")
         self.halo = {"s1": (ops.BT, self.s1), "t1": (ops.A, self.t1), "t4": (ops.B, self.t4)}
+        self.ghost_mode = os.environ.get("NSS_GHOST_T4", "1") == "1" and self._setup_ghosts()
         self.native = None
         # 0: exchange, then one launch per SpMV, all on the compute stream.  1: exchange on a second
         # stream while the interior row blocks are multiplied.  Measured on one GPU at 1/8 of the
@@ -549,6 +556,34 @@ class DistributedBpcg2:
         comm_handle = getattr(self.comm, "comm", None)         # RcclComm: an ncclComm_t
         if comm_handle is not None and hasattr(self.loop.lib, "nss_bpcg2_iterate_dist"):
             self.enable_native(comm_handle)
+
+    def _setup_ghosts(self):
+        """Ghost copies of s0 / w0 on the ghost columns of B's operand (nss_bpcg2_t.ghost_*): every
+        ghost of B must also be a ghost of A's operand, which DistributedStokes arranges."""
+        ops, eng = self.ops, self.engine
+        gb, ga = ops.B.plan.ghosts, ops.A.plan.ghosts
+        pos = np.searchsorted(ga, gb)
+        if gb.size and (pos.max(initial=0) >= ga.size or not np.array_equal(ga[np.minimum(pos, ga.size - 1)], gb)):
+            return False
+        self._ghost_map = eng.index_buffer((ops.A.plan.n_owned + pos).astype(np.int32))
+        self._ghost_s0 = eng.zeros(max(1, gb.size))
+        self._ghost_w0 = eng.zeros(max(1, gb.size))
+        st = self.loop.state
+        st.ghost_mode, st.ghost_n = 1, int(gb.size)
+        st.ghost_map = self._ghost_map.data_ptr()
+        st.ghost_s0, st.ghost_w0 = self._ghost_s0.data_ptr(), self._ghost_w0.data_ptr()
+        self._ghost_tmp = ops.B.operand()
+        return True
+
+    def _fill_ghosts(self):
+        """Initial values of the ghost copies: one exchange each of s0 and w0 over B's halo plan."""
+        ops, eng = self.ops, self.engine
+        n_own, n_g = ops.B.plan.n_owned, ops.B.plan.n_ghost
+        for src, dst in ((self.vecs["s0"], self._ghost_s0), (self.vecs["w0"], self._ghost_w0)):
+            eng.copy(src.buf, self._ghost_tmp.buf)
+            ops.B.exchange(self._ghost_tmp)
+            if n_g:
+                eng.copy(eng.view(self._ghost_tmp.ext, n_own, n_own + n_g), eng.view(dst, 0, n_g))
 
     def enable_native(self, comm_handle, interior=None):
         """Issue the partitioned iterations from C (nss_bpcg2_iterate_dist): RCCL calls, halo
@@ -578,6 +613,8 @@ class DistributedBpcg2:
     def start(self, tol, maxsteps, rel_err=True):
         self.first_direction()
         self.loop.start(self.wdn, self.err0, tol, rel_err, maxsteps)
+        if self.ghost_mode:
+            self._fill_ghosts()
 
     def iterate(self, it_begin, it_end):
         if self.native is not None:
@@ -586,6 +623,8 @@ class DistributedBpcg2:
         loop, comm = self.loop, self.comm
         for it in range(it_begin, it_end):
             for kind, what in self.SCHEDULE:
+                if kind == "halo" and what == "t4" and self.ghost_mode:
+                    continue                             # t4's ghosts are derived from t1's in K2
                 if kind == "phases":
                     loop.phases(what[0], what[1], it)
                 elif kind == "halo":

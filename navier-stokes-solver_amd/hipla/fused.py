@@ -32,7 +32,9 @@ class Bpcg2State(C.Structure):
                 + [("scal", C.c_void_p), ("ctrl", C.c_void_p), ("hist", C.c_void_p),
                    ("partials_a", C.c_void_p), ("partials_b", C.c_void_p), ("partials_c", C.c_void_p),
                    ("k", C.c_double), ("n_u", C.c_int32), ("n_p", C.c_int32)]
-                + [(n, C.c_void_p) for n in ("cond_HT", "cond_H", "cond_inner", "cond_f")])
+                + [(n, C.c_void_p) for n in ("cond_HT", "cond_H", "cond_inner", "cond_f")]
+                + [("ghost_mode", C.c_int32), ("ghost_n", C.c_int32), ("ghost_map", C.c_void_p),
+                   ("ghost_s0", C.c_void_p), ("ghost_w0", C.c_void_p)])
 
 
 class HaloStruct(C.Structure):

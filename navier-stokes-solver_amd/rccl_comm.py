@@ -1,7 +1,7 @@
 """RCCL communicator driven through ctypes (no torch.distributed on the data path).
 
 `TorchComm` costs 30-60 us of host time per collective (c10d dispatch, work objects); with
-three halo exchanges and two all-reduces per Krylov iteration that makes an 8-GPU run
+two to three halo exchanges and two all-reduces per Krylov iteration that makes an 8-GPU run
 host-bound.  Here the same operations are issued straight into librccl on the compute stream
 (a handful of ctypes calls each): ``ncclAllReduce`` for the inner products and one
 ``ncclGroupStart / ncclSend.. / ncclRecv.. / ncclGroupEnd`` per halo exchange -- point-to-point
