@@ -7,7 +7,6 @@ oracle window at cfg4 (a dozen CPU iterations on the identical matrices)."""
 import contextlib
 import io
 import os
-import re
 
 import numpy as np
 import pytest

@@ -6,7 +6,6 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "navier-stokes-solver_amd"))
 
-import numpy as np
 
 import hipla
 from hipla import amg

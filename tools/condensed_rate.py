@@ -3,9 +3,7 @@ statement) next to the fused uncondensed loop:  python tools/condensed_rate.py [
 import contextlib
 import io
 import os
-import re
 import sys
-import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "navier-stokes-solver_amd"))

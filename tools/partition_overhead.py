@@ -11,7 +11,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "navier-stokes-solver_amd"))
 
-import numpy as np
 import torch
 import torch.distributed as dist
 
