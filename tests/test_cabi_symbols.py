@@ -53,6 +53,15 @@ def test_argument_errors_are_reported_not_thrown(lib):
     rc = lib.nss_csr_create(1, 1, 1, ctypes.addressof(rowptr), ctypes.addressof(col), ctypes.addressof(val),
                             ctypes.byref(out))
     assert rc != 0 and b"rowptr" in lib.nss_last_error()
+    # NULL handles / pointers of the set-up entry points are rejected before anything is launched
+    width = ctypes.c_int32()
+    assert lib.nss_csr_index_width(None, ctypes.byref(width)) != 0 and b"NULL" in lib.nss_last_error()
+    assert lib.nss_csr_spgemm(None, None, 0, ctypes.byref(out), None) != 0 and b"NULL" in lib.nss_last_error()
+    nagg = ctypes.c_int64()
+    assert lib.nss_amg_aggregate(None, 0.0, None, None, ctypes.byref(nagg), None) != 0
+    assert lib.nss_amg_prolongator(None, None, 1, 0.5, ctypes.byref(out), None) != 0
+    assert lib.nss_csr_download(None, None, None, None) != 0
+    assert lib.nss_csr_transpose(None, ctypes.byref(out)) != 0
 
 
 def test_product_engine_fails_loudly_without_gpu():
