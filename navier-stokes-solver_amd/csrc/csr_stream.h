@@ -42,7 +42,10 @@ namespace nss {
 #define NSS_STREAM_VEC2 0   // 1: 16-byte (val) / 8-byte (col) loads, two consecutive entries per lane
 #endif
 
-constexpr int kChunk = 2048;            // products staged per workgroup: 16 KiB of LDS
+#ifndef NSS_CHUNK
+#define NSS_CHUNK 2048
+#endif
+constexpr int kChunk = NSS_CHUNK;       // products staged per workgroup: 16 KiB of LDS
 constexpr int kMaxRowsPerBlock = 2048;  // bound for blocks of empty / very short rows
 constexpr int kXcds = 8;
 constexpr int kWindows = 16;          // column windows per row block of the 16-bit index stream
