@@ -100,6 +100,20 @@ NSS_API int nss_csr_spgemm(nss_csr_t x, nss_csr_t y, int64_t max_products_per_pa
  * bits of offset, decoded through 16 per-block window bases), else 4.  The values and the order of
  * the products are the same either way. */
 NSS_API int nss_csr_index_width(nss_csr_t a, int32_t* bytes);
+/* ---- multicolour ordering of the block Gauss-Seidel sweep, on the device (scope row N1) -------------
+ * nss_csr_ones_like: the pattern of `a` with every value 1 (products of patterns cannot cancel).
+ * nss_graph_color: colours (DEVICE int32[n] out) such that no two neighbours share one; every
+ *   colour is a maximal independent set of the still uncoloured nodes (Luby rounds with the
+ *   caller's distinct positive priorities, DEVICE int64[n]).  Neighbours = off-diagonal entries of
+ *   `g` and, when given, of `g_transposed` (structurally non-symmetric graphs).  Integer state only:
+ *   identical to hipla/coloring.py::color_blocks with the same priorities.
+ * nss_csr_select_rows: new matrix whose row r is row d_rows[r] of `a` (DEVICE int32[nrows]); the
+ *   launch plan does not span the ascending HOST row positions h_cuts (colour boundaries). */
+NSS_API int nss_csr_ones_like(nss_csr_t a, nss_csr_t* out, nss_stream_t stream);
+NSS_API int nss_graph_color(nss_csr_t g, nss_csr_t g_transposed, const int64_t* d_priority, int32_t* d_colors,
+                            int32_t* ncolors_out, nss_stream_t stream);
+NSS_API int nss_csr_select_rows(nss_csr_t a, int32_t nrows, const int32_t* d_rows, int32_t ncuts,
+                                const int32_t* h_cuts, nss_csr_t* out, nss_stream_t stream);
 /* the set-up entry points (nss_csr_spgemm, nss_csr_transpose, nss_amg_*) keep their multi-GB
  * temporaries in a pool between calls; this returns the unused ones to the driver */
 NSS_API int nss_scratch_trim(void);

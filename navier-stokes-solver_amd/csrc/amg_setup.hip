@@ -426,16 +426,97 @@ __global__ __launch_bounds__(kBlock) void permute_kernel(int64_t nnz, const uint
 }
 
 
+
+// ---- multicolour ordering (block Gauss-Seidel set-up) -------------------------------------------
+// max over the neighbours of row i in one or two graphs (second graph: the transpose, for a
+// structurally non-symmetric matrix); the diagonal is skipped, values are ignored
+__global__ __launch_bounds__(kBlock) void nbr_max_kernel(int32_t m, const int32_t* __restrict__ rp1,
+                                                          const int32_t* __restrict__ c1,
+                                                          const int32_t* __restrict__ rp2,
+                                                          const int32_t* __restrict__ c2,
+                                                          const int64_t* __restrict__ x, int64_t* __restrict__ y) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= m) return;
+  int64_t best = 0;
+  for (int p = rp1[i]; p < rp1[i + 1]; ++p)
+    if (c1[p] != i) best = max(best, x[c1[p]]);
+  if (rp2)
+    for (int p = rp2[i]; p < rp2[i + 1]; ++p)
+      if (c2[p] != i) best = max(best, x[c2[p]]);
+  y[i] = best;
+}
+
+// candidates of the current colour: priority of the uncoloured nodes, 0 for the others
+__global__ __launch_bounds__(kBlock) void color_reset_kernel(int32_t m, const int32_t* __restrict__ colors,
+                                                              const int64_t* __restrict__ priority,
+                                                              int64_t* __restrict__ pri,
+                                                              unsigned long long* __restrict__ count) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= m) return;
+  const bool open = colors[i] < 0;
+  pri[i] = open ? priority[i] : 0;
+  if (open) atomicAdd(count, 1ull);
+}
+
+// a candidate whose priority beats all neighbouring candidates takes the colour
+__global__ __launch_bounds__(kBlock) void color_win_kernel(int32_t m, const int64_t* __restrict__ pri,
+                                                            const int64_t* __restrict__ nmax, int32_t color,
+                                                            int32_t* __restrict__ colors, int64_t* __restrict__ win) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= m) return;
+  const bool w = pri[i] > 0 && pri[i] > nmax[i];
+  win[i] = w ? 1 : 0;
+  if (w) colors[i] = color;
+}
+
+// winners and their neighbours stop being candidates of this colour
+__global__ __launch_bounds__(kBlock) void color_drop_kernel(int32_t m, const int64_t* __restrict__ win,
+                                                             const int64_t* __restrict__ hit, int64_t* __restrict__ pri,
+                                                             unsigned long long* __restrict__ remaining) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= m) return;
+  if (win[i] || hit[i] > 0) pri[i] = 0;
+  if (pri[i] > 0) atomicAdd(remaining, 1ull);
+}
+
+__global__ __launch_bounds__(kBlock) void ones_kernel(int64_t n, double* __restrict__ v) {
+  const int64_t p = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+  if (p < n) v[p] = 1.0;
+}
+
+__global__ __launch_bounds__(kBlock) void row_length_kernel(int32_t m, const int32_t* __restrict__ rowptr,
+                                                             const int32_t* __restrict__ rows,
+                                                             int32_t* __restrict__ len) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i < m) len[i] = rowptr[rows[i] + 1] - rowptr[rows[i]];
+}
+
+__global__ __launch_bounds__(kBlock) void row_copy_kernel(int32_t m, const int32_t* __restrict__ rowptr,
+                                                           const int32_t* __restrict__ col,
+                                                           const double* __restrict__ val,
+                                                           const int32_t* __restrict__ rows,
+                                                           const int32_t* __restrict__ out_rowptr,
+                                                           int32_t* __restrict__ out_col, double* __restrict__ out_val) {
+  const int i = blockIdx.x * (kBlock / 8) + threadIdx.x / 8;     // 8 lanes per row
+  if (i >= m) return;
+  const int src = rowptr[rows[i]], n = rowptr[rows[i] + 1] - src, dst = out_rowptr[i];
+  for (int k = threadIdx.x & 7; k < n; k += 8) {
+    out_col[dst + k] = col[src + k];
+    out_val[dst + k] = val[src + k];
+  }
+}
+
 }  // namespace
 
 // Build the handle around device arrays (ownership passes to the handle).  col / val must have
 // been allocated with 4 spare entries (see nss_csr_create_cuts).
-nss_csr_s* adopt_csr(int32_t m, int32_t n, int64_t nnz, Dev<int32_t>& rowptr, Dev<int32_t>& col, Dev<double>& val) {
+nss_csr_s* adopt_csr(int32_t m, int32_t n, int64_t nnz, Dev<int32_t>& rowptr, Dev<int32_t>& col, Dev<double>& val,
+                     const int32_t* cuts = nullptr, int ncuts = 0) {
   std::vector<int32_t> h_rowptr(size_t(m) + 1);
   NSS_HIP(hipMemcpy(h_rowptr.data(), rowptr.p, sizeof(int32_t) * (size_t(m) + 1), hipMemcpyDeviceToHost));
   std::vector<int32_t> blk;
   int32_t rg = 1;
-  plan_row_blocks(m, nnz, h_rowptr.data(), &rg, blk, nullptr, 0);
+  plan_row_blocks(m, nnz, h_rowptr.data(), &rg, blk, cuts, ncuts);
   Dev<int32_t> rowblk(blk.size(), true);
   NSS_HIP(hipMemcpy(rowblk.p, blk.data(), sizeof(int32_t) * blk.size(), hipMemcpyHostToDevice));
   nss_csr_s* A = new nss_csr_s;
@@ -676,6 +757,96 @@ int nss_csr_spgemm(nss_csr_t x, nss_csr_t y, int64_t max_products_per_pass, nss_
     spgemm(*x, *y, as_stream(stream), cap, c);
     drop_zeros(c, as_stream(stream));
     *out = c.adopt();
+  });
+}
+
+int nss_csr_ones_like(nss_csr_t a, nss_csr_t* out, nss_stream_t stream) {
+  return guarded([&] {
+    NSS_REQUIRE(a != nullptr && out != nullptr, "csr_ones_like: NULL argument");
+    hipStream_t st = as_stream(stream);
+    Dev<int32_t> rowptr(size_t(a->m) + 1, true), col(size_t(a->nnz) + 4, true);
+    Dev<double> val(size_t(a->nnz) + 4, true);
+    NSS_HIP(hipMemcpyAsync(rowptr.p, a->rowptr, sizeof(int32_t) * (size_t(a->m) + 1), hipMemcpyDeviceToDevice, st));
+    NSS_HIP(hipMemsetAsync(col.p, 0, sizeof(int32_t) * (size_t(a->nnz) + 4), st));
+    NSS_HIP(hipMemsetAsync(val.p, 0, sizeof(double) * (size_t(a->nnz) + 4), st));
+    if (a->nnz > 0) {
+      NSS_HIP(hipMemcpyAsync(col.p, a->col, sizeof(int32_t) * a->nnz, hipMemcpyDeviceToDevice, st));
+      hipLaunchKernelGGL(ones_kernel, dim3(grid_for(a->nnz)), dim3(kBlock), 0, st, a->nnz, val.p);
+      NSS_CHECK_LAUNCH();
+    }
+    NSS_HIP(hipStreamSynchronize(st));
+    *out = adopt_csr(a->m, a->n, a->nnz, rowptr, col, val);
+  });
+}
+
+int nss_csr_select_rows(nss_csr_t a, int32_t nrows, const int32_t* d_rows, int32_t ncuts, const int32_t* h_cuts,
+                        nss_csr_t* out, nss_stream_t stream) {
+  return guarded([&] {
+    NSS_REQUIRE(a != nullptr && out != nullptr && nrows >= 0 && (nrows == 0 || d_rows != nullptr),
+                "csr_select_rows: NULL argument");
+    NSS_REQUIRE(ncuts >= 0 && (ncuts == 0 || h_cuts != nullptr), "csr_select_rows: bad cuts");
+    for (int i = 0; i < ncuts; ++i)
+      NSS_REQUIRE(h_cuts[i] >= 0 && h_cuts[i] <= nrows && (i == 0 || h_cuts[i] >= h_cuts[i - 1]),
+                  "csr_select_rows: cuts must be ascending row positions");
+    hipStream_t st = as_stream(stream);
+    Dev<int32_t> len(size_t(nrows) + 1), rowptr(size_t(nrows) + 1, true);
+    NSS_HIP(hipMemsetAsync(len.p, 0, sizeof(int32_t) * (size_t(nrows) + 1), st));
+    if (nrows > 0) {
+      hipLaunchKernelGGL(row_length_kernel, dim3(grid_for(nrows)), dim3(kBlock), 0, st, nrows, a->rowptr, d_rows, len.p);
+      NSS_CHECK_LAUNCH();
+    }
+    exclusive_sum(len.p, rowptr.p, size_t(nrows) + 1, st);
+    const int64_t nnz = fetch(rowptr.p + nrows, st);
+    Dev<int32_t> col(size_t(nnz) + 4, true);
+    Dev<double> val(size_t(nnz) + 4, true);
+    NSS_HIP(hipMemsetAsync(col.p, 0, sizeof(int32_t) * (size_t(nnz) + 4), st));
+    NSS_HIP(hipMemsetAsync(val.p, 0, sizeof(double) * (size_t(nnz) + 4), st));
+    if (nrows > 0 && nnz > 0) {
+      hipLaunchKernelGGL(row_copy_kernel, dim3((nrows + kBlock / 8 - 1) / (kBlock / 8)), dim3(kBlock), 0, st, nrows,
+                         a->rowptr, a->col, a->val, d_rows, rowptr.p, col.p, val.p);
+      NSS_CHECK_LAUNCH();
+    }
+    NSS_HIP(hipStreamSynchronize(st));
+    *out = adopt_csr(nrows, a->n, nnz, rowptr, col, val, h_cuts, ncuts);
+  });
+}
+
+int nss_graph_color(nss_csr_t g, nss_csr_t g_transposed, const int64_t* d_priority, int32_t* d_colors,
+                    int32_t* ncolors_out, nss_stream_t stream) {
+  return guarded([&] {
+    NSS_REQUIRE(g != nullptr && d_priority != nullptr && d_colors != nullptr && ncolors_out != nullptr,
+                "graph_color: NULL argument");
+    NSS_REQUIRE(g->m == g->n && (!g_transposed || (g_transposed->m == g->m && g_transposed->n == g->n)),
+                "graph_color: the graph must be square");
+    hipStream_t st = as_stream(stream);
+    const int32_t m = g->m;
+    *ncolors_out = 0;
+    if (m == 0) return;
+    const int32_t* rp2 = g_transposed ? g_transposed->rowptr : nullptr;
+    const int32_t* c2 = g_transposed ? g_transposed->col : nullptr;
+    Dev<int64_t> pri(m), nmax(m), win(m), hit(m);
+    Dev<unsigned long long> counter(1);
+    const dim3 grid(grid_for(m)), block(kBlock);
+    NSS_HIP(hipMemsetAsync(d_colors, 0xff, sizeof(int32_t) * m, st));      // -1: uncoloured
+    for (int32_t color = 0; color <= m; ++color) {
+      NSS_HIP(hipMemsetAsync(counter.p, 0, sizeof(unsigned long long), st));
+      hipLaunchKernelGGL(color_reset_kernel, grid, block, 0, st, m, d_colors, d_priority, pri.p, counter.p);
+      NSS_CHECK_LAUNCH();
+      if (fetch(counter.p, st) == 0) {
+        *ncolors_out = color;
+        return;
+      }
+      for (int round = 0; round <= m; ++round) {         // Luby rounds: a maximal independent set of the rest
+        hipLaunchKernelGGL(nbr_max_kernel, grid, block, 0, st, m, g->rowptr, g->col, rp2, c2, pri.p, nmax.p);
+        hipLaunchKernelGGL(color_win_kernel, grid, block, 0, st, m, pri.p, nmax.p, color, d_colors, win.p);
+        hipLaunchKernelGGL(nbr_max_kernel, grid, block, 0, st, m, g->rowptr, g->col, rp2, c2, win.p, hit.p);
+        NSS_HIP(hipMemsetAsync(counter.p, 0, sizeof(unsigned long long), st));
+        hipLaunchKernelGGL(color_drop_kernel, grid, block, 0, st, m, win.p, hit.p, pri.p, counter.p);
+        NSS_CHECK_LAUNCH();
+        if (fetch(counter.p, st) == 0) break;
+      }
+    }
+    throw Error("graph_color: did not terminate");
   });
 }
 

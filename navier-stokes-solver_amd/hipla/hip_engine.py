@@ -46,6 +46,9 @@ def _signatures():
         "nss_csr_download": (C.c_int, [vp, vp, vp, vp]),
         "nss_csr_index_width": (C.c_int, [vp, c_i32_p]),
         "nss_scratch_trim": (C.c_int, []),
+        "nss_csr_ones_like": (C.c_int, [vp, C.POINTER(vp), vp]),
+        "nss_graph_color": (C.c_int, [vp, vp, vp, vp, c_i32_p, vp]),
+        "nss_csr_select_rows": (C.c_int, [vp, i32, vp, i32, vp, C.POINTER(vp), vp]),
         "nss_reciprocal_f64": (C.c_int, [i64, vp, vp, vp]),
         "nss_amg_aggregate": (C.c_int, [vp, dbl, vp, vp, c_i64_p, vp]),
         "nss_amg_prolongator": (C.c_int, [vp, vp, i64, dbl, C.POINTER(vp), vp]),
@@ -357,6 +360,36 @@ class HipEngine:
 
     def index_to_host(self, buf):
         return buf.cpu().numpy()
+
+    # ---- multicolour ordering on the device ------------------------------------------------------
+    def csr_ones_like(self, h):
+        out = C.c_void_p()
+        self._check(self.lib.nss_csr_ones_like(h.ptr, C.byref(out), self.stream))
+        return self._wrap_csr(out)
+
+    def graph_color(self, g, g_transposed, priority):
+        """Colours (host int32 array) of the graph `g` (+ its transpose), `nss_graph_color`."""
+        priority = np.ascontiguousarray(priority, dtype=np.int64)
+        if priority.shape != (g.m,):
+            raise ValueError("one priority per node expected")
+        pri = self.torch.from_numpy(priority).to(self.device)
+        colors = self.torch.empty(g.m, dtype=self.torch.int32, device=self.device)
+        ncolors = C.c_int32()
+        self._check(self.lib.nss_graph_color(g.ptr, g_transposed.ptr if g_transposed is not None else None,
+                                             pri.data_ptr(), colors.data_ptr(), C.byref(ncolors), self.stream))
+        return colors.cpu().numpy(), int(ncolors.value)
+
+    def csr_select_rows(self, h, rows, cuts=None):
+        """New matrix whose row r is row rows[r] of `h`; the launch plan respects `cuts`."""
+        rows = np.ascontiguousarray(rows, dtype=np.int32)
+        if rows.size and (rows.min() < 0 or rows.max() >= h.m):
+            raise ValueError("row index out of range")
+        cuts = np.zeros(0, dtype=np.int32) if cuts is None else np.ascontiguousarray(cuts, dtype=np.int32)
+        drows = self.torch.from_numpy(rows).to(self.device)
+        out = C.c_void_p()
+        self._check(self.lib.nss_csr_select_rows(h.ptr, rows.size, drows.data_ptr() if rows.size else None, cuts.size,
+                                                 cuts.ctypes.data if cuts.size else None, C.byref(out), self.stream))
+        return self._wrap_csr(out)
 
     def scratch_trim(self):
         """Give the pooled set-up temporaries back to the driver."""

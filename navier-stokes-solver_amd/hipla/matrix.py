@@ -632,10 +632,16 @@ class BlockGaussSeidel(BaseMatrix):
         self.mat = mat
         self.n = mat.height
         base = BlockJacobi._as_table(blocks)
-        graph = coloring.block_graph(mat.to_scipy(), base)
-        colors = coloring.color_blocks(graph, seed) if colors is None else np.asarray(colors, dtype=np.int32)
-        if colors.shape != (base.shape[1],) or not coloring.check_coloring(graph, colors):
-            raise RuntimeError("block colouring is not proper")
+        on_device = colors is None and hasattr(self.engine, "graph_color")
+        if on_device:
+            # block graph (two sparse products of patterns) and Luby colouring on the GPU: a proper
+            # colouring by construction (of two adjacent candidates only the higher priority wins)
+            colors = self._device_colors(mat, base, seed)
+        else:
+            graph = coloring.block_graph(mat.to_scipy(), base)
+            colors = coloring.color_blocks(graph, seed) if colors is None else np.asarray(colors, dtype=np.int32)
+            if colors.shape != (base.shape[1],) or not coloring.check_coloring(graph, colors):
+                raise RuntimeError("block colouring is not proper")
         order, ptr = coloring.colour_major_order(colors)
         self.idx_host = np.ascontiguousarray(base[:, order])
         self.color_ptr = ptr
@@ -651,12 +657,36 @@ class BlockGaussSeidel(BaseMatrix):
         rows_per_block = live.sum(axis=1)
         block_row0 = np.concatenate([[0], np.cumsum(rows_per_block)])
         color_rowptr = block_row0[ptr]
-        perm = mat.to_scipy()[rowdof]
-        perm.sort_indices()
-        self.perm_handle = self.engine.csr_create(perm.shape[0], perm.shape[1], perm.indptr, perm.indices, perm.data,
-                                                  cuts=color_rowptr)
+        if hasattr(self.engine, "csr_select_rows"):
+            self.perm_handle = self.engine.csr_select_rows(mat.handle, rowdof, cuts=color_rowptr)
+        else:
+            perm = mat.to_scipy()[rowdof]
+            perm.sort_indices()
+            self.perm_handle = self.engine.csr_create(perm.shape[0], perm.shape[1], perm.indptr, perm.indices,
+                                                      perm.data, cuts=color_rowptr)
         self.engine.bjac_set_colors(self.handle, self.perm_handle, ptr, color_rowptr, rowdof,
                                     np.ascontiguousarray(ridx.T))
+
+    @staticmethod
+    def _device_colors(mat, base, seed):
+        """Colours of the blocks `base` (bs x nblocks table): adjacency M^T |A| M of the blocks by two
+        device SpGEMMs over 0/1 patterns (no cancellation), then `nss_graph_color` with the priorities
+        `coloring.color_blocks` would use -- the result equals the host colouring."""
+        import scipy.sparse as sp
+        eng = mat.engine
+        n, nb = mat.height, base.shape[1]
+        live = base >= 0
+        dofs = base[live]
+        blocks = np.broadcast_to(np.arange(nb, dtype=np.int64), base.shape)[live]
+        member = SparseMatrix.from_scipy(sp.csr_matrix((np.ones(dofs.size), (dofs, blocks)), shape=(n, nb)), engine=eng)
+        pattern = eng.csr_ones_like(mat.handle)
+        graph = SparseMatrix.from_handle(
+            eng.csr_spgemm(member.CreateTranspose().handle, eng.csr_spgemm(pattern, member.handle)), eng)
+        priority = np.random.default_rng(seed).permutation(nb).astype(np.int64) + 1
+        colors, _ = eng.graph_color(graph.handle, graph.CreateTranspose().handle, priority)
+        if hasattr(eng, "scratch_trim"):
+            eng.scratch_trim()
+        return colors
 
     def Height(self):
         return self.n

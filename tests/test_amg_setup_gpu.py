@@ -126,3 +126,36 @@ def test_hierarchy_built_on_device_equals_cpu_hierarchy(hip_engine, numpy_engine
             _same_csr(d["R"], c["R"].to_scipy())
         else:
             _same_csr(d["inv"], c["inv"].to_scipy())
+
+
+def test_device_colouring_and_row_selection(hip_engine):
+    """Multicolour ordering on the device (nss_csr_ones_like + two sparse products + nss_graph_color)
+    gives exactly the colours of the host algorithm (hipla/coloring.py) with the same priorities,
+    and nss_csr_select_rows the row-permuted matrix scipy builds."""
+    import hipla
+    from hipla import coloring
+    for dim, n, bs in ((2, 24, 3), (3, 10, 3), (3, 8, 1)):
+        s = mac_stokes(dim, n, 0.01)
+        A = s.A.tocsr()
+        A.sort_indices()
+        idx = s.line_blocks(bs)
+        Ad = hipla.SparseMatrix.from_scipy(A)
+        dev = hipla.BlockGaussSeidel._device_colors(Ad, idx, 0)
+        graph = coloring.block_graph(A, idx)
+        host = coloring.color_blocks(graph, 0)
+        np.testing.assert_array_equal(dev, host)
+        assert coloring.check_coloring(graph, dev)
+        rng = np.random.default_rng(dim)
+        rows = rng.permutation(A.shape[0])[: A.shape[0] * 2 // 3].astype(np.int32)
+        cuts = np.array([0, rows.size // 3, rows.size], dtype=np.int32)
+        sel = hipla.SparseMatrix.from_handle(hip_engine.csr_select_rows(Ad.handle, rows, cuts))
+        _same_csr(sel, A[rows])
+        rb = sel.handle.row_blocks()
+        assert rows.size // 3 in rb                      # the launch plan does not span a colour boundary
+    # structurally non-symmetric matrix: neighbours through the transposed graph as well
+    M = sp.csr_matrix(np.array([[2.0, 1, 0, 0], [0, 2, 1, 0], [0, 0, 2, 1], [0, 0, 0, 2]]))
+    g = hipla.SparseMatrix.from_scipy(M)
+    colors, ncol = hip_engine.graph_color(g.handle, g.CreateTranspose().handle, np.array([4, 3, 2, 1], dtype=np.int64))
+    assert ncol == 2 and all(colors[i] != colors[i + 1] for i in range(3))
+    pat = hipla.SparseMatrix.from_handle(hip_engine.csr_ones_like(g.handle))
+    np.testing.assert_array_equal(pat.to_scipy().toarray(), (M.toarray() != 0).astype(float))
