@@ -9,6 +9,8 @@ struct nss_bjac_s {
   int32_t bs = 0, nblocks = 0;
   int64_t n = 0;
   int32_t* idx = nullptr;      // [bs][nblocks], -1 = padding
+  int32_t* run = nullptr;      // [nblocks]: first dof * 32 + length, when every block is a run of
+                               // consecutive dofs (4 bytes per block instead of 4 per dof)
   double* inv = nullptr;       // [bs*bs][nblocks]
   double* inv_sym = nullptr;   // [bs*(bs+1)/2][nblocks]: upper triangles, when every inverse block is
                                // symmetric (A symmetric): the apply kernel then reads ~half the bytes

@@ -96,6 +96,7 @@ __global__ __launch_bounds__(kBlock) void bjac_pack_sym_kernel(int bs, int32_t n
 // symmetric inverse blocks: every stored entry is read once and used for both triangles
 template <int BS>
 __global__ __launch_bounds__(kBlock) void bjac_apply_sym_kernel(int32_t nb, const int32_t* __restrict__ idx,
+                                                                 const int32_t* __restrict__ run,
                                                                  const double* __restrict__ packed, double alpha,
                                                                  const double* __restrict__ x, double beta,
                                                                  double* __restrict__ y,
@@ -105,8 +106,14 @@ __global__ __launch_bounds__(kBlock) void bjac_apply_sym_kernel(int32_t nb, cons
   for (int b = blockIdx.x * kBlock + threadIdx.x; b < nb; b += stride) {
     int32_t dof[BS];
     double xv[BS], s[BS];
+    if (run) {                                   // consecutive dofs: one word per block
+      const int32_t w = run[b], first = w >> 5, len = w & 31;
 #pragma unroll
-    for (int c = 0; c < BS; ++c) dof[c] = idx[size_t(c) * nb + b];
+      for (int c = 0; c < BS; ++c) dof[c] = c < len ? first + c : -1;
+    } else {
+#pragma unroll
+      for (int c = 0; c < BS; ++c) dof[c] = idx[size_t(c) * nb + b];
+    }
 #pragma unroll
     for (int c = 0; c < BS; ++c) {
       xv[c] = dof[c] >= 0 ? x[dof[c]] : 0.0;
@@ -257,8 +264,8 @@ static void launch_bjac(const nss_bjac_s& j, double alpha, const double* x, doub
                         const int32_t* done, hipStream_t st) {
   const int grid = stream_grid(j.nblocks, kBlock);
   if (j.inv_sym)
-    hipLaunchKernelGGL((bjac_apply_sym_kernel<BS>), dim3(grid), dim3(kBlock), 0, st, j.nblocks, j.idx, j.inv_sym, alpha,
-                       x, beta, y, done);
+    hipLaunchKernelGGL((bjac_apply_sym_kernel<BS>), dim3(grid), dim3(kBlock), 0, st, j.nblocks, j.idx, j.run,
+                       j.inv_sym, alpha, x, beta, y, done);
   else
     hipLaunchKernelGGL((bjac_apply_kernel<BS>), dim3(grid), dim3(kBlock), 0, st, j.nblocks, j.idx, j.inv, alpha, x,
                        beta, y, done);
@@ -324,6 +331,26 @@ int nss_bjac_create(nss_csr_t a, int32_t bs, int32_t nblocks, const int32_t* h_i
         NSS_HIP(hipMalloc(&j->covered, sizeof(int32_t) * uncovered.size()));
         NSS_HIP(hipMemcpy(j->covered, uncovered.data(), sizeof(int32_t) * uncovered.size(), hipMemcpyHostToDevice));
       }
+      {   // blocks that are runs of consecutive dofs (padding last): one packed word per block
+        std::vector<int32_t> runs{};
+        runs.resize(size_t(nblocks));
+        bool all_runs = a->m < (1 << 26);
+        for (int32_t b = 0; b < nblocks && all_runs; ++b) {
+          const int32_t first = h_idx[b];
+          int len = 0;
+          while (len < bs && h_idx[size_t(len) * nblocks + b] >= 0) ++len;
+          all_runs = first >= 0 && len > 0;
+          for (int c = 0; c < bs && all_runs; ++c) {
+            const int32_t d = h_idx[size_t(c) * nblocks + b];
+            all_runs = c < len ? d == first + c : d < 0;
+          }
+          runs[b] = first * 32 + len;
+        }
+        if (all_runs) {
+          NSS_HIP(hipMalloc(&j->run, sizeof(int32_t) * size_t(nblocks)));
+          NSS_HIP(hipMemcpy(j->run, runs.data(), sizeof(int32_t) * size_t(nblocks), hipMemcpyHostToDevice));
+        }
+      }
       NSS_HIP(hipMalloc(&singular, sizeof(int32_t)));
       NSS_HIP(hipMemset(singular, 0, sizeof(int32_t)));
       hipLaunchKernelGGL(bjac_setup_kernel, dim3((nblocks + kBlock - 1) / kBlock), dim3(kBlock), 0, nullptr, bs,
@@ -367,6 +394,7 @@ int nss_bjac_destroy(nss_bjac_t j) {
     (void)hipFree(j->idx);
     (void)hipFree(j->inv);
     (void)hipFree(j->inv_sym);
+    (void)hipFree(j->run);
     (void)hipFree(j->covered);
     (void)hipFree(j->rowdof);
     (void)hipFree(j->ridx);
