@@ -86,23 +86,26 @@ def event_time_ms(torch, fn, reps):
     return start.elapsed_time(stop) / reps
 
 
-PROBE_OK, PROBE_FELL_BACK = 0, 7
+TIERS = ("torch", "rccl-python", "native")     # data paths of a multi-rank run, slowest first
+TIER_MARK = "NSS_TIER_OK "
 
 
 def rehearse_native_path(args, rank):
     """Multi-rank runs only.  The RCCL-through-ctypes communicator and the native partitioned loop
     cannot be exercised on the single-GPU development box (RCCL refuses two ranks on one device),
     so before this process touches its GPU every rank starts a CHILD `bench.py` that runs the same
-    code path on a small system (own rendezvous port), with a time limit.  A child that hangs,
-    crashes or falls back makes the parent job use the torch.distributed data path instead --
-    slower, but the job still reports a number.  Returns True when the native path is proven."""
+    code paths on a small system (own rendezvous port), with a time limit: first RCCL driven from
+    the Python schedule, then the native C loop, each cross-checked against torch.distributed; the
+    child prints a marker per path that held up.  Whatever hangs or crashes in the child is not
+    used by the parent job, which still reports a number on the best proven path.  Returns the index
+    into TIERS of the fastest proven path."""
     import subprocess
     forced = os.environ.get("NSS_PROBE_FORCE") == "1"     # exercise the child mechanics on any backend (tests)
     if not forced and (os.environ.get("NSS_COMM", "rccl") != "rccl"
                        or os.environ.get("NSS_DIST_BACKEND", "nccl") != "nccl"):
-        return False
+        return 0
     if os.environ.get("NSS_SKIP_REHEARSAL") == "1":
-        return True
+        return len(TIERS) - 1
     env = os.environ.copy()
     env["NSS_PROBE_CHILD"] = "1"
     env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1 + int(os.environ.get("NSS_PROBE_PORT_OFFSET", "36")))
@@ -119,14 +122,13 @@ def rehearse_native_path(args, rank):
         child.kill()
         _, err = child.communicate()
         rc = -9
-    ok = rc == PROBE_OK
-    if not ok:
-        tail = err.decode(errors="replace").strip().splitlines()[-6:]
-        print("rank %d: rehearsal of the native multi-GPU path failed (exit %s, %.0f s); using torch.distributed\n  %s"
-              % (rank, rc, time.perf_counter() - t0, "\n  ".join(tail)), file=sys.stderr)
-    else:
-        print("rank %d: native multi-GPU path rehearsed in %.0f s" % (rank, time.perf_counter() - t0), file=sys.stderr)
-    return ok
+    text = err.decode(errors="replace")
+    level = max([0] + [TIERS.index(t) for t in TIERS if TIER_MARK + t in text])
+    tail = [ln for ln in text.strip().splitlines() if TIER_MARK not in ln][-4:]
+    print("rank %d: rehearsal (%.0f s, exit %s): best proven data path = %s%s"
+          % (rank, time.perf_counter() - t0, rc, TIERS[level],
+             "" if level == len(TIERS) - 1 else "\n  " + "\n  ".join(tail)), file=sys.stderr)
+    return level
 
 
 def emit(fd, doc):
@@ -152,9 +154,9 @@ def main():
     # RCCL bootstrap / native loop on a single GPU)
     partitioned = world > 1 or os.environ.get("NSS_FORCE_DIST") == "1"
     probe_child = os.environ.get("NSS_PROBE_CHILD") == "1"
-    native_proven = True
+    tier_level = len(TIERS) - 1
     if partitioned and world > 1 and not probe_child:
-        native_proven = rehearse_native_path(args, rank)          # before this process initialises its GPU
+        tier_level = rehearse_native_path(args, rank)             # before this process initialises its GPU
     if partitioned:
         # NSS_DIST_BACKEND=gloo lets several ranks share one GPU for rehearsals (RCCL refuses
         # that); the driver's runs use the default: one rank per GPU over RCCL / xGMI.
@@ -166,10 +168,9 @@ def main():
         else:
             dist.init_process_group(backend)
         if world > 1:                                    # every rank must take the same data path
-            agree = torch.tensor([1.0 if native_proven else 0.0], dtype=torch.float64,
-                                 device="cuda" if backend == "nccl" else "cpu")
+            agree = torch.tensor([float(tier_level)], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
             dist.all_reduce(agree, op=dist.ReduceOp.MIN)
-            native_proven = bool(agree.item() == 1.0)
+            tier_level = int(agree.item())
     if args.gpus != world and rank == 0:
         print("note: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
 
@@ -206,71 +207,73 @@ def main():
 
     if partitioned:
         from distributed import DistributedBpcg2, TorchComm
-        comm, comm_kind = None, "torch.distributed/" + backend
+        comm_kind = "torch.distributed/" + backend
         crosscheck_ms = {}
-        if backend == "nccl" and os.environ.get("NSS_COMM", "rccl") == "rccl" and native_proven:
+        rccl = None
+        if backend == "nccl" and os.environ.get("NSS_COMM", "rccl") == "rccl" and tier_level >= 1:
             try:                                   # RCCL straight through ctypes on the compute stream
                 from rccl_comm import RcclComm
-                comm = RcclComm(dist, eng)
-                comm.self_test(torch)
-                comm_kind = "rccl-ctypes"
+                rccl = RcclComm(dist, eng)
+                rccl.self_test(torch)
             except Exception as exc:               # any doubt -> the torch.distributed data path
                 print("rank %d: RCCL ctypes communicator unavailable (%s); using torch.distributed" % (rank, exc),
                       file=sys.stderr)
-                comm = None
-        flag = torch.tensor([1.0 if comm is not None else 0.0], dtype=torch.float64, device="cuda")
+                rccl = None
+        flag = torch.tensor([1.0 if rccl is not None else 0.0], dtype=torch.float64,
+                            device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)      # all ranks must agree on the data path
         if flag.item() == 0.0:
-            comm = None
+            rccl = None
         torch_comm = TorchComm(dist, eng)
-        if comm is not None:
-            # cross-check: a few iterations of the native loop (RCCL + halo overlap issued from C)
-            # against the same iterations over torch.distributed collectives, from the same state
-            probe_its, timed_its = 6, 40
-            hists = []
-            try:
-                for label, c in (("native", comm), ("torch", torch_comm)):
-                    with quiet:
-                        probe = DistributedBpcg2(sysm, f, g, blocks, dist, eng, comm=c)
-                    probe.start(tol=0.0, maxsteps=probe_its + timed_its)
-                    probe.iterate(0, probe_its)
-                    torch.cuda.synchronize()
-                    hists.append(probe.history(probe_its - 1))
-                    dist.barrier()                       # diagnostics: what one iteration costs on either path
-                    t_probe = time.perf_counter()
-                    probe.iterate(probe_its, probe_its + timed_its)
-                    torch.cuda.synchronize()
-                    crosscheck_ms[label] = 1e3 * (time.perf_counter() - t_probe) / timed_its
-                    del probe
-                same = bool(np.all(np.isfinite(hists[0])) and np.allclose(hists[0], hists[1], rtol=1e-9, atol=0.0))
-            except Exception as exc:
-                print("rank %d: native partitioned loop raised %r" % (rank, exc), file=sys.stderr)
-                same = False
-            flag = torch.tensor([1.0 if same else 0.0], dtype=torch.float64, device="cuda")
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if flag.item() == 0.0:
-                print("rank %d: native partitioned loop disagrees with the torch.distributed path; "
-                      "falling back" % rank, file=sys.stderr)
-                comm = None
+        comm, use_native = torch_comm, False
+
+        def probe_path(c, native, probe_its=6, timed_its=40):
+            """History of a few iterations on one data path + its cost per iteration."""
+            with quiet:
+                probe = DistributedBpcg2(sysm, f, g, blocks, dist, eng, comm=c, native=native)
+            probe.start(tol=0.0, maxsteps=probe_its + timed_its)
+            probe.iterate(0, probe_its)
+            torch.cuda.synchronize()
+            h = probe.history(probe_its - 1)
+            dist.barrier()
+            t_probe = time.perf_counter()
+            probe.iterate(probe_its, probe_its + timed_its)
+            torch.cuda.synchronize()
+            return h, 1e3 * (time.perf_counter() - t_probe) / timed_its
+
+        if rccl is not None:
+            # cross-check every candidate path against torch.distributed collectives from the same state;
+            # the rehearsal child walks them slowest first (a hang then leaves the markers of the paths
+            # that held up), the job itself fastest first
+            ref_hist, crosscheck_ms["torch"] = probe_path(torch_comm, False)
+            candidates = [("rccl-python", False), ("native", True)]
+            candidates = [c for c in candidates if TIERS.index(c[0]) <= tier_level]
+            if not probe_child:
+                candidates.reverse()
+            for label, native in candidates:
+                try:
+                    h, crosscheck_ms[label] = probe_path(rccl, native)
+                    same = bool(np.all(np.isfinite(h)) and np.allclose(h, ref_hist, rtol=1e-9, atol=0.0))
+                except Exception as exc:
+                    print("rank %d: data path %s raised %r" % (rank, label, exc), file=sys.stderr)
+                    same = False
+                flag = torch.tensor([1.0 if same else 0.0], dtype=torch.float64, device="cuda")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if flag.item() == 1.0:
+                    if probe_child:
+                        print(TIER_MARK + label, file=sys.stderr, flush=True)
+                        continue
+                    comm, use_native = rccl, native
+                    comm_kind = "rccl-ctypes" + ("" if native else " issued from the Python schedule")
+                    break
+                print("rank %d: data path %s disagrees with torch.distributed; not used" % (rank, label), file=sys.stderr)
         if probe_child:
-            # rehearsal child: report through the exit code whether the native path held up
-            native = comm is not None
-            if native:
-                with quiet:
-                    run = DistributedBpcg2(sysm, f, g, blocks, dist, eng, comm=comm)
-                native = run.native is not None
-                run.start(tol=0.0, maxsteps=total_its)
-                run.iterate(0, total_its)
-                torch.cuda.synchronize()
-                native = native and bool(np.all(np.isfinite(run.history(total_its - 1))))
             dist.barrier()
             dist.destroy_process_group()
             sys.stderr.flush()
-            os._exit(PROBE_OK if native else PROBE_FELL_BACK)
-        if comm is None:
-            comm, comm_kind = torch_comm, "torch.distributed/" + backend
+            os._exit(0)
         with quiet:
-            run = DistributedBpcg2(sysm, f, g, blocks, dist, eng, comm=comm)
+            run = DistributedBpcg2(sysm, f, g, blocks, dist, eng, comm=comm, native=use_native)
         if run.native is not None:
             comm_kind += " + native loop (%s)" % ("exchange overlapped with the interior rows" if run.overlap
                                                   else "exchange, then SpMV, on one stream")
@@ -302,7 +305,7 @@ def main():
                                        % (args.n, sysm.ndof, args.pre, world),
                            "n_u": sysm.n_u, "n_p": sysm.n_p, "nnz_A": int(sysm.A.nnz), "nnz_B": int(sysm.B.nnz)},
                 "valid": ok, "halo_doubles_per_rank": run.halo_summary(), "comm": comm_kind,
-                "ms_per_iteration_by_path_rank0": crosscheck_ms or None, "native_path_rehearsed": bool(native_proven),
+                "ms_per_iteration_by_path_rank0": crosscheck_ms or None, "rehearsed_best_path": TIERS[tier_level],
             }
             emit(result_fd, out)
         dist.destroy_process_group()

@@ -499,8 +499,11 @@ class DistributedBpcg2:
                 ("halo", "t4"), ("phases", ("K3", "SUM1")), ("allreduce", 1), ("phases", ("ALPHA", "SUM2")),
                 ("allreduce", 2), ("phases", ("BETA", "K5")))
 
-    def __init__(self, sysm, f, g, blocks, dist, engine=None, comm=None, quiet=True):
+    def __init__(self, sysm, f, g, blocks, dist, engine=None, comm=None, quiet=True, native=True):
+        """`native=False` keeps the Python-driven schedule even when `comm` is an `RcclComm` (its
+        collectives are then single ctypes calls into librccl between the device phases)."""
         import contextlib
+        self.want_native = bool(native)
         import io
         from hipla import BlockVector
         from solvers.bramblepasciak_new import BpcgSession
@@ -554,7 +557,7 @@ class DistributedBpcg2:
         # mode 1 cost 98 us per iteration -- more than the three small exchanges they hide.
         self.overlap = int(os.environ.get("NSS_OVERLAP", "0"))
         comm_handle = getattr(self.comm, "comm", None)         # RcclComm: an ncclComm_t
-        if comm_handle is not None and hasattr(self.loop.lib, "nss_bpcg2_iterate_dist"):
+        if comm_handle is not None and getattr(self, "want_native", True) and hasattr(self.loop.lib, "nss_bpcg2_iterate_dist"):
             self.enable_native(comm_handle)
 
     def _setup_ghosts(self):
