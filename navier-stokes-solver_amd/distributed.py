@@ -253,6 +253,9 @@ class DistSparseMatrix(BaseMatrix):
         """Make the ghost tail of `hv.ext` current (pack -> all_to_all -> tail)."""
         if self.comm.size == 1:
             return
+        if self.plan.direct and getattr(self.comm, "direct_sends", False):
+            self.comm.exchange_direct(self.plan, hv.ext)       # contiguous runs: no pack kernel
+            return
         self.comm.exchange(self.plan, self.pack(hv), hv.ext)
 
     def interior_row_blocks(self):

@@ -100,6 +100,34 @@ class RcclComm(TorchComm):
             self._check(lib.ncclRecv(ptr, cnt, NCCL_FLOAT64, peer, comm, st))
         self._check(lib.ncclGroupEnd())
 
+    direct_sends = True
+
+    def exchange_direct(self, plan, ext):
+        """Halo exchange of a plan whose destinations are all served by one contiguous run of the
+        owned entries (`plan.direct`): sends straight out of the operand, no pack kernel."""
+        if self.size == 1:
+            return
+        key = ("direct", id(plan), ext.data_ptr())
+        ops = self._plans.get(key)
+        if ops is None:
+            sends = [(ext.data_ptr() + 8 * plan.send_runs[q], int(c), q) for q, c in enumerate(plan.send_counts) if c]
+            recvs, off = [], plan.n_owned
+            for q, c in enumerate(plan.recv_counts):
+                if c:
+                    recvs.append((ext.data_ptr() + 8 * off, int(c), q))
+                off += int(c)
+            ops = self._plans[key] = (sends, recvs)
+        sends, recvs = ops
+        if not sends and not recvs:
+            return
+        lib, comm, st = self.lib, self.comm, self._stream()
+        self._check(lib.ncclGroupStart())
+        for ptr, cnt, peer in sends:
+            self._check(lib.ncclSend(ptr, cnt, NCCL_FLOAT64, peer, comm, st))
+        for ptr, cnt, peer in recvs:
+            self._check(lib.ncclRecv(ptr, cnt, NCCL_FLOAT64, peer, comm, st))
+        self._check(lib.ncclGroupEnd())
+
     def self_test(self, torch):
         """Ring shift + all-reduce against torch.distributed; raises on any mismatch."""
         dev = self.engine.device
