@@ -203,3 +203,49 @@ def test_halo_plans_of_slab_partitions_send_contiguous_runs(numpy_engine):
     np.testing.assert_array_equal(g, [100, 150, 199])
     g = densify_ghosts(np.array([100, 101, 103]), np.array([0, 100, 200]))
     np.testing.assert_array_equal(g, [100, 101, 102, 103])
+
+
+def test_rccl_direct_exchange_issues_the_right_segments():
+    """`RcclComm.exchange_direct` (multi-rank RCCL cannot run on the development box): with a recording
+    stand-in for librccl, the sends start at the contiguous runs of the operand and the receives fill
+    the ghost tail owner by owner."""
+    import types
+    from rccl_comm import RcclComm
+    calls = []
+
+    class FakeLib:
+        def ncclGroupStart(self):
+            calls.append(("start",))
+            return 0
+
+        def ncclGroupEnd(self):
+            calls.append(("end",))
+            return 0
+
+        def ncclSend(self, ptr, cnt, dtype, peer, comm, st):
+            calls.append(("send", ptr, cnt, peer))
+            return 0
+
+        def ncclRecv(self, ptr, cnt, dtype, peer, comm, st):
+            calls.append(("recv", ptr, cnt, peer))
+            return 0
+
+    comm = object.__new__(RcclComm)
+    comm.size, comm.rank, comm._plans, comm.lib, comm.comm = 3, 1, {}, FakeLib(), 1234
+    comm.engine = types.SimpleNamespace(stream=0)
+    plan = types.SimpleNamespace(n_owned=100, send_counts=np.array([7, 0, 5]), recv_counts=np.array([4, 0, 6]),
+                                 send_runs={0: 0, 2: 95}, direct=True)
+    ext = types.SimpleNamespace(data_ptr=lambda: 1 << 20)
+    comm.exchange_direct(plan, ext)
+    base = 1 << 20
+    assert calls == [("start",), ("send", base, 7, 0), ("send", base + 8 * 95, 5, 2),
+                     ("recv", base + 8 * 100, 4, 0), ("recv", base + 8 * 104, 6, 2), ("end",)]
+    calls.clear()
+    comm.exchange_direct(plan, ext)                      # cached plan: same calls
+    assert len(calls) == 6
+    # packed variant: segments of the send buffer in destination order
+    calls.clear()
+    sendbuf = types.SimpleNamespace(data_ptr=lambda: 1 << 24)
+    comm.exchange(plan, sendbuf, ext)
+    assert calls == [("start",), ("send", 1 << 24, 7, 0), ("send", (1 << 24) + 8 * 7, 5, 2),
+                     ("recv", base + 8 * 100, 4, 0), ("recv", base + 8 * 104, 6, 2), ("end",)]
