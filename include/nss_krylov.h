@@ -245,6 +245,15 @@ typedef struct nss_bpcg2_s {
   int32_t ghost_mode, ghost_n;
   const int32_t* ghost_map;
   double *ghost_s0, *ghost_w0;
+  /* the same for the pressure part, so that s1 needs no exchange either (one halo exchange per
+   * iteration: t1): ghost_b = the rows of B of the ghost pressure cells of B^T's operand, with columns
+   * in the layout of the t4 operand; every iteration t3_g = ghost_b t4 (one small SpMV before K4),
+   * w1_g -= alpha minv_g t3_g (K4), s1_g = beta s1_g + w1_g (K5), where s1_g is the ghost tail of the
+   * s1 operand buffer itself (s1 + n_p).  ghost_p_mode == 0: off (s1 is exchanged). */
+  int32_t ghost_p_mode, ghost_p_n;
+  nss_csr_t ghost_b;
+  double *ghost_t3, *ghost_w1;
+  const double* ghost_minv;
 } nss_bpcg2_t;
 
 enum {

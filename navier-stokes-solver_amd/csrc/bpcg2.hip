@@ -137,6 +137,15 @@ struct EpiAddGuarded {
   __device__ void finish(int, double*) const {}
 };
 
+// y = A x, frozen once the loop has stopped (ghost rows of B)
+struct EpiGuardedStore {
+  const int32_t* __restrict__ ctrl;
+  double* __restrict__ y;
+  __device__ bool skip() const { return ctrl[C_DONE] != 0; }
+  __device__ void row(int r, double ax) const { y[r] = ax; }
+  __device__ void finish(int, double*) const {}
+};
+
 struct EpiK3 {
   const int32_t* __restrict__ ctrl;
   const double* __restrict__ s1;
@@ -213,6 +222,10 @@ struct K4Args {
   int32_t ghost_n;
   const int32_t* ghost_map;
   double* ghost_w0;
+  int32_t ghost_p_n;
+  const double* ghost_t3;
+  const double* ghost_minv;
+  double* ghost_w1;
 };
 
 __global__ __launch_bounds__(kBlock) void bpcg2_k4_kernel(K4Args a) {
@@ -257,6 +270,8 @@ __global__ __launch_bounds__(kBlock) void bpcg2_k4_kernel(K4Args a) {
   }
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < a.ghost_n; i += stride)   // ghost copies: same recurrence
     a.ghost_w0[i] = fma(-alpha, a.t1[a.ghost_map[i]], a.ghost_w0[i]);
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < a.ghost_p_n; i += stride)
+    a.ghost_w1[i] = fma(-alpha, a.ghost_minv[i] * a.ghost_t3[i], a.ghost_w1[i]);
   const double s = block_sum(acc, lds);
   if (threadIdx.x == 0) a.partials[blockIdx.x] = s;
 }
@@ -268,7 +283,9 @@ __global__ __launch_bounds__(kBlock) void bpcg2_k5_kernel(int32_t* __restrict__ 
                                                            double* __restrict__ hist, int32_t it, int32_t n_p,
                                                            double* __restrict__ s1, const double* __restrict__ w1,
                                                            int32_t ghost_n, double* __restrict__ ghost_s0,
-                                                           const double* __restrict__ ghost_w0) {
+                                                           const double* __restrict__ ghost_w0, int32_t ghost_p_n,
+                                                           double* __restrict__ ghost_s1,
+                                                           const double* __restrict__ ghost_w1) {
   if (ctrl[C_DONE] != 0) return;
   const double wd = scal[wd_slot(it)], wdn = scal[S_WDN];
   const double beta = wdn / wd;
@@ -288,6 +305,7 @@ __global__ __launch_bounds__(kBlock) void bpcg2_k5_kernel(int32_t* __restrict__ 
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < n_p; i += stride) s1[i] = fma(beta, s1[i], w1[i]);
   // ghost copies of s0: what K1 of the next iteration does to the owned entries with this beta
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < ghost_n; i += stride) ghost_s0[i] = fma(beta, ghost_s0[i], ghost_w0[i]);
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < ghost_p_n; i += stride) ghost_s1[i] = fma(beta, ghost_s1[i], ghost_w1[i]);
 }
 
 // what K1 of the next iteration would have done, for a loop that ends here
@@ -317,7 +335,11 @@ void bpcg2_check_state(const nss_bpcg2_t* s) {
               "bpcg2: NULL work buffer");
   NSS_REQUIRE(!s->ghost_mode || s->ghost_n == 0 || (s->ghost_map && s->ghost_s0 && s->ghost_w0),
               "bpcg2: ghost mode without ghost arrays");
-  NSS_REQUIRE(s->ghost_n >= 0, "bpcg2: negative ghost count");
+  NSS_REQUIRE(s->ghost_n >= 0 && s->ghost_p_n >= 0, "bpcg2: negative ghost count");
+  NSS_REQUIRE(!s->ghost_p_mode || s->ghost_p_n == 0 ||
+                  (s->ghost_mode && s->ghost_b && s->ghost_t3 && s->ghost_w1 && s->ghost_minv &&
+                   s->ghost_b->m == s->ghost_p_n),
+              "bpcg2: pressure ghost mode without its arrays (it also needs the velocity ghost mode)");
   const bool cond = s->cond_HT || s->cond_H || s->cond_inner || s->cond_f;
   if (cond) {
     NSS_REQUIRE(s->cond_HT && s->cond_H && s->cond_inner && s->cond_f, "bpcg2: condensed form needs H^T, H, A_ii^-1 and a work vector");
@@ -403,7 +425,9 @@ void bpcg2_phase(const nss_bpcg2_t& s, int which, int it, hipStream_t st) {
     case NSS_BPCG2_K4: {
       K4Args a{s.ctrl, s.scal, s.n_u, s.n_p, it, s.u0, s.d0, s.w0, s.u1, s.d1, s.w1,
                s.s0, s.t0, s.t1, s.t2, s.s1, s.t3, s.minv, s.partials_c, s.ghost_mode ? s.ghost_n : 0, s.ghost_map,
-               s.ghost_w0};
+               s.ghost_w0, s.ghost_p_mode ? s.ghost_p_n : 0, s.ghost_t3, s.ghost_minv, s.ghost_w1};
+      if (s.ghost_p_mode && s.ghost_p_n > 0)     // t3 on the ghost pressure rows (t4 and its ghosts are complete)
+        launch_csr_stream(*s.ghost_b, s.t4, EpiGuardedStore{s.ctrl, s.ghost_t3}, st);
       hipLaunchKernelGGL(bpcg2_k4_kernel, dim3(k4_grid(s)), dim3(kBlock), 0, st, a);
       NSS_CHECK_LAUNCH();
       break;
@@ -417,7 +441,8 @@ void bpcg2_phase(const nss_bpcg2_t& s, int which, int it, hipStream_t st) {
       break;
     case NSS_BPCG2_K5:
       hipLaunchKernelGGL(bpcg2_k5_kernel, dim3(stream_grid(s.n_p, kBlock * 4)), dim3(kBlock), 0, st, s.ctrl, s.scal,
-                         s.hist, it, s.n_p, s.s1, s.w1, s.ghost_mode ? s.ghost_n : 0, s.ghost_s0, s.ghost_w0);
+                         s.hist, it, s.n_p, s.s1, s.w1, s.ghost_mode ? s.ghost_n : 0, s.ghost_s0, s.ghost_w0,
+                         s.ghost_p_mode ? s.ghost_p_n : 0, s.s1 + s.n_p, s.ghost_w1);
       NSS_CHECK_LAUNCH();
       break;
     default:

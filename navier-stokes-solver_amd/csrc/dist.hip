@@ -197,7 +197,8 @@ int nss_bpcg2_iterate_dist(const nss_bpcg2_t* s, nss_dist_t d, const nss_halo_t*
     hipStream_t cs = as_stream(stream);
     const int ov = overlap;
     for (int it = it_begin; it < it_end; ++it) {
-      spmv_with_halo(*s, *d, *halo_s1, 0, NSS_BPCG2_K1, it, *s->BT, ov, cs);
+      if (s->ghost_p_mode) bpcg2_spmv_phase(*s, NSS_BPCG2_K1, it, cs, 0, -1);   // s1's ghosts are kept up to date locally
+      else spmv_with_halo(*s, *d, *halo_s1, 0, NSS_BPCG2_K1, it, *s->BT, ov, cs);
       bpcg2_k1_finish(*s, cs);
       spmv_with_halo(*s, *d, *halo_t1, 1, NSS_BPCG2_K2, it, *s->A, ov, cs);
       if (s->ghost_mode) bpcg2_spmv_phase(*s, NSS_BPCG2_K3, it, cs, 0, -1);   // t4's ghosts were computed in K2

@@ -440,10 +440,33 @@ class DistributedStokes:
         self.n_u, self.n_p = int(self.vel[r + 1] - self.vel[r]), int(self.prs[r + 1] - self.prs[r])
         BT = sysm.B.T.tocsr()
         BT.sort_indices()
-        self.B = DistSparseMatrix(sysm.B, self.prs, self.vel, comm, self.engine)
+        # Ghost pressure cells of B^T's operand and the velocity dofs their rows of B touch: B's and A's
+        # operands receive those as well, so that the fused loop can keep s1 and t4 current on the
+        # ghosts by redundant computation instead of exchanging them (nss_bpcg2_t.ghost_*).
+        v0g, v1g = int(self.vel[r]), int(self.vel[r + 1])
+        _, ghost_p = localize_rows(BT, (v0g, v1g), self.prs, r)
+        rows_gp = sp.csr_matrix(sysm.B[ghost_p, :]) if ghost_p.size else sp.csr_matrix((0, sysm.B.shape[1]))
+        touched = np.unique(rows_gp.indices.astype(np.int64))
+        extra_v = touched[(touched < v0g) | (touched >= v1g)]
+        self.B = DistSparseMatrix(sysm.B, self.prs, self.vel, comm, self.engine, extra_ghosts=extra_v)
         # A's operand also receives the ghost columns of B's operand: the fused loop then derives the
         # ghosts of t4 = t1 - s0 locally instead of exchanging them (nss_bpcg2_t.ghost_mode)
         self.A = DistSparseMatrix(sysm.A, self.vel, self.vel, comm, self.engine, extra_ghosts=self.B.plan.ghosts)
+        # rows of B of the ghost pressure cells, columns in the layout of B's operand
+        cols = rows_gp.indices.astype(np.int64)
+        own = (cols >= v0g) & (cols < v1g)
+        newc = np.empty_like(cols)
+        newc[own] = cols[own] - v0g
+        pos = np.searchsorted(self.B.plan.ghosts, cols[~own])
+        if cols[~own].size and not np.array_equal(self.B.plan.ghosts[np.minimum(pos, self.B.plan.ghosts.size - 1)],
+                                                  cols[~own]):
+            raise RuntimeError("ghost rows of B reference columns outside B's operand")
+        newc[~own] = self.B.plan.n_owned + pos
+        self.ghost_p = ghost_p
+        self.ghost_rows_B = sp.csr_matrix((rows_gp.data, newc.astype(np.int32), rows_gp.indptr),
+                                          shape=(ghost_p.size, self.B.plan.n_owned + self.B.plan.n_ghost))
+        self.ghost_rows_B.sort_indices()
+        self.ghost_minv = 1.0 / sysm.mass[ghost_p] if ghost_p.size else np.zeros(0)
         self.BT = DistSparseMatrix(BT, self.vel, self.prs, comm, self.engine)
         self.B.attach_transpose(self.BT)
         v0, v1 = int(self.vel[r]), int(self.vel[r + 1])
@@ -494,8 +517,9 @@ class DistributedStokes:
 class DistributedBpcg2:
     """Row-partitioned Bramble-Pasciak CG (v2) on this rank: set-up through the operator
     protocol with distributed operands (halo + all_reduce inside ``Mult`` / inner product),
-    iteration through the fused device phases (``nss_bpcg2_phase``) with the two halo
-    exchanges and two all-reduces in between."""
+    iteration through the fused device phases (``nss_bpcg2_phase``) with one halo
+    exchange (t1) and two all-reduces in between; the ghosts of the other two SpMV operands are kept
+    current by redundant computation (nss_bpcg2_t.ghost_*)."""
 
     # (kind, argument): device phases between two communication points go down in one C call
     SCHEDULE = (("halo", "s1"), ("phases", ("K1", "K1")), ("halo", "t1"), ("phases", ("K2", "K2")),
@@ -579,6 +603,21 @@ class DistributedBpcg2:
         st.ghost_map = self._ghost_map.data_ptr()
         st.ghost_s0, st.ghost_w0 = self._ghost_s0.data_ptr(), self._ghost_w0.data_ptr()
         self._ghost_tmp = ops.B.operand()
+        # pressure part: s1 on the ghost cells of B^T's operand (nss_bpcg2_t.ghost_p_*)
+        self.ghost_p_mode = False
+        gp = getattr(ops, "ghost_p", None)
+        if (os.environ.get("NSS_GHOST_S1", "1") == "1" and gp is not None
+                and np.array_equal(gp, ops.BT.plan.ghosts)):
+            self._ghost_b = SparseMatrix.from_scipy(ops.ghost_rows_B, engine=eng) if gp.size else None
+            self._ghost_t3 = eng.zeros(max(1, gp.size))
+            self._ghost_w1 = eng.zeros(max(1, gp.size))
+            self._ghost_minv = eng.from_host(ops.ghost_minv) if gp.size else eng.zeros(1)
+            st.ghost_p_mode, st.ghost_p_n = 1, int(gp.size)
+            st.ghost_b = self._ghost_b.handle.ptr if gp.size else None
+            st.ghost_t3, st.ghost_w1 = self._ghost_t3.data_ptr(), self._ghost_w1.data_ptr()
+            st.ghost_minv = self._ghost_minv.data_ptr()
+            self._ghost_tmp_p = ops.BT.operand()
+            self.ghost_p_mode = True
         return True
 
     def _fill_ghosts(self):
@@ -590,6 +629,13 @@ class DistributedBpcg2:
             ops.B.exchange(self._ghost_tmp)
             if n_g:
                 eng.copy(eng.view(self._ghost_tmp.ext, n_own, n_own + n_g), eng.view(dst, 0, n_g))
+        if getattr(self, "ghost_p_mode", False):
+            n_own, n_g = ops.BT.plan.n_owned, ops.BT.plan.n_ghost
+            ops.BT.exchange(self.s1)                                   # s1's ghost tail: once per solve
+            eng.copy(self.vecs["w1"].buf, self._ghost_tmp_p.buf)
+            ops.BT.exchange(self._ghost_tmp_p)
+            if n_g:
+                eng.copy(eng.view(self._ghost_tmp_p.ext, n_own, n_own + n_g), eng.view(self._ghost_w1, 0, n_g))
 
     def enable_native(self, comm_handle, interior=None):
         """Issue the partitioned iterations from C (nss_bpcg2_iterate_dist): RCCL calls, halo
@@ -631,6 +677,8 @@ class DistributedBpcg2:
             for kind, what in self.SCHEDULE:
                 if kind == "halo" and what == "t4" and self.ghost_mode:
                     continue                             # t4's ghosts are derived from t1's in K2
+                if kind == "halo" and what == "s1" and getattr(self, "ghost_p_mode", False):
+                    continue                             # s1's ghosts follow their own recurrence
                 if kind == "phases":
                     loop.phases(what[0], what[1], it)
                 elif kind == "halo":

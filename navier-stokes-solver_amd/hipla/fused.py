@@ -34,7 +34,9 @@ class Bpcg2State(C.Structure):
                    ("k", C.c_double), ("n_u", C.c_int32), ("n_p", C.c_int32)]
                 + [(n, C.c_void_p) for n in ("cond_HT", "cond_H", "cond_inner", "cond_f")]
                 + [("ghost_mode", C.c_int32), ("ghost_n", C.c_int32), ("ghost_map", C.c_void_p),
-                   ("ghost_s0", C.c_void_p), ("ghost_w0", C.c_void_p)])
+                   ("ghost_s0", C.c_void_p), ("ghost_w0", C.c_void_p),
+                   ("ghost_p_mode", C.c_int32), ("ghost_p_n", C.c_int32), ("ghost_b", C.c_void_p),
+                   ("ghost_t3", C.c_void_p), ("ghost_w1", C.c_void_p), ("ghost_minv", C.c_void_p)])
 
 
 class HaloStruct(C.Structure):

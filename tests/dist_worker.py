@@ -91,7 +91,7 @@ def run(rank, world, mode, init_file, out_dir, dim, n, pre, tol, maxsteps):
         run_ = DistributedBpcg2(sysm, f, g, blocks, dist, eng, comm=comm)
         it, conv = run_.solve(tol=tol, maxsteps=maxsteps, poll_every=8)
         res["hist"] = run_.history(it)
-        res["ghost_mode"] = int(bool(run_.ghost_mode))
+        res["ghost_mode"] = int(bool(run_.ghost_mode)) + int(bool(getattr(run_, "ghost_p_mode", False)))
         res["it"], res["k"], res["err0"] = it, run_.k, run_.err0
         res["u"], res["p"] = run_.sol[0].numpy(), run_.sol[1].numpy()
     # ---- distributed AMG (replicated coarse levels) as preA, BPCG v2 through the protocol ------------

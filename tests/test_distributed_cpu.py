@@ -97,10 +97,11 @@ def test_gloo_row_partitioned_solve_matches_single_rank(numpy_engine, world, dim
         assert list(d["slices"]) == [vel[r], vel[r + 1], prs[r], prs[r + 1]]
         assert d["err_AxBTp"] < 1e-12 and d["err_Bx"] < 1e-12
         assert abs(d["dot"] - d["dot_ref"]) < 1e-10 * d["dot_ref"]
-        # neighbour halos only: at most two planes of velocity for A, one plane for B / B^T
+        # neighbour halos only: a few grid planes (A's and B's operands also carry the velocity dofs
+        # around the ghost pressure cells, for the redundant ghost updates of the fused loop)
         plane_u = s.velocity_slab_offsets[1] - s.velocity_slab_offsets[0]
-        assert 0 < d["halo"][0] <= 2 * plane_u
-        assert 0 <= d["halo"][1] <= plane_u and 0 <= d["halo"][2] <= s.n ** (dim - 1)
+        assert 0 < d["halo"][0] <= 4 * plane_u
+        assert 0 <= d["halo"][1] <= 4 * plane_u and 0 <= d["halo"][2] <= 2 * s.n ** (dim - 1)
         # scalars are identical on every rank (all-reduced), histories match the single-rank run
         assert abs(d["k"] - ref["k"]) < 1e-9 * ref["k"]
         assert abs(d["err0"] - ref["err0"]) < 1e-10 * ref["err0"]

@@ -45,7 +45,7 @@ def test_fused_distributed_loop_matches_single_gpu(hip_engine, world, dim, n, pr
     s, ref = single_gpu(dim, n, pre, tol, maxsteps)
     ranks = launch(world, "gpu", dim, n, pre, tol, maxsteps)
     for d in ranks:
-        assert int(d["ghost_mode"]) == 1      # two halo exchanges per iteration: t4's ghosts are derived locally
+        assert int(d["ghost_mode"]) == 2      # one halo exchange per iteration: t4's and s1's ghosts are kept locally
         assert abs(d["k"] - ref["k"]) < 1e-9 * ref["k"]
         assert abs(d["err0"] - ref["err0"]) < 1e-10 * ref["err0"]
         assert d["err_AxBTp"] < 1e-12 and d["err_Bx"] < 1e-12
