@@ -45,6 +45,7 @@ def run(rank, world, mode, init_file, out_dir, dim, n, pre, tol, maxsteps):
     us, ps = ops.local_slices()
     res["slices"] = np.array([us.start, us.stop, ps.start, ps.stop])
     res["halo"] = np.array([ops.A.plan.n_ghost, ops.B.plan.n_ghost, ops.BT.plan.n_ghost])
+    res["direct"] = np.array([int(ops.A.plan.direct), int(ops.B.plan.direct), int(ops.BT.plan.direct)])
     # distributed SpMV against the global product
     rng = np.random.default_rng(5)
     xu, xp = rng.standard_normal(sysm.n_u), rng.standard_normal(sysm.n_p)

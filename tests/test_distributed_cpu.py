@@ -100,6 +100,7 @@ def test_gloo_row_partitioned_solve_matches_single_rank(numpy_engine, world, dim
         # neighbour halos only: a few grid planes (A's and B's operands also carry the velocity dofs
         # around the ghost pressure cells, for the redundant ghost updates of the fused loop)
         plane_u = s.velocity_slab_offsets[1] - s.velocity_slab_offsets[0]
+        assert list(d["direct"]) == [1, 1, 1]           # every neighbour is served by one contiguous run
         assert 0 < d["halo"][0] <= 4 * plane_u
         assert 0 <= d["halo"][1] <= 4 * plane_u and 0 <= d["halo"][2] <= 2 * s.n ** (dim - 1)
         # scalars are identical on every rank (all-reduced), histories match the single-rank run
