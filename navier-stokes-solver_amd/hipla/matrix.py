@@ -803,9 +803,12 @@ class Projector(BaseMatrix):
 
 
 def Preconditioner(form, kind, blocks=None, **_):
-    """``Preconditioner(blf, 'local')`` -> point Jacobi; ``'blockjacobi'`` -> additive
-    block Jacobi over `blocks`.  'bddc' / 'h1amg' belong to NGSolve's FE stack and are
-    out of scope."""
+    """``Preconditioner(blf, 'local')`` -> point Jacobi; ``'blockjacobi'`` -> additive block Jacobi
+    over `blocks`; ``'h1amg'`` / ``'multigrid'`` -> the smoothed-aggregation V-cycle on the assembled
+    matrix (`hipla.amg`).  ``'bddc'`` (stokes_hcurldiv.py:48, templates/...iterative.py:77,88,122,306)
+    is NGSolve's domain-decomposition preconditioner built on its FE spaces; it has no algebraic
+    counterpart here, and the same V-cycle is returned in its place -- a mesh-independent SPD
+    preconditioner for the same operator, with different iteration counts than the reference's."""
     mat = form.mat if hasattr(form, "mat") else form
     if kind == "local":
         if blocks is not None:
@@ -815,4 +818,7 @@ def Preconditioner(form, kind, blocks=None, **_):
         if blocks is None:
             raise ValueError("blockjacobi needs blocks=")
         return BlockJacobi(mat, blocks)
+    if kind in ("h1amg", "multigrid", "bddc"):
+        from .amg import SmoothedAggregationAMG
+        return SmoothedAggregationAMG(mat)
     raise NotImplementedError("preconditioner %r is outside the hot-path scope (SURVEY.md section 8f)" % (kind,))

@@ -4,7 +4,8 @@ reference's columns (run.py:244-259), solver timers as in :32-56.
 
 Differences, all forced by scope: assembly is the synthetic staggered-grid
 generator behind `discretizations.py`; preconditioners are the hot-path ones ('local' = point
-Jacobi, 'blockjacobi' = additive facet-block Jacobi) -- 'bddc' belongs to NGSolve and raises;
+Jacobi, 'blockjacobi' = additive facet-block Jacobi, 'h1amg' / 'bddc' = the algebraic V-cycle of
+`hipla.amg` -- NGSolve's BDDC itself is not available);
 no GUI (`Draw`, `input`); importing this module does not start a run (use `main()`)."""
 
 import sys
@@ -52,7 +53,7 @@ def _preconditioner(form, kind, system=None):
         return hipla.Preconditioner(form, "local")
     if kind == "blockjacobi":
         return hipla.Preconditioner(form, "blockjacobi", blocks=system.facet_blocks())
-    raise NotImplementedError("preconditioner %r needs NGSolve's FE stack (SURVEY.md section 8f)" % (kind,))
+    return hipla.Preconditioner(form, kind)          # 'h1amg' / 'multigrid' / 'bddc' -> algebraic V-cycle
 
 
 def create_iterative_solver_factory(solver, a_pre, schur_complement_pre, tolerance, max_steps):

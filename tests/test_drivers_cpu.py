@@ -278,6 +278,25 @@ def test_smoothed_aggregation_restatement_properties(numpy_engine):
     assert len(lone) == 1 and "inv" in lone[0]
 
 
+def test_preconditioner_factory_kinds(numpy_engine):
+    """`Preconditioner(form, kind)` for the kinds the reference's drivers ask for."""
+    import hipla
+    from staggered_grid import mac_stokes
+    s = mac_stokes(2, 12, 0.01)
+    A = hipla.SparseMatrix.from_scipy(s.A)
+    assert isinstance(hipla.Preconditioner(A, "local"), hipla.JacobiPreconditioner)
+    assert isinstance(hipla.Preconditioner(A, "local", blocks=s.line_blocks(3)), hipla.BlockJacobi)
+    for kind in ("h1amg", "multigrid", "bddc"):
+        P = hipla.Preconditioner(A, kind)
+        assert isinstance(P, hipla.SmoothedAggregationAMG)
+        x = np.random.default_rng(0).standard_normal(s.n_u)
+        y = hipla.Vector(s.n_u)
+        y.data = P * hipla.Vector.from_numpy(x)
+        assert y.numpy() @ x > 0
+    with pytest.raises(NotImplementedError):
+        hipla.Preconditioner(A, "direct")
+
+
 def test_time_stepping_orchestration(numpy_engine):
     """Scope row N4: CGSolver as an operator, pressure projection, IMEX step and the pseudo time
     stepping branch of SolveInitial, checked against dense host algebra."""
