@@ -27,16 +27,17 @@ struct EpiResidual {   // r = b - A x
   __device__ void finish(int, double*) const {}
 };
 
-struct EpiJacobi {     // y = x + w dinv (b - A x)
+struct EpiJacobi {     // y = scale * (x + w dinv (b - A x))
   const double* __restrict__ b;
   const double* __restrict__ x;
   const double* __restrict__ dinv;
   double* __restrict__ y;
   double w;
+  double scale;
   __device__ bool skip() const { return false; }
   struct Pre { double b = 0.0, x = 0.0, dinv = 0.0; };
   __device__ Pre fetch(int i) const { return Pre{b[i], x[i], dinv[i]}; }
-  __device__ void row(int i, double ax, const Pre& p) const { y[i] = fma(w * p.dinv, p.b - ax, p.x); }
+  __device__ void row(int i, double ax, const Pre& p) const { y[i] = scale * fma(w * p.dinv, p.b - ax, p.x); }
   __device__ void finish(int, double*) const {}
 };
 
@@ -47,17 +48,12 @@ __global__ __launch_bounds__(kBlock) void amg_diag_kernel(int32_t n, double s, c
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) y[i] = s * (d[i] * x[i]);
 }
 
-// y = s * x
-__global__ __launch_bounds__(kBlock) void amg_scale_kernel(int32_t n, double s, const double* __restrict__ x,
-                                                            double* __restrict__ y) {
-  const int stride = gridDim.x * kBlock;
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) y[i] = s * x[i];
-}
-
-static void cycle(const nss_amg_s& a, int l, const double* b, double* out, hipStream_t st) {
+// out = scale * V_l(b); the cycle is linear, so the scale factor of the outermost call (preA = k V)
+// rides in the last kernel instead of a pass over the right-hand side
+static void cycle(const nss_amg_s& a, int l, const double* b, double* out, hipStream_t st, double scale = 1.0) {
   const AmgLevel& lv = a.levels[l];
   if (l == int(a.levels.size()) - 1) {
-    launch_csr_stream(*a.coarse_inverse, b, EpiAxpby{1.0, 0.0, out}, st);   // x = A^-1 b
+    launch_csr_stream(*a.coarse_inverse, b, EpiAxpby{scale, 0.0, out}, st);   // x = A^-1 b
     return;
   }
   const int n = lv.n;
@@ -69,19 +65,11 @@ static void cycle(const nss_amg_s& a, int l, const double* b, double* out, hipSt
   launch_csr_stream(*lv.R, lv.r, EpiAxpby{1.0, 0.0, next.b}, st);
   cycle(a, l + 1, next.b, next.y, st);
   launch_csr_stream(*lv.P, next.y, EpiAxpby{1.0, 1.0, lv.x}, st);
-  launch_csr_stream(*lv.A, lv.x, EpiJacobi{b, lv.x, lv.dinv, out, a.omega}, st);
+  launch_csr_stream(*lv.A, lv.x, EpiJacobi{b, lv.x, lv.dinv, out, a.omega, scale}, st);
 }
 
 void amg_apply(const nss_amg_s& a, double bscale, const double* b, double* x, hipStream_t st) {
-  const double* rhs = b;
-  if (bscale != 1.0) {   // the cycle is linear: scale the right-hand side once
-    const int n = a.levels[0].n;
-    hipLaunchKernelGGL(amg_scale_kernel, dim3(stream_grid(n, kBlock * 4)), dim3(kBlock), 0, st, n, bscale, b,
-                       a.levels[0].b);
-    NSS_CHECK_LAUNCH();
-    rhs = a.levels[0].b;
-  }
-  cycle(a, 0, rhs, x, st);
+  cycle(a, 0, b, x, st, bscale);
 }
 
 }  // namespace nss
