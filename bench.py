@@ -294,6 +294,12 @@ def main():
         done, _, last = run.poll()
         hist = run.history(total_its - 1)
         ok = (not done) and last == total_its - 1 and bool(np.all(np.isfinite(hist)))
+        # roofline of the dominant kernel on this rank's slab: fused A-SpMV (K2), HIP events on its stream
+        a_loc = run.ops.A.local.handle.info()
+        k2_bytes = a_loc["algorithmic_bytes"] + 24 * run.ops.n_u
+        k2_ms = event_time_ms(torch, lambda: run.loop.phase("K2", total_its - 1), args.kernel_reps)
+        k2_gbs = k2_bytes / (k2_ms * 1e-3) / 1e9
+        dist.barrier()
         if rank == 0:
             out = {
                 "metric": "Krylov iters/sec, 3D SIMPLE Stokes solve (BPCG)", "value": K / elapsed, "unit": "iters/s",
@@ -304,6 +310,10 @@ def main():
                                        "%d DoF, BPCG v2, %s preA, row-partitioned over %d GPUs"
                                        % (args.n, sysm.ndof, args.pre, world),
                            "n_u": sysm.n_u, "n_p": sysm.n_p, "nnz_A": int(sysm.A.nnz), "nnz_B": int(sysm.B.nnz)},
+                "roofline": {"bound": "hbm", "kernel": "csr_stream_kernel<1, EpiK2> on rank 0's slab",
+                             "achieved": k2_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k2_gbs / HBM_PEAK_GBS,
+                             "traffic": None, "algorithmic_bytes_per_launch": k2_bytes, "avg_launch_ms": k2_ms},
+                "cpu_baseline": None,
                 "valid": ok, "halo_doubles_per_rank": run.halo_summary(), "comm": comm_kind,
                 "ms_per_iteration_by_path_rank0": crosscheck_ms or None, "rehearsed_best_path": TIERS[tier_level],
             }
