@@ -59,14 +59,14 @@ struct EpiK1 {
     if (it != 0) {
       const double alpha = scal[S_ALPHA], beta = scal[S_BETA];
       const double zo = z0[r], t2v = t2[r], so = s0[r];
-      if (ctrl[C_PENDING] == it) u0[r] = fma(alpha, so, u0[r]);   // deferred u += alpha s of iteration it - 1
+      if (ctrl[C_PENDING] == it) NSS_ST(u0[r], fma(alpha, so, u0[r]));   // deferred u += alpha s of iteration it - 1
       qv = fma(-alpha, t2v, fma(beta, qv, zo));
-      z0[r] = fma(-alpha, t2v, zo);
-      q[r] = qv;
-      s0[r] = fma(beta, so, w0[r]);
+      NSS_ST(z0[r], fma(-alpha, t2v, zo));
+      NSS_ST(q[r], qv);
+      NSS_ST3(s0[r], fma(beta, so, w0[r]));
     }
     const double t = qv + bts;
-    t0[r] = t;
+    NSS_ST3(t0[r], t);
     if (dinv) t1[r] = k * (dinv[r] * t);
   }
   __device__ void finish(int, double*) const {}
@@ -89,8 +89,8 @@ struct EpiK2 {
   struct Pre { double s0 = 0.0, t1 = 0.0, t0 = 0.0; };
   __device__ Pre fetch(int r) const { return Pre{s0[r], t1[r], t0[r]}; }
   __device__ void row(int r, double at1, const Pre& p) {
-    t2[r] = at1;
-    t4[r] = p.t1 - p.s0;
+    NSS_ST(t2[r], at1);
+    NSS_ST2(t4[r], p.t1 - p.s0);
     acc = fma(p.s0, at1 - p.t0, acc);
   }
   __device__ void finish(int b, double* lds) {
@@ -156,7 +156,7 @@ struct EpiK3 {
   struct Pre { double s1 = 0.0; };
   __device__ Pre fetch(int r) const { return Pre{s1[r]}; }
   __device__ void row(int r, double bt4, const Pre& p) {
-    t3[r] = bt4;
+    NSS_ST2(t3[r], bt4);
     acc = fma(p.s1, bt4, acc);
   }
   __device__ void finish(int b, double* lds) {
@@ -255,8 +255,8 @@ __global__ __launch_bounds__(kBlock) void bpcg2_k4_kernel(K4Args a) {
     const double t0v = a.t0[i], t1v = a.t1[i], t2v = a.t2[i];
     const double dn = fma(-alpha, t2v - t0v, a.d0[i]);
     const double wn = fma(-alpha, t1v, a.w0[i]);
-    a.d0[i] = dn;
-    a.w0[i] = wn;
+    NSS_ST(a.d0[i], dn);
+    NSS_ST(a.w0[i], wn);
     acc = fma(wn, dn, acc);
   }
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < a.n_p; i += stride) {

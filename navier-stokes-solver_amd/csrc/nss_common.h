@@ -12,6 +12,33 @@
 
 #include "../../include/nss_krylov.h"
 
+// Non-temporal stores for vectors that are written once and next read by a later kernel: they do not
+// allocate in the 4-MiB XCD L2s, which the SpMV kernels need for the gathered x window.  Levels
+// (A/B on one box, 1e7 DoF): 1 = t2 / q / z0 / u0 / d0 / w0 (K2 0.183 -> 0.157 ms), 2 = + t4 / t3
+// (K2 0.146 ms, iteration +8 % over level 0), 3 = + s0 / t0 (no further change).  Non-temporal stores of the
+// block-Jacobi output (scattered 24-byte pieces) and of the plain SpMV result were slower (K1 + block
+// Jacobi 0.217 -> 0.255 ms) and are not used.
+#ifndef NSS_NT_STORE
+#define NSS_NT_STORE 2
+#endif
+#define NSS_NT_(ptr, v) __builtin_nontemporal_store((v), &(ptr))
+#define NSS_PLAIN_(ptr, v) ((ptr) = (v))
+#if NSS_NT_STORE >= 1
+#define NSS_ST(ptr, v) NSS_NT_(ptr, v)
+#else
+#define NSS_ST(ptr, v) NSS_PLAIN_(ptr, v)
+#endif
+#if NSS_NT_STORE >= 2
+#define NSS_ST2(ptr, v) NSS_NT_(ptr, v)
+#else
+#define NSS_ST2(ptr, v) NSS_PLAIN_(ptr, v)
+#endif
+#if NSS_NT_STORE >= 3
+#define NSS_ST3(ptr, v) NSS_NT_(ptr, v)
+#else
+#define NSS_ST3(ptr, v) NSS_PLAIN_(ptr, v)
+#endif
+
 namespace nss {
 
 constexpr int kWave = 64;
