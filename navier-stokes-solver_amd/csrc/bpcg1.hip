@@ -166,7 +166,7 @@ __global__ __launch_bounds__(kBlock) void bpcg1_v4_kernel(V4Args a) {
   const int stride = gridDim.x * kBlock;
   double acc = 0.0;
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < a.n_u; i += stride) {
-    a.xu[i] = fma(alpha, a.du[i], a.xu[i]);
+    NSS_ST(a.xu[i], fma(alpha, a.du[i], a.xu[i]));
     const double rn = fma(-alpha, a.t1u[i], a.ru[i]);
     const double an = fma(-alpha, a.t2u[i], a.au[i]);
     a.ru[i] = rn;
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(kBlock) void bpcg1_v4_kernel(V4Args a) {
     acc = fma(an, rn, acc);
   }
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < a.n_p; i += stride) {
-    a.xp[i] = fma(alpha, a.dp[i], a.xp[i]);
+    NSS_ST(a.xp[i], fma(alpha, a.dp[i], a.xp[i]));
     a.rp[i] = fma(-alpha, a.t1p[i], a.rp[i]);
     a.ap[i] = fma(-alpha, a.t2p[i], a.ap[i]);
   }

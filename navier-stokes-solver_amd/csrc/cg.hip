@@ -75,7 +75,7 @@ __global__ __launch_bounds__(kBlock) void cg_update_kernel(CgArgs a, int fused_p
   const int stride = gridDim.x * kBlock;
   double acc = 0.0;
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < a.n; i += stride) {
-    a.x[i] = fma(alpha, a.p[i], a.x[i]);
+    NSS_ST(a.x[i], fma(alpha, a.p[i], a.x[i]));
     const double rn = fma(-alpha, a.q[i], a.r[i]);
     a.r[i] = rn;
     if (fused_pre) {

@@ -203,11 +203,11 @@ __device__ __forceinline__ void minres_k5_body(int i, double invg, double a1inv,
                                                 double* zn, double* vn, double* wn, double* u, const double* z,
                                                 const double* wo, const double* w) {
   zn[i] *= invg;
-  vn[i] *= invg;
+  NSS_ST(vn[i], vn[i] * invg);
   double t = fma(-a2, w[i], fma(-a3, wo[i], z[i]));   // :115
   t *= a1inv;                                         // :116
-  wn[i] = t;
-  u[i] = fma(uc, t, u[i]);                            // :118
+  NSS_ST(wn[i], t);                                   // next read one iteration later
+  NSS_ST(u[i], fma(uc, t, u[i]));                     // :118
 }
 
 __global__ __launch_bounds__(kBlock) void minres_k5_kernel(MK5Args a) {
