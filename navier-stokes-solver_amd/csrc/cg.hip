@@ -142,13 +142,18 @@ static void cg_iteration(const nss_cg_t& s, int it, hipStream_t st) {
   CgArgs a{s.ctrl, s.scal, s.hist, s.n, it, s.x, s.r, s.z, s.p, s.q, s.pre_diag, s.partials_b};
   hipLaunchKernelGGL(cg_update_kernel, dim3(cg_grid(s)), dim3(kBlock), 0, st, a, fused_pre ? 1 : 0);
   NSS_CHECK_LAUNCH();
+  int nb = cg_grid(s);
   if (!fused_pre) {
-    if (s.pre_bjac) bjac_apply(*s.pre_bjac, 1.0, s.r, 0.0, s.z, s.ctrl, st);
-    else amg_apply(*s.pre_amg, 1.0, s.r, s.z, st);
-    hipLaunchKernelGGL(cg_dot_kernel, dim3(cg_grid(s)), dim3(kBlock), 0, st, s.ctrl, s.n, s.r, s.z, s.partials_b);
-    NSS_CHECK_LAUNCH();
+    if (s.pre_bjac && !s.pre_bjac->gs_mat) {   // block Jacobi: <r, z> comes out of the apply kernel
+      nb = bjac_apply_dot(*s.pre_bjac, 1.0, s.r, s.z, s.partials_b, s.ctrl, st);
+    } else {
+      if (s.pre_bjac) bjac_apply(*s.pre_bjac, 1.0, s.r, 0.0, s.z, s.ctrl, st);
+      else amg_apply(*s.pre_amg, 1.0, s.r, s.z, st);
+      hipLaunchKernelGGL(cg_dot_kernel, dim3(nb), dim3(kBlock), 0, st, s.ctrl, s.n, s.r, s.z, s.partials_b);
+      NSS_CHECK_LAUNCH();
+    }
   }
-  hipLaunchKernelGGL(cg_sum_kernel, dim3(1), dim3(kCgSum), 0, st, s.ctrl, cg_grid(s), s.partials_b, s.scal, int(G_RZN));
+  hipLaunchKernelGGL(cg_sum_kernel, dim3(1), dim3(kCgSum), 0, st, s.ctrl, nb, s.partials_b, s.scal, int(G_RZN));
   NSS_CHECK_LAUNCH();
   hipLaunchKernelGGL(cg_direction_kernel, dim3(cg_grid(s)), dim3(kBlock), 0, st, a);
   NSS_CHECK_LAUNCH();
@@ -164,7 +169,7 @@ int nss_cg_workspace(const nss_cg_t* s, int64_t* partials_a, int64_t* partials_b
   return guarded([&] {
     NSS_REQUIRE(s && s->A, "cg_workspace: NULL state / matrix");
     if (partials_a) *partials_a = s->A->nblk;
-    if (partials_b) *partials_b = cg_grid(*s);
+    if (partials_b) *partials_b = std::max<int64_t>(cg_grid(*s), s->pre_bjac ? bjac_dot_grid(*s->pre_bjac) : 0);
   });
 }
 

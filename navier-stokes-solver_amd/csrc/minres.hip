@@ -266,13 +266,17 @@ static void minres_iteration(const nss_minres_t& s, int k, hipStream_t st) {
         const int rc = nss_diag_apply_f64(s.n_u, s.pre_diag, 1.0, s.v[in][0], 1.0, s.z[zn][0], st);
         if (rc != 0) throw Error(nss_last_error());
       }
-    } else {
+    } else if (s.pre_bjac->gs_mat) {
       bjac_apply(*s.pre_bjac, 1.0, s.v[in][0], 0.0, s.z[zn][0], nullptr, st);
+    } else {                          // block Jacobi: <z_new, v_new> comes out of the apply kernel
+      nb2 = bjac_apply_dot(*s.pre_bjac, 1.0, s.v[in][0], s.z[zn][0], s.partials_a, nullptr, st);
     }
-    nb2 = m_dot_grid(s);
-    hipLaunchKernelGGL(minres_dot_kernel, dim3(nb2), dim3(kBlock), 0, st, s.ctrl, k, s.n_u, s.z[zn][0], s.v[in][0],
-                       s.partials_a);
-    NSS_CHECK_LAUNCH();
+    if (nb2 == 0) {
+      nb2 = m_dot_grid(s);
+      hipLaunchKernelGGL(minres_dot_kernel, dim3(nb2), dim3(kBlock), 0, st, s.ctrl, k, s.n_u, s.z[zn][0], s.v[in][0],
+                         s.partials_a);
+      NSS_CHECK_LAUNCH();
+    }
   }
   hipLaunchKernelGGL(minres_sum_kernel, dim3(1), dim3(kMSum), 0, st, s.ctrl, k, nb2, s.partials_a, m_grid(s),
                      s.partials_c, s.scal, int(M_G2));
@@ -294,7 +298,8 @@ extern "C" {
 int nss_minres_workspace(const nss_minres_t* s, int64_t* partials_a, int64_t* partials_b, int64_t* partials_c) {
   return guarded([&] {
     NSS_REQUIRE(s && s->A && s->B && s->BT, "minres_workspace: NULL state / matrices");
-    const int64_t dotg = m_dot_grid(*s);
+    int64_t dotg = m_dot_grid(*s);
+    if (s->pre_bjac) dotg = std::max<int64_t>(dotg, bjac_dot_grid(*s->pre_bjac));
     if (partials_a) *partials_a = std::max<int64_t>(s->BT->nblk, dotg);
     if (partials_b) *partials_b = s->B->nblk;
     if (partials_c) *partials_c = m_grid(*s);

@@ -33,6 +33,12 @@ constexpr int kMaxBs = 16;
 // `done` (device int, may be NULL) is non-zero.
 void bjac_apply(const nss_bjac_s& j, double alpha, const double* x, double beta, double* y, const int32_t* done,
                 hipStream_t st);
+// y = alpha * J x (dofs outside every block: 0) and, from the same registers, the per-workgroup
+// partial sums of <y, x> into partials[0 .. bjac_dot_grid(j)); returns that count.  Block-Jacobi
+// mode only.  Saves the separate dot pass (two vector reads and a launch) after the apply.
+int bjac_dot_grid(const nss_bjac_s& j);
+int bjac_apply_dot(const nss_bjac_s& j, double alpha, const double* x, double* y, double* partials, const int32_t* done,
+                   hipStream_t st);
 
 
 // one multicolour block Gauss-Seidel sweep / the symmetric pair as an operator (y = 0 first)

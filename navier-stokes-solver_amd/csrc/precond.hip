@@ -100,9 +100,12 @@ __global__ __launch_bounds__(kBlock) void bjac_apply_sym_kernel(int32_t nb, cons
                                                                  const double* __restrict__ packed, double alpha,
                                                                  const double* __restrict__ x, double beta,
                                                                  double* __restrict__ y,
-                                                                 const int32_t* __restrict__ done) {
+                                                                 const int32_t* __restrict__ done,
+                                                                 double* __restrict__ partials) {
+  __shared__ double red[kBlock / kWave];
   if (done && done[0] != 0) return;
   const int stride = gridDim.x * kBlock;
+  double acc = 0.0;                              // partial <y, x> of this lane (partials != NULL)
   for (int b = blockIdx.x * kBlock + threadIdx.x; b < nb; b += stride) {
     int32_t dof[BS];
     double xv[BS], s[BS];
@@ -135,8 +138,13 @@ __global__ __launch_bounds__(kBlock) void bjac_apply_sym_kernel(int32_t nb, cons
         double v = alpha * s[r];
         if (beta != 0.0) v = fma(beta, y[dof[r]], v);
         y[dof[r]] = v;
+        acc = fma(v, xv[r], acc);
       }
     }
+  }
+  if (partials) {
+    const double t = block_sum(acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t;
   }
 }
 
@@ -144,9 +152,12 @@ template <int BS>
 __global__ __launch_bounds__(kBlock) void bjac_apply_kernel(int32_t nb, const int32_t* __restrict__ idx,
                                                              const double* __restrict__ inv, double alpha,
                                                              const double* __restrict__ x, double beta,
-                                                             double* __restrict__ y, const int32_t* __restrict__ done) {
+                                                             double* __restrict__ y, const int32_t* __restrict__ done,
+                                                             double* __restrict__ partials) {
+  __shared__ double red[kBlock / kWave];
   if (done && done[0] != 0) return;
   const int stride = gridDim.x * kBlock;
+  double acc = 0.0;
   for (int b = blockIdx.x * kBlock + threadIdx.x; b < nb; b += stride) {
     int32_t dof[BS];
     double xv[BS];
@@ -163,8 +174,13 @@ __global__ __launch_bounds__(kBlock) void bjac_apply_kernel(int32_t nb, const in
         double t = alpha * s;
         if (beta != 0.0) t = fma(beta, y[dof[r]], t);
         y[dof[r]] = t;
+        acc = fma(t, xv[r], acc);
       }
     }
+  }
+  if (partials) {
+    const double t = block_sum(acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t;
   }
 }
 
@@ -261,25 +277,43 @@ void bjac_symgs_apply(const nss_bjac_s& j, double xscale, const double* x, doubl
 
 template <int BS>
 static void launch_bjac(const nss_bjac_s& j, double alpha, const double* x, double beta, double* y,
-                        const int32_t* done, hipStream_t st) {
-  const int grid = stream_grid(j.nblocks, kBlock);
+                        const int32_t* done, double* partials, hipStream_t st) {
+  const int grid = bjac_dot_grid(j);
   if (j.inv_sym)
     hipLaunchKernelGGL((bjac_apply_sym_kernel<BS>), dim3(grid), dim3(kBlock), 0, st, j.nblocks, j.idx, j.run,
-                       j.inv_sym, alpha, x, beta, y, done);
+                       j.inv_sym, alpha, x, beta, y, done, partials);
   else
     hipLaunchKernelGGL((bjac_apply_kernel<BS>), dim3(grid), dim3(kBlock), 0, st, j.nblocks, j.idx, j.inv, alpha, x,
-                       beta, y, done);
+                       beta, y, done, partials);
 }
+
+int bjac_dot_grid(const nss_bjac_s& j) { return stream_grid(j.nblocks, kBlock); }
+
+static void bjac_apply_impl(const nss_bjac_s& j, double alpha, const double* x, double beta, double* y,
+                            const int32_t* done, double* partials, hipStream_t st);
 
 void bjac_apply(const nss_bjac_s& j, double alpha, const double* x, double beta, double* y, const int32_t* done,
                 hipStream_t st) {
+  bjac_apply_impl(j, alpha, x, beta, y, done, nullptr, st);
+}
+
+int bjac_apply_dot(const nss_bjac_s& j, double alpha, const double* x, double* y, double* partials, const int32_t* done,
+                   hipStream_t st) {
+  if (j.gs_mat) throw Error("bjac_apply_dot: not available in Gauss-Seidel mode");
+  if (partials == nullptr) throw Error("bjac_apply_dot: NULL partials");
+  bjac_apply_impl(j, alpha, x, 0.0, y, done, partials, st);   // uncovered dofs get y = 0: nothing to add
+  return bjac_dot_grid(j);
+}
+
+static void bjac_apply_impl(const nss_bjac_s& j, double alpha, const double* x, double beta, double* y,
+                            const int32_t* done, double* partials, hipStream_t st) {
   if (j.gs_mat) {  // a handle in Gauss-Seidel mode is the symmetric sweep operator
     if (beta != 0.0) throw Error("bjac_apply: Gauss-Seidel mode supports beta == 0 only");
     bjac_symgs_apply(j, alpha, x, y, done, st);
     return;
   }
   switch (j.bs) {
-#define NSS_BJ(N) case N: launch_bjac<N>(j, alpha, x, beta, y, done, st); break;
+#define NSS_BJ(N) case N: launch_bjac<N>(j, alpha, x, beta, y, done, partials, st); break;
     NSS_BJ(1) NSS_BJ(2) NSS_BJ(3) NSS_BJ(4) NSS_BJ(5) NSS_BJ(6) NSS_BJ(7) NSS_BJ(8)
     NSS_BJ(9) NSS_BJ(10) NSS_BJ(11) NSS_BJ(12) NSS_BJ(13) NSS_BJ(14) NSS_BJ(15) NSS_BJ(16)
 #undef NSS_BJ
