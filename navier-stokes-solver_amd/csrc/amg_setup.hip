@@ -515,8 +515,8 @@ nss_csr_s* adopt_csr(int32_t m, int32_t n, int64_t nnz, Dev<int32_t>& rowptr, De
   std::vector<int32_t> h_rowptr(size_t(m) + 1);
   NSS_HIP(hipMemcpy(h_rowptr.data(), rowptr.p, sizeof(int32_t) * (size_t(m) + 1), hipMemcpyDeviceToHost));
   std::vector<int32_t> blk;
-  int32_t rg = 1;
-  plan_row_blocks(m, nnz, h_rowptr.data(), &rg, blk, cuts, ncuts);
+  int32_t rg = 1, chunk = kChunk;
+  plan_row_blocks(m, nnz, h_rowptr.data(), &rg, &chunk, blk, cuts, ncuts);
   Dev<int32_t> rowblk(blk.size(), true);
   NSS_HIP(hipMemcpy(rowblk.p, blk.data(), sizeof(int32_t) * blk.size(), hipMemcpyHostToDevice));
   nss_csr_s* A = new nss_csr_s;
@@ -524,6 +524,7 @@ nss_csr_s* adopt_csr(int32_t m, int32_t n, int64_t nnz, Dev<int32_t>& rowptr, De
   A->n = n;
   A->nnz = nnz;
   A->rg = rg;
+  A->chunk = chunk;
   A->nblk = int32_t(blk.size()) - 1;
   A->rowptr = rowptr.take();
   A->col = col.take();

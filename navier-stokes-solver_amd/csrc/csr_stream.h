@@ -46,6 +46,11 @@ namespace nss {
 #define NSS_CHUNK 2048
 #endif
 constexpr int kChunk = NSS_CHUNK;       // products staged per workgroup: 16 KiB of LDS
+// Matrices with long rows (mean >= kLongRowMean non-zeros) stage twice as many: a row block then
+// holds enough rows to keep the phase-2 lanes busy and 16 loads per lane are in flight (K2 +5 % at
+// 82 non-zeros per row); short-row matrices lose occupancy to the 32 KiB and stay at kChunk.
+constexpr int kChunkLong = 2 * kChunk;
+constexpr int kLongRowMean = 48;
 constexpr int kMaxRowsPerBlock = 2048;  // bound for blocks of empty / very short rows
 constexpr int kXcds = 8;
 constexpr int kWindows = 16;          // column windows per row block of the 16-bit index stream
@@ -74,6 +79,7 @@ struct nss_csr_s {
   int32_t* rowblk = nullptr;
   int32_t nblk = 0;
   int32_t rg = 1;
+  int32_t chunk = nss::kChunk;   // products per row block: kChunk or kChunkLong (plan_row_blocks)
   // Compressed column stream: when the columns of every row block fall into at most 16 aligned
   // windows of 4096 columns (grid operators: a row block touches its own grid plane and the two
   // neighbouring ones -- a few narrow clusters far apart) the kernel streams 2 bytes per entry,
@@ -97,8 +103,8 @@ namespace nss {
 void compress_columns(nss_csr_s& A, hipStream_t st);
 
 // Launch plan of a CSR matrix: lanes per row (*rg_out) and the row-block boundaries (spmv.hip).
-void plan_row_blocks(int32_t m, int64_t nnz, const int32_t* rowptr, int32_t* rg_out, std::vector<int32_t>& blk,
-                     const int32_t* cuts = nullptr, int ncuts = 0);
+void plan_row_blocks(int32_t m, int64_t nnz, const int32_t* rowptr, int32_t* rg_out, int32_t* chunk_out,
+                     std::vector<int32_t>& blk, const int32_t* cuts = nullptr, int ncuts = 0);
 
 // Epi interface:
 //   __device__ void row(int r, double ax);          // called once per row by one lane
@@ -122,9 +128,9 @@ struct EpiPre<E, std::void_t<typename E::Pre>> {
   static __device__ void row(E& e, int r, double ax, const type& p) { e.row(r, ax, p); }
 };
 
-template <int RG, class Epi, bool C16 = false>
+template <int RG, class Epi, bool C16 = false, int CH = kChunk>
 __global__ __launch_bounds__(kBlock) void csr_stream_kernel(CsrView a, const double* __restrict__ x, Epi epi) {
-  __shared__ double prod[kChunk];
+  __shared__ double prod[CH];
   __shared__ double red[kBlock / kWave];
   __shared__ int32_t window[kWindows];
   if (epi.skip()) return;
@@ -149,11 +155,11 @@ __global__ __launch_bounds__(kBlock) void csr_stream_kernel(CsrView a, const dou
     const int rf_e = has_first ? a.rowptr[rf + 1] : 0;
     typename EpiPre<Epi>::type pre0 = has_first ? EpiPre<Epi>::fetch(epi, rf) : typename EpiPre<Epi>::type{};
 #endif
-    if (cnt <= kChunk) {
+    if (cnt <= CH) {
       // ---- phase 1: coalesced stream of (col, val), gather x, stage products ---------
 #if NSS_STREAM_VEC2
       // two consecutive entries per lane from an even-aligned base: 16-byte val / 8-byte col loads
-      constexpr int kPer = kChunk / (2 * kBlock);
+      constexpr int kPer = CH / (2 * kBlock);
       const int pa = p0 & ~1;
       const int lead = p0 - pa;                  // 0 or 1 entries in front of the row block
       const int span = cnt + lead;
@@ -176,7 +182,7 @@ __global__ __launch_bounds__(kBlock) void csr_stream_kernel(CsrView a, const dou
         if (i1 < cnt && e < span) prod[i1] = v[k].y * x[c[k].y];
       }
 #else
-      constexpr int kPer = kChunk / kBlock;
+      constexpr int kPer = CH / kBlock;
       int32_t c[kPer];
       double v[kPer];
       uint16_t c16[kPer];
@@ -258,17 +264,20 @@ inline void launch_csr_stream(const nss_csr_s& A, const double* x, const Epi& ep
   if (A.m == 0 || b1 <= b0) return;
   const CsrView v = A.view(b0, b1);
   const dim3 grid(nss_csr_s::grid(b1 - b0)), block(kBlock);
-#define NSS_LAUNCH_RG(N)                                                                      \
-  case N:                                                                                      \
-    if (A.col16) hipLaunchKernelGGL((csr_stream_kernel<N, Epi, true>), grid, block, 0, st, v, x, epi);   \
-    else hipLaunchKernelGGL((csr_stream_kernel<N, Epi, false>), grid, block, 0, st, v, x, epi);          \
+#define NSS_LAUNCH_RG(N)                                                                                      \
+  case N:                                                                                                      \
+    if (A.chunk == kChunkLong) {                                                                               \
+      if (A.col16) hipLaunchKernelGGL((csr_stream_kernel<N, Epi, true, kChunkLong>), grid, block, 0, st, v, x, epi);   \
+      else hipLaunchKernelGGL((csr_stream_kernel<N, Epi, false, kChunkLong>), grid, block, 0, st, v, x, epi);          \
+    } else {                                                                                                   \
+      if (A.col16) hipLaunchKernelGGL((csr_stream_kernel<N, Epi, true>), grid, block, 0, st, v, x, epi);       \
+      else hipLaunchKernelGGL((csr_stream_kernel<N, Epi, false>), grid, block, 0, st, v, x, epi);              \
+    }                                                                                                          \
     break;
   switch (A.rg) {
     NSS_LAUNCH_RG(1) NSS_LAUNCH_RG(2) NSS_LAUNCH_RG(4) NSS_LAUNCH_RG(8) NSS_LAUNCH_RG(16) NSS_LAUNCH_RG(32)
-    default:
-      if (A.col16) hipLaunchKernelGGL((csr_stream_kernel<64, Epi, true>), grid, block, 0, st, v, x, epi);
-      else hipLaunchKernelGGL((csr_stream_kernel<64, Epi, false>), grid, block, 0, st, v, x, epi);
-      break;
+    NSS_LAUNCH_RG(64)
+    default: throw Error("csr_stream: bad lanes-per-row in the launch plan");
   }
 #undef NSS_LAUNCH_RG
   NSS_CHECK_LAUNCH();

@@ -12,20 +12,22 @@ namespace nss {
 #endif
 constexpr int kMinRowBlocks = 2048;   // 256 CUs x 8 resident workgroups
 
-void plan_row_blocks(int32_t m, int64_t nnz, const int32_t* rowptr, int32_t* rg_out, std::vector<int32_t>& blk,
-                     const int32_t* cuts, int ncuts) {
+void plan_row_blocks(int32_t m, int64_t nnz, const int32_t* rowptr, int32_t* rg_out, int32_t* chunk_out,
+                     std::vector<int32_t>& blk, const int32_t* cuts, int ncuts) {
   const double mean = m > 0 ? double(nnz) / double(m) : 0.0;
+  const int chunk = mean >= double(kLongRowMean) ? kChunkLong : kChunk;
+  *chunk_out = chunk;
   // Lanes per row: the largest power of two for which one reduce pass (kBlock / rg rows) still
   // covers a full chunk of products, i.e. rg ~ mean / 8.  Long rows then fill the LDS chunk
   // (all 8 loads per lane in flight) and every row's bounds and epilogue operands are
   // prefetched (csr_stream.h); rows shorter than 8 take several passes with one lane per row.
   int rg = 1;
-  while (rg < kWave && double(2 * rg) * (kChunk / kBlock) <= mean) rg *= 2;
+  while (rg < kWave && double(2 * rg) * (chunk / kBlock) <= mean) rg *= 2;
   *rg_out = rg;
   const int rows_per_pass = kBlock / rg;
   int passes = 1;
   if (rg == 1) {
-    passes = mean > 0.0 ? int(double(kChunk) / (mean * rows_per_pass)) : kMaxRowsPerBlock / rows_per_pass;
+    passes = mean > 0.0 ? int(double(chunk) / (mean * rows_per_pass)) : kMaxRowsPerBlock / rows_per_pass;
     passes = std::max(1, passes);
 #if NSS_PLAN_FILL_CHIP
     // small matrices (a slab of a partitioned system, the small configs): rather more, shorter row
@@ -45,7 +47,7 @@ void plan_row_blocks(int32_t m, int64_t nnz, const int32_t* rowptr, int32_t* rg_
     const int32_t limit = ci < ncuts ? std::min<int32_t>(m, cuts[ci]) : m;
     while (r < limit && r - start < row_cap) {
       const int64_t len = int64_t(rowptr[r + 1]) - rowptr[r];
-      if (acc + len > kChunk) break;
+      if (acc + len > chunk) break;
       acc += len;
       ++r;
     }
@@ -65,14 +67,14 @@ void plan_row_blocks(int32_t m, int64_t nnz, const int32_t* rowptr, int32_t* rg_
 // 4-byte indices).
 __global__ __launch_bounds__(kBlock) void col_windows_kernel(int32_t nblk, const int32_t* __restrict__ rowblk,
                                                               const int32_t* __restrict__ rowptr,
-                                                              const int32_t* __restrict__ col,
+                                                              const int32_t* __restrict__ col, int32_t chunk,
                                                               int32_t* __restrict__ base, int32_t* __restrict__ wide) {
   const int b = blockIdx.x * kBlock + threadIdx.x;      // one lane per row block
   if (b >= nblk) return;
   const int p0 = rowptr[rowblk[b]], p1 = rowptr[rowblk[b + 1]];
   int32_t tab[kWindows];
   int cnt = 0;
-  if (p1 - p0 <= kChunk) {
+  if (p1 - p0 <= chunk) {
     int32_t last = -1;
     for (int p = p0; p < p1; ++p) {
       const int32_t w = col[p] >> kWindowBits;
@@ -93,7 +95,7 @@ __global__ __launch_bounds__(kBlock) void col_windows_kernel(int32_t nblk, const
 
 __global__ __launch_bounds__(kBlock) void col_pack16_kernel(int32_t nblk, const int32_t* __restrict__ rowblk,
                                                              const int32_t* __restrict__ rowptr,
-                                                             const int32_t* __restrict__ col,
+                                                             const int32_t* __restrict__ col, int32_t chunk,
                                                              const int32_t* __restrict__ base,
                                                              uint16_t* __restrict__ col16) {
   __shared__ int32_t window[kWindows];
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(kBlock) void col_pack16_kernel(int32_t nblk, const 
   if (threadIdx.x < kWindows) window[threadIdx.x] = base[b * kWindows + threadIdx.x];
   __syncthreads();
   const int p0 = rowptr[rowblk[b]], p1 = rowptr[rowblk[b + 1]];
-  if (p1 - p0 > kChunk) return;
+  if (p1 - p0 > chunk) return;
   for (int p = p0 + threadIdx.x; p < p1; p += kBlock) {
     const int32_t c = col[p];
     const int32_t w = (c >> kWindowBits) << kWindowBits;
@@ -123,7 +125,7 @@ void compress_columns(nss_csr_s& A, hipStream_t st) {
     NSS_HIP(hipMalloc(&wide, sizeof(int32_t)));
     NSS_HIP(hipMemsetAsync(wide, 0, sizeof(int32_t), st));
     hipLaunchKernelGGL(col_windows_kernel, dim3((A.nblk + kBlock - 1) / kBlock), dim3(kBlock), 0, st, A.nblk, A.rowblk,
-                       A.rowptr, A.col, base, wide);
+                       A.rowptr, A.col, A.chunk, base, wide);
     NSS_CHECK_LAUNCH();
     int32_t h_wide = 0;
     NSS_HIP(hipMemcpyAsync(&h_wide, wide, sizeof(int32_t), hipMemcpyDeviceToHost, st));
@@ -131,8 +133,8 @@ void compress_columns(nss_csr_s& A, hipStream_t st) {
     if (h_wide == 0) {
       NSS_HIP(hipMalloc(&c16, sizeof(uint16_t) * (size_t(A.nnz) + 8)));
       NSS_HIP(hipMemsetAsync(c16, 0, sizeof(uint16_t) * (size_t(A.nnz) + 8), st));
-      hipLaunchKernelGGL(col_pack16_kernel, dim3(A.nblk), dim3(kBlock), 0, st, A.nblk, A.rowblk, A.rowptr, A.col, base,
-                         c16);
+      hipLaunchKernelGGL(col_pack16_kernel, dim3(A.nblk), dim3(kBlock), 0, st, A.nblk, A.rowblk, A.rowptr, A.col,
+                         A.chunk, base, c16);
       NSS_CHECK_LAUNCH();
       NSS_HIP(hipStreamSynchronize(st));
       A.col16 = c16;
@@ -198,7 +200,7 @@ int nss_csr_create_cuts(int32_t nrows, int32_t ncols, int64_t nnz, const int32_t
       A->n = ncols;
       A->nnz = nnz;
       std::vector<int32_t> blk;
-      plan_row_blocks(nrows, nnz, h_rowptr, &A->rg, blk, h_cuts, ncuts);
+      plan_row_blocks(nrows, nnz, h_rowptr, &A->rg, &A->chunk, blk, h_cuts, ncuts);
       A->nblk = int32_t(blk.size()) - 1;
       NSS_HIP(hipMalloc(&A->rowptr, sizeof(int32_t) * (size_t(nrows) + 1)));
       NSS_HIP(hipMalloc(&A->col, sizeof(int32_t) * (nnz + 4)));   // +4: paired loads may touch one entry past the end

@@ -112,23 +112,45 @@ def test_spmv_stokes_blocks(hip_engine, dim, n):
     assert relerr(out.numpy(), s.B.T @ p) < RTOL
 
 
+def _plan_lanes(mean):
+    """The plan rule of csrc/spmv.hip: matrices with mean >= 48 non-zeros per row stage 4096 products
+    per row block (16 per lane), the others 2048 (8 per lane); lanes per row = the largest power of
+    two for which one reduce pass still covers a full chunk."""
+    per = 16 if mean >= 48 else 8
+    lanes = 1
+    while lanes < 64 and 2 * lanes * per <= mean:
+        lanes *= 2
+    return lanes
+
+
 def test_spmv_row_length_regimes(hip_engine):
-    """Every lanes-per-row instantiation of the CSR-stream kernel (1 ... 64), picked from the mean
-    row length by the plan rule `largest power of two with 16 * lanes <= mean`."""
+    """Every lanes-per-row instantiation of the CSR-stream kernel (1 ... 64) in both chunk sizes,
+    picked from the mean row length by the plan rule."""
     s = mac_stokes(3, 6)
     seen = set()
-    for bs in (1, 3, 6, 12, 22, 44, 90):            # ~6 ... ~560 non-zeros per row
+    for bs in (1, 3, 6, 9, 12, 22, 44, 90):         # ~6 ... ~560 non-zeros per row
         infl = s.inflate(bs) if bs > 1 else s
         M = _spmv_check(hip_engine, infl.A)
         mean = infl.A.nnz / infl.A.shape[0]
-        lanes = 1
-        while lanes < 64 and 16 * lanes <= mean:
-            lanes *= 2
-        assert M.handle.info()["lanes_per_row"] == lanes
-        seen.add(lanes)
+        assert M.handle.info()["lanes_per_row"] == _plan_lanes(mean)
+        seen.add((mean >= 48, _plan_lanes(mean)))
         if bs <= 12:
             _spmv_check(hip_engine, infl.B, seed=5, alpha=2.0, beta=-1.0)
-    assert seen == {1, 2, 4, 8, 16, 32, 64}
+    rng = np.random.default_rng(3)
+    for m, n in ((24, 1100), (24, 3500)):      # dense rows: 64 lanes per row
+        mat = sp.csr_matrix(rng.standard_normal((m, n)))
+        M = _spmv_check(hip_engine, mat, seed=m + n)
+        assert M.handle.info()["lanes_per_row"] == _plan_lanes(float(n))
+        seen.add((True, _plan_lanes(float(n))))
+    # long-row matrix with rows beyond the 4096-product chunk (whole-workgroup row reduction)
+    lens = np.full(400, 60)
+    lens[7], lens[399] = 4500, 9000
+    rows = np.repeat(np.arange(400), lens)
+    cols = np.concatenate([rng.choice(12000, size=k, replace=False) for k in lens])
+    mat = sp.csr_matrix((rng.standard_normal(rows.size), (rows, cols)), shape=(400, 12000))
+    _spmv_check(hip_engine, mat, seed=8, alpha=-0.5, beta=2.0)
+    assert {l for long_rows, l in seen if not long_rows} == {1, 2, 4}
+    assert {l for long_rows, l in seen if long_rows} == {2, 4, 8, 16, 32, 64}
 
 
 def test_spmv_ragged_empty_and_long_rows(hip_engine):
