@@ -48,9 +48,12 @@ namespace nss {
 constexpr int kChunk = NSS_CHUNK;       // products staged per workgroup: 16 KiB of LDS
 // Matrices with long rows (mean >= kLongRowMean non-zeros) stage twice as many: a row block then
 // holds enough rows to keep the phase-2 lanes busy and 16 loads per lane are in flight (K2 +5 % at
-// 82 non-zeros per row); short-row matrices lose occupancy to the 32 KiB and stay at kChunk.
+// 82 non-zeros per row, +1.5 % at 34); short-row matrices lose occupancy to the 32 KiB and stay at kChunk.
 constexpr int kChunkLong = 2 * kChunk;
-constexpr int kLongRowMean = 48;
+#ifndef NSS_LONG_ROW_MEAN
+#define NSS_LONG_ROW_MEAN 32
+#endif
+constexpr int kLongRowMean = NSS_LONG_ROW_MEAN;
 constexpr int kMaxRowsPerBlock = 2048;  // bound for blocks of empty / very short rows
 constexpr int kXcds = 8;
 constexpr int kWindows = 16;          // column windows per row block of the 16-bit index stream
