@@ -209,18 +209,49 @@ def bpcg_v1(A, B, pre_a, pre_s, f, g, k, x0=None, tolerance=1e-12, max_steps=100
 
 
 # --------------------------------------------------------------------------
-# BPCG v2  (solvers/bramblepasciak_new.py:24-253, non-condensed branch)
+# BPCG v2  (solvers/bramblepasciak_new.py:24-253, both branches of harmonic_extension)
 # --------------------------------------------------------------------------
+class CondensedOperator:
+    """`myAmatrix` (solvers/bramblepasciak_new.py:84-103): x -> (I - H^T)(S + A_ii)(I - H) x,
+    evaluated right to left as the reference's composite operator does (:88,91)."""
+
+    def __init__(self, S, inner_matrix, H, HT):
+        self.mid = (sp.csr_matrix(S) + sp.csr_matrix(inner_matrix)).tocsr()
+        self.H, self.HT = sp.csr_matrix(H), sp.csr_matrix(HT)
+        self.shape = self.mid.shape
+
+    def __matmul__(self, x):
+        t = x - self.H @ x
+        t = self.mid @ t
+        return t - self.HT @ t
+
+
 def bpcg_v2(A, B, pre_a_unscaled, pre_m, f, g, k, x0=None, tol=1e-6, maxsteps=100,
-            rel_err=True, timing=None):
-    """Returns (it, u, p, history) where history[i] = sqrt(|wd|) printed at
+            rel_err=True, timing=None, condensed=None):
+    """Returns (it, u, p, history, err0) where history[i] = sqrt(|wd|) printed at
     iteration i (:243-245) and history has it+1 entries.  `x0` = (u0, p0) is the
-    warm start (initialize=False, :137-139); None = zero start."""
+    warm start (initialize=False, :137-139); None = zero start.
+
+    `condensed` = dict(harmonic_extension, harmonic_extension_trans, inner_solve, inner_matrix)
+    (scipy CSR, n_u x n_u) selects the `blfA.condense` branch: `A` is then the Schur complement
+    `blfA.mat`, the operator is `myAmatrix` (:84-109) and every preconditioner apply goes through
+    the condensed branch of `harmonic_extension` (:11-18)."""
     BT = B.T.tocsr()                             # :198 (built once)
     n_u, n_p = A.shape[0], B.shape[0]
 
-    def pre_a(x):                                # preA = k * preA_unscaled (:122), plain branch of harmonic_extension (:20)
-        return k * pre_a_unscaled(x)
+    if condensed is None:
+        def pre_a(x):                            # preA = k * preA_unscaled (:122), plain branch of harmonic_extension (:20)
+            return k * pre_a_unscaled(x)
+    else:
+        H, HT = sp.csr_matrix(condensed["harmonic_extension"]), sp.csr_matrix(condensed["harmonic_extension_trans"])
+        inner_solve = sp.csr_matrix(condensed["inner_solve"])
+        A = CondensedOperator(A, condensed["inner_matrix"], H, HT)     # :105-106
+
+        def pre_a(x):                            # harmonic_extension(), condensed branch
+            f_residual = x + HT @ x              # :12-13
+            result = k * pre_a_unscaled(f_residual)   # :15
+            result = result + H @ result         # :16
+            return result + inner_solve @ f_residual  # :17
 
     tmp0 = pre_a(f)                              # :129
     f_new = A @ tmp0 - f                         # :130

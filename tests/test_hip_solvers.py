@@ -16,6 +16,7 @@ import numpy as np
 import pytest
 
 from conftest import GOLDEN, golden_path, iteration_tolerance
+from golden_cases import Case
 from staggered_grid import diffusion_2d, mac_stokes
 
 pytestmark = pytest.mark.gpu
@@ -28,15 +29,58 @@ class Form:
         self.mat, self.condense = mat, False
 
 
-def operands(d):
+class CondensedFormOf:
+    """`blfA` with `condense = True` over the operators of a golden case
+    (solvers/bramblepasciak_new.py:11-17,88,105-109)."""
+
+    def __init__(self, parts):
+        import hipla
+        self.condense = True
+        self.mat = hipla.SparseMatrix.from_scipy(parts["mat"])
+        for key in ("inner_matrix", "inner_solve", "harmonic_extension", "harmonic_extension_trans"):
+            setattr(self, key, hipla.SparseMatrix.from_scipy(parts[key]))
+
+
+def case_operands(d):
+    """Device operands of a golden fixture: (Case, blfA, A, B, preA, preS)."""
     import hipla
-    s = mac_stokes(int(d["dim"]), int(d["n"]), float(d["nu"]))
-    f, g = s.rhs(int(d["seed"]))
+    c = Case(d)
+    s = c.system
     A = hipla.SparseMatrix.from_scipy(s.A)
     B = hipla.SparseMatrix.from_scipy(s.B)
-    preA = hipla.JacobiPreconditioner(A) if str(d["pre"]) == "jacobi" else hipla.BlockJacobi(A, s.line_blocks(3))
-    preS = hipla.DiagonalMatrix(1.0 / s.mass)
-    return s, f, g, A, B, preA, preS
+    blfA = CondensedFormOf(c.parts) if c.condense else Form(A)
+    if c.blocks is None:
+        preA = hipla.DiagonalMatrix(c.jacobi_diagonal()) if c.condense else hipla.JacobiPreconditioner(A)
+    else:
+        preA = hipla.BlockJacobi(blfA.mat, c.blocks)
+    return c, blfA, A, B, preA, hipla.DiagonalMatrix(1.0 / s.mass)
+
+
+def operands(d):
+    c, _, A, B, preA, preS = case_operands(d)
+    assert not c.condense
+    return c.system, c.f, c.g, A, B, preA, preS
+
+
+@contextlib.contextmanager
+def fused_loops_counted():
+    """Counts the runs of the device-resident loops, so that a test can assert that the fused HIP
+    path (not the statement-by-statement protocol path) produced what it compares."""
+    from hipla import fused
+    counts = {"bpcg2": 0, "bpcg1": 0, "minres": 0}
+    saved = {}
+    for key, cls in (("bpcg2", fused.Bpcg2Loop), ("bpcg1", fused.Bpcg1Loop), ("minres", fused.MinresLoop)):
+        saved[cls] = cls.run
+
+        def counting(self, *a, _key=key, _orig=cls.run, **kw):
+            counts[_key] += 1
+            return _orig(self, *a, **kw)
+        cls.run = counting
+    try:
+        yield counts
+    finally:
+        for cls, orig in saved.items():
+            cls.run = orig
 
 
 def check_history(h, ref, window, rtol=1e-8):
@@ -65,10 +109,23 @@ def test_entry_points_match_goldens(hip_engine, case):
     from minres import MinRes
     from solvers.bramblepasciak_new import BramblePasciakCG
     d = np.load(golden_path(case))
-    s, f, g, A, B, preA, preS = operands(d)
+    c, blfA, A, B, preA, preS = case_operands(d)
+    s, f, g = c.system, c.f, c.g
     fv, gv = hipla.Vector.from_numpy(f), hipla.Vector.from_numpy(g)
     solver = str(d["solver"])
     out = io.StringIO()
+    with fused_loops_counted() as counts:
+        x = _run_entry_point(d, solver, c, blfA, A, B, preA, preS, fv, gv, out)
+    assert counts[solver] == 1, "the fused device loop did not run: %r" % (counts,)
+    check_solution(x, s, f, g, d)
+
+
+def _run_entry_point(d, solver, c, blfA, A, B, preA, preS, fv, gv, out):
+    import hipla
+    from bramble_pasciak_cg import bramble_pasciak_cg
+    from minres import MinRes
+    from solvers.bramblepasciak_new import BramblePasciakCG
+    s = c.system
     if solver == "bpcg1":
         with contextlib.redirect_stdout(out):
             sol, errors = bramble_pasciak_cg(A, B, None, preA, preS, fv, gv, tolerance=float(d["tol"]),
@@ -81,7 +138,7 @@ def test_entry_points_match_goldens(hip_engine, case):
     elif solver == "bpcg2":
         sol = hipla.BlockVector([hipla.Vector(s.n_u), hipla.Vector(s.n_p)])
         with contextlib.redirect_stdout(out):
-            it, seconds = BramblePasciakCG(Form(A), Form(B), None, fv, gv, preA, preS, sol, tol=float(d["tol"]),
+            it, seconds = BramblePasciakCG(blfA, Form(B), None, fv, gv, preA, preS, sol, tol=float(d["tol"]),
                                            maxsteps=int(d["maxsteps"]), printrates=True)
         text = out.getvalue()
         hist = np.array([float(m) for m in re.findall(r"it =\s+\d+\s+err =\s+(\S+)", text)])
@@ -101,7 +158,7 @@ def test_entry_points_match_goldens(hip_engine, case):
         check_iterations(len(errors) - 1, d["iterations"], d)
         assert ("Warning" in out.getvalue()) == bool(d["warned"])
         x = u.numpy()
-    check_solution(x, s, f, g, d)
+    return x
 
 
 def test_protocol_path_with_user_subclasses(hip_engine):
