@@ -25,6 +25,23 @@ for _p in (ROOT, os.path.join(ROOT, "navier-stokes-solver_amd")):
         sys.path.insert(0, _p)
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s)
+HBM_ACHIEVABLE_GBS = 6290.0  # measured float4 copy, same guide ("8 TB/s peak (spec); ~6.3 TB/s achievable")
+
+
+def csrc_digest():
+    """sha256 over the kernel sources (csrc/*.hip, *.h, include/nss_krylov.h): stored with every PMC
+    traffic profile, so that a profile taken with other kernels is not replayed as this run's traffic."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "navier-stokes-solver_amd", "csrc", "*.hip"))
+                   + glob.glob(os.path.join(ROOT, "navier-stokes-solver_amd", "csrc", "*.h"))
+                   + [os.path.join(ROOT, "include", "nss_krylov.h")])
+    for path in files:
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
 
 
 def parse_args():
@@ -52,12 +69,15 @@ class Form:
 
 
 def pmc_traffic(kernel_substring, workload_args):
-    """HBM bytes per launch of the dominant kernel from the latest committed rocprofv3 PMC
-    passes (profiles/*_traffic.json, written by tools/profile_bench.sh on this same command;
-    FETCH_SIZE corrected x2 as MI355X_MICROARCH.md prescribes, calibrated on the triad kernel).
-    None when no profile of this workload is committed."""
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/*_traffic.json, written by tools/profile_bench.sh on this same command; FETCH_SIZE
+    corrected x2 as MI355X_MICROARCH.md prescribes, calibrated on the triad kernel).  PMC counters
+    cannot be read from inside an unprofiled run, so the figure comes from a profile -- but only from
+    one taken with EXACTLY these kernel sources (`csrc_sha256` stored in the profile == csrc_digest()
+    now).  Returns (record-or-None, note)."""
     import glob
-    best = None
+    digest = csrc_digest()
+    best, note = None, "no PMC profile of this workload under profiles/"
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json"))):
         try:
             with open(path) as fh:
@@ -66,10 +86,16 @@ def pmc_traffic(kernel_substring, workload_args):
             continue
         if doc.get("workload") and doc["workload"] != workload_args:
             continue
+        if doc.get("csrc_sha256") != digest:
+            if best is None:
+                note = ("%s was taken with other kernel sources (csrc hash differs): not replayed"
+                        % os.path.relpath(path, ROOT))
+            continue
         for name, rec in doc.get("kernels", {}).items():
             if kernel_substring in name:
                 best = {"bytes": rec["hbm_bytes_per_launch"], "source": os.path.relpath(path, ROOT)}
-    return best
+                note = "rocprofv3 PMC passes of this command with these kernel sources (profile, not this run)"
+    return best, note
 
 
 def event_time_ms(torch, fn, reps):
@@ -410,7 +436,7 @@ def main():
 
     # per-iteration algorithmic bytes (DESIGN.md section "bytes per iteration")
     n_u, n_p = sysm.n_u, sysm.n_p
-    mat_bytes = sum(12 * i["nnz"] + 4 * (i["rows"] + 1) for i in (a_info, b_info, bt_info))
+    mat_bytes = sum((8 + i["index_bytes"]) * i["nnz"] + 4 * (i["rows"] + 1) for i in (a_info, b_info, bt_info))
     if args.pre == "amg":      # per level: two SpMVs with A_l (residual, post-smoothing), one each with P_l, R_l
         spmv_bytes = lambda i: 12 * i["nnz"] + 4 * (i["rows"] + 1) + 8 * (i["rows"] + i["cols"])
         pre_bytes = 0
@@ -447,7 +473,8 @@ def main():
                   "history_max_rel_diff": float(np.max(np.abs(hist[:m] - hist_c[:m]) / np.abs(hist_c[:m]))),
                   "err0_rel_diff": abs(ses.err0 - err0_c) / err0_c}
 
-    traffic = pmc_traffic("EpiK2", "grid=%d dim=%d pre=%s" % (args.n, args.dim, args.pre))
+    traffic, traffic_note = pmc_traffic("EpiK2", "grid=%d dim=%d pre=%s" % (args.n, args.dim, args.pre))
+    k2_bytes_int32 = k2_bytes + (2 * a_info["nnz"] if a_info["index_bytes"] == 2 else 0)
     out = {
         "metric": "Krylov iters/sec, 3D SIMPLE Stokes solve (BPCG)", "value": K / elapsed, "unit": "iters/s",
         "n_gpus": 1, "steps": K, "warmup": W, "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True,
@@ -462,8 +489,13 @@ def main():
         "roofline": {"bound": "hbm", "kernel": "csr_stream_kernel<1, EpiK2> (A SpMV + fused t4 / <s0,v0>)",
                      "achieved": k2_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k2_gbs / HBM_PEAK_GBS,
                      "traffic": traffic["bytes"] if traffic else None,
-                     "traffic_source": traffic["source"] if traffic else None,
+                     "traffic_source": traffic["source"] if traffic else None, "traffic_note": traffic_note,
                      "algorithmic_bytes_per_launch": k2_bytes, "avg_launch_ms": k2_ms,
+                     "bytes_accounting": "value stream 8 B + column stream %d B per non-zero (as stored), row "
+                                         "pointers, x and y once, + t0, s0 read and t4 written by the fused epilogue"
+                                         % a_info["index_bytes"],
+                     "achieved_if_priced_as_int32_csr": k2_bytes_int32 / (k2_ms * 1e-3) / 1e9,
+                     "frac_of_achievable_6290": k2_gbs / HBM_ACHIEVABLE_GBS,
                      "frac_of_stream_triad": k2_gbs / triad_gbs,
                      "timing": "HIP events around the kernel inside %d iterations of the running loop" % (probe_its - 8)},
         "cpu_baseline": cpu,

@@ -254,6 +254,11 @@ typedef struct nss_bpcg2_s {
   nss_csr_t ghost_b;
   double *ghost_t3, *ghost_w1;
   const double* ghost_minv;
+  /* row-partitioned runs: SUM1 / SUM2 leave the LOCAL sums in scal[9] / scal[10] and the caller
+   * all-reduces them OUT OF PLACE into scal[1] (as_s) / scal[2] (wdn), so that the scalars stay frozen
+   * once the stop flag is set (the sum kernels then return early and every further all-reduce
+   * reproduces the same value).  0: the sums go straight to scal[1] / scal[2] (single GPU). */
+  int32_t local_sums;
 } nss_bpcg2_t;
 
 enum {

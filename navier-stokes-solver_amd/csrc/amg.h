@@ -24,6 +24,8 @@ struct nss_amg_s {
 };
 
 namespace nss {
-// x = V(bscale * b)
-void amg_apply(const nss_amg_s& a, double bscale, const double* b, double* x, hipStream_t st);
+// x = V(bscale * b); every kernel of the cycle returns at once when `done` (device int, may be NULL)
+// is non-zero: a solver that has stopped leaves x untouched
+void amg_apply(const nss_amg_s& a, double bscale, const double* b, double* x, hipStream_t st,
+               const int32_t* done = nullptr);
 }  // namespace nss

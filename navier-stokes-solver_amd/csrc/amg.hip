@@ -20,7 +20,8 @@ namespace nss {
 struct EpiResidual {   // r = b - A x
   const double* __restrict__ b;
   double* __restrict__ r;
-  __device__ bool skip() const { return false; }
+  const int32_t* __restrict__ done;
+  __device__ bool skip() const { return done != nullptr && *done != 0; }
   struct Pre { double b = 0.0; };
   __device__ Pre fetch(int i) const { return Pre{b[i]}; }
   __device__ void row(int i, double ax, const Pre& p) const { r[i] = p.b - ax; }
@@ -34,7 +35,8 @@ struct EpiJacobi {     // y = scale * (x + w dinv (b - A x))
   double* __restrict__ y;
   double w;
   double scale;
-  __device__ bool skip() const { return false; }
+  const int32_t* __restrict__ done;
+  __device__ bool skip() const { return done != nullptr && *done != 0; }
   struct Pre { double b = 0.0, x = 0.0, dinv = 0.0; };
   __device__ Pre fetch(int i) const { return Pre{b[i], x[i], dinv[i]}; }
   __device__ void row(int i, double ax, const Pre& p) const { y[i] = scale * fma(w * p.dinv, p.b - ax, p.x); }
@@ -43,33 +45,36 @@ struct EpiJacobi {     // y = scale * (x + w dinv (b - A x))
 
 // y = s * d .* x
 __global__ __launch_bounds__(kBlock) void amg_diag_kernel(int32_t n, double s, const double* __restrict__ d,
-                                                           const double* __restrict__ x, double* __restrict__ y) {
+                                                           const double* __restrict__ x, double* __restrict__ y,
+                                                           const int32_t* __restrict__ done) {
+  if (done != nullptr && *done != 0) return;
   const int stride = gridDim.x * kBlock;
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) y[i] = s * (d[i] * x[i]);
 }
 
 // out = scale * V_l(b); the cycle is linear, so the scale factor of the outermost call (preA = k V)
 // rides in the last kernel instead of a pass over the right-hand side
-static void cycle(const nss_amg_s& a, int l, const double* b, double* out, hipStream_t st, double scale = 1.0) {
+static void cycle(const nss_amg_s& a, int l, const double* b, double* out, hipStream_t st, const int32_t* done,
+                  double scale = 1.0) {
   const AmgLevel& lv = a.levels[l];
   if (l == int(a.levels.size()) - 1) {
-    launch_csr_stream(*a.coarse_inverse, b, EpiAxpby{scale, 0.0, out}, st);   // x = A^-1 b
+    launch_csr_stream(*a.coarse_inverse, b, EpiAxpby{scale, 0.0, out, done}, st);   // x = A^-1 b
     return;
   }
   const int n = lv.n;
   hipLaunchKernelGGL(amg_diag_kernel, dim3(stream_grid(n, kBlock * 4)), dim3(kBlock), 0, st, n, a.omega, lv.dinv, b,
-                     lv.x);
+                     lv.x, done);
   NSS_CHECK_LAUNCH();
-  launch_csr_stream(*lv.A, lv.x, EpiResidual{b, lv.r}, st);
+  launch_csr_stream(*lv.A, lv.x, EpiResidual{b, lv.r, done}, st);
   const AmgLevel& next = a.levels[l + 1];
-  launch_csr_stream(*lv.R, lv.r, EpiAxpby{1.0, 0.0, next.b}, st);
-  cycle(a, l + 1, next.b, next.y, st);
-  launch_csr_stream(*lv.P, next.y, EpiAxpby{1.0, 1.0, lv.x}, st);
-  launch_csr_stream(*lv.A, lv.x, EpiJacobi{b, lv.x, lv.dinv, out, a.omega, scale}, st);
+  launch_csr_stream(*lv.R, lv.r, EpiAxpby{1.0, 0.0, next.b, done}, st);
+  cycle(a, l + 1, next.b, next.y, st, done);
+  launch_csr_stream(*lv.P, next.y, EpiAxpby{1.0, 1.0, lv.x, done}, st);
+  launch_csr_stream(*lv.A, lv.x, EpiJacobi{b, lv.x, lv.dinv, out, a.omega, scale, done}, st);
 }
 
-void amg_apply(const nss_amg_s& a, double bscale, const double* b, double* x, hipStream_t st) {
-  cycle(a, 0, b, x, st, bscale);
+void amg_apply(const nss_amg_s& a, double bscale, const double* b, double* x, hipStream_t st, const int32_t* done) {
+  cycle(a, 0, b, x, st, done, bscale);
 }
 
 }  // namespace nss

@@ -111,7 +111,9 @@ __global__ __launch_bounds__(kBlock) void triad_kernel(int64_t n, double a, cons
 // y = alpha * d .* x + beta * y
 template <bool VEC2, bool BETA>
 __global__ __launch_bounds__(kBlock) void diag_kernel(int64_t n, const double* __restrict__ d, double alpha,
-                                                       const double* x, double beta, double* y) {
+                                                       const double* x, double beta, double* y,
+                                                       const int32_t* __restrict__ done) {
+  if (done != nullptr && *done != 0) return;
   const int64_t stride = int64_t(gridDim.x) * kBlock;
   int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x;
   if (VEC2) {
@@ -145,6 +147,22 @@ __global__ __launch_bounds__(kBlock) void gather_kernel(int64_t n, const int32_t
                                                          const double* __restrict__ src, double* __restrict__ dst) {
   const int64_t stride = int64_t(gridDim.x) * kBlock;
   for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride) dst[i] = src[idx[i]];
+}
+
+// y = alpha * d .* x + beta * y; no-op on the device once *done != 0 (done may be NULL)
+void diag_apply(int64_t n, const double* d, double alpha, const double* x, double beta, double* y, const int32_t* done,
+                hipStream_t st) {
+  if (n <= 0) return;
+  const int grid = stream_grid(n, kBlock * 4);
+  const bool vec = aligned16(d) && aligned16(x) && aligned16(y);
+  if (beta == 0.0) {
+    if (vec) hipLaunchKernelGGL((diag_kernel<true, false>), dim3(grid), dim3(kBlock), 0, st, n, d, alpha, x, beta, y, done);
+    else hipLaunchKernelGGL((diag_kernel<false, false>), dim3(grid), dim3(kBlock), 0, st, n, d, alpha, x, beta, y, done);
+  } else {
+    if (vec) hipLaunchKernelGGL((diag_kernel<true, true>), dim3(grid), dim3(kBlock), 0, st, n, d, alpha, x, beta, y, done);
+    else hipLaunchKernelGGL((diag_kernel<false, true>), dim3(grid), dim3(kBlock), 0, st, n, d, alpha, x, beta, y, done);
+  }
+  NSS_CHECK_LAUNCH();
 }
 
 void gather_launch(int64_t n, const int32_t* idx, const double* src, double* dst, hipStream_t st) {
@@ -359,20 +377,7 @@ int nss_stream_triad_f64(int64_t n, double a, const double* x, const double* y, 
 
 int nss_diag_apply_f64(int64_t n, const double* d, double alpha, const double* x, double beta, double* y,
                        nss_stream_t stream) {
-  return guarded([&] {
-    if (n <= 0) return;
-    const int grid = stream_grid(n, kBlock * 4);
-    const bool vec = aligned16(d) && aligned16(x) && aligned16(y);
-    hipStream_t st = as_stream(stream);
-    if (beta == 0.0) {
-      if (vec) hipLaunchKernelGGL((diag_kernel<true, false>), dim3(grid), dim3(kBlock), 0, st, n, d, alpha, x, beta, y);
-      else hipLaunchKernelGGL((diag_kernel<false, false>), dim3(grid), dim3(kBlock), 0, st, n, d, alpha, x, beta, y);
-    } else {
-      if (vec) hipLaunchKernelGGL((diag_kernel<true, true>), dim3(grid), dim3(kBlock), 0, st, n, d, alpha, x, beta, y);
-      else hipLaunchKernelGGL((diag_kernel<false, true>), dim3(grid), dim3(kBlock), 0, st, n, d, alpha, x, beta, y);
-    }
-    NSS_CHECK_LAUNCH();
-  });
+  return guarded([&] { diag_apply(n, d, alpha, x, beta, y, nullptr, as_stream(stream)); });
 }
 
 }  // extern "C"

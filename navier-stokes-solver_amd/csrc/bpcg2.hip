@@ -28,7 +28,13 @@
 
 namespace nss {
 
-enum { S_WD = 0, S_AS = 1, S_WDN = 2, S_ALPHA = 3, S_BETA = 4, S_ERR0 = 5, S_TOL = 6, S_REL = 7, S_WD_ODD = 8 };
+enum { S_WD = 0, S_AS = 1, S_WDN = 2, S_ALPHA = 3, S_BETA = 4, S_ERR0 = 5, S_TOL = 6, S_REL = 7, S_WD_ODD = 8,
+       S_AS_LOCAL = 9, S_WDN_LOCAL = 10 };
+// Row-partitioned runs (nss_bpcg2_t.local_sums): the local sums go to S_AS_LOCAL / S_WDN_LOCAL and the
+// all-reduce writes S_AS / S_WDN out of place.  Once the loop has stopped the sum kernels return early,
+// the local slots keep their last value and every further all-reduce reproduces the same global sum:
+// the poll-visible scalars stay frozen (an in-place all-reduce of a frozen slot would multiply it by
+// the number of ranks each time).
 // wd of iteration `it` lives in slot S_WD (it even) or S_WD_ODD (it odd): K5 of iteration it writes
 // the slot of it+1 while its other lanes still read the slot of it.
 __device__ __forceinline__ int wd_slot(int it) { return (it & 1) ? S_WD_ODD : S_WD; }
@@ -96,7 +102,8 @@ struct EpiK2 {
   __device__ void finish(int b, double* lds) {
     const double s = block_sum(acc, lds);
     if (threadIdx.x == 0 && b >= 0) partials[b] = s;
-    const int stride = gridDim.x * kBlock;   // t1's ghosts arrived before this launch
+    // ghost_n > 0 only in a launch that is ordered after the arrival of t1's ghosts
+    const int stride = gridDim.x * kBlock;
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < ghost_n; i += stride) ghost_t4[i] = t1[ghost_map[i]] - ghost_s0[i];
   }
 };
@@ -353,7 +360,7 @@ void bpcg2_check_state(const nss_bpcg2_t* s) {
 
 // SpMV phases over the row blocks [b0, b1) of their matrix (b1 < 0: all).  The block-Jacobi
 // apply that completes K1 is a separate step (`bpcg2_k1_finish`) because it needs all of t0.
-void bpcg2_spmv_phase(const nss_bpcg2_t& s, int which, int it, hipStream_t st, int b0, int b1) {
+void bpcg2_spmv_phase(const nss_bpcg2_t& s, int which, int it, hipStream_t st, int b0, int b1, bool ghost_tail) {
   switch (which) {
     case NSS_BPCG2_K1: {
       // the point-Jacobi apply rides in the epilogue unless an AMG term comes first
@@ -363,7 +370,7 @@ void bpcg2_spmv_phase(const nss_bpcg2_t& s, int which, int it, hipStream_t st, i
       break;
     }
     case NSS_BPCG2_K2: {
-      EpiK2 e{s.ctrl, s.t0, s.t1, s.s0, s.t2, s.t4, s.partials_a, s.ghost_mode ? s.ghost_n : 0, s.ghost_map,
+      EpiK2 e{s.ctrl, s.t0, s.t1, s.s0, s.t2, s.t4, s.partials_a, (s.ghost_mode && ghost_tail) ? s.ghost_n : 0, s.ghost_map,
               s.ghost_s0, s.t4 + s.n_u};
       launch_csr_stream(*s.A, s.t1, e, st, b0, b1);
       break;
@@ -386,12 +393,9 @@ void bpcg2_k1_finish(const nss_bpcg2_t& s, hipStream_t st) {
     launch_csr_stream(*s.cond_HT, s.t0, EpiLift{s.ctrl, s.t0, s.cond_f}, st);
     src = s.cond_f;
   }
-  auto diag = [&](double beta) {
-    const int rc = nss_diag_apply_f64(s.n_u, s.pre_diag, s.k, src, beta, s.t1, st);
-    if (rc != 0) throw Error(nss_last_error());
-  };
+  auto diag = [&](double beta) { diag_apply(s.n_u, s.pre_diag, s.k, src, beta, s.t1, s.ctrl, st); };
   if (s.pre_amg) {
-    amg_apply(*s.pre_amg, s.k, src, s.t1, st);
+    amg_apply(*s.pre_amg, s.k, src, s.t1, st, s.ctrl);
     if (s.pre_bjac) bjac_apply(*s.pre_bjac, s.k, src, 1.0, s.t1, s.ctrl, st);
     if (s.pre_diag) diag(1.0);
   } else if (s.pre_bjac) {
@@ -417,7 +421,7 @@ void bpcg2_phase(const nss_bpcg2_t& s, int which, int it, hipStream_t st) {
       break;
     case NSS_BPCG2_SUM1:
       hipLaunchKernelGGL(bpcg2_sum_kernel, dim3(1), dim3(kSumBlock), 0, st, s.ctrl, s.A->nblk, s.partials_a, s.B->nblk,
-                         s.partials_b, s.scal, int(S_AS));
+                         s.partials_b, s.scal, int(s.local_sums ? S_AS_LOCAL : S_AS));
       NSS_CHECK_LAUNCH();
       break;
     case NSS_BPCG2_ALPHA:   // folded into K4 (kept as a phase id for callers that list all phases)
@@ -434,7 +438,7 @@ void bpcg2_phase(const nss_bpcg2_t& s, int which, int it, hipStream_t st) {
     }
     case NSS_BPCG2_SUM2:
       hipLaunchKernelGGL(bpcg2_sum_kernel, dim3(1), dim3(kSumBlock), 0, st, s.ctrl, k4_grid(s), s.partials_c, 0,
-                         s.partials_c, s.scal, int(S_WDN));
+                         s.partials_c, s.scal, int(s.local_sums ? S_WDN_LOCAL : S_WDN));
       NSS_CHECK_LAUNCH();
       break;
     case NSS_BPCG2_BETA:    // folded into K5

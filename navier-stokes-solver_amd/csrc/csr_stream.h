@@ -290,8 +290,9 @@ inline void launch_csr_stream(const nss_csr_s& A, const double* x, const Epi& ep
 struct EpiAxpby {
   double alpha, beta;
   double* __restrict__ y;
+  const int32_t* __restrict__ done = nullptr;   // solver stop flag (device), or NULL
   struct Pre { double y = 0.0; };
-  __device__ bool skip() const { return false; }
+  __device__ bool skip() const { return done != nullptr && *done != 0; }
   __device__ Pre fetch(int r) const { return Pre{beta != 0.0 ? y[r] : 0.0}; }
   __device__ void row(int r, double ax, const Pre& p) const {
     double t = alpha * ax;

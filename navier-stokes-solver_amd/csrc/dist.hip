@@ -36,7 +36,7 @@ namespace nss {
 
 constexpr int kNcclFloat64 = 8;
 constexpr int kNcclSum = 0;
-enum { S_AS_SLOT = 1, S_WDN_SLOT = 2 };
+enum { S_AS_SLOT = 1, S_WDN_SLOT = 2, S_LOCAL_OFFSET = 8 };   // local sums: slots 9 / 10 (bpcg2.hip)
 
 static void nccl_check(const nss_dist_s& d, int rc, const char* what) {
   if (rc != 0) throw Error(std::string(what) + ": " + (d.GetErrorString ? d.GetErrorString(rc) : "RCCL error"));
@@ -107,25 +107,43 @@ static void spmv_with_halo(const nss_bpcg2_t& s, const nss_dist_s& d, const nss_
   }
   if (overlap_mode == 3) {             // measurement only: the split launches without the second stream
     exchange(d, h, cs);
-    bpcg2_spmv_phase(s, which, it, cs, h.int_begin, h.int_end);
-    bpcg2_spmv_phase(s, which, it, cs, 0, h.int_begin);
-    bpcg2_spmv_phase(s, which, it, cs, h.int_end, mat.nblk);
+    const bool has_suffix = h.int_end < mat.nblk;
+    bpcg2_spmv_phase(s, which, it, cs, h.int_begin, h.int_end, !has_suffix && h.int_begin == 0);
+    bpcg2_spmv_phase(s, which, it, cs, 0, h.int_begin, !has_suffix);
+    bpcg2_spmv_phase(s, which, it, cs, h.int_end, mat.nblk, true);
     return;
   }
   NSS_HIP(hipEventRecord(d.ev_ready[slot], cs));
   NSS_HIP(hipStreamWaitEvent(d.xstream, d.ev_ready[slot], 0));
   exchange(d, h, d.xstream);
   NSS_HIP(hipEventRecord(d.ev_halo[slot], d.xstream));
-  bpcg2_spmv_phase(s, which, it, cs, h.int_begin, h.int_end);          // interior: no ghost columns
+  // interior rows touch no ghost column; K2's ghost tail (t4 on B's ghost columns, from t1's ghosts)
+  // rides in exactly one launch that is ordered after the arrival of the halo
+  const bool has_prefix = h.int_begin > 0, has_suffix = h.int_end < mat.nblk;
+  if (!has_prefix && !has_suffix) {
+    NSS_HIP(hipStreamWaitEvent(cs, d.ev_halo[slot], 0));
+    bpcg2_spmv_phase(s, which, it, cs, h.int_begin, h.int_end, true);
+    return;
+  }
+  bpcg2_spmv_phase(s, which, it, cs, h.int_begin, h.int_end, false);
   NSS_HIP(hipStreamWaitEvent(cs, d.ev_halo[slot], 0));
-  bpcg2_spmv_phase(s, which, it, cs, 0, h.int_begin);                   // boundary prefix
-  bpcg2_spmv_phase(s, which, it, cs, h.int_end, mat.nblk);              // boundary suffix
+  bpcg2_spmv_phase(s, which, it, cs, 0, h.int_begin, !has_suffix);      // boundary prefix
+  bpcg2_spmv_phase(s, which, it, cs, h.int_end, mat.nblk, true);        // boundary suffix
 }
 
+__global__ void dist_copy_slot_kernel(double* scal, int dst, int src) { scal[dst] = scal[src]; }
+
 static void allreduce_slot(const nss_bpcg2_t& s, const nss_dist_s& d, int slot, hipStream_t cs) {
-  if (d.nranks <= 1 && d.comm == nullptr) return;
+  if (d.nranks <= 1 && d.comm == nullptr) {
+    if (s.local_sums) {   // one rank, no communicator: the "all-reduce" is a copy of the local sum
+      hipLaunchKernelGGL(dist_copy_slot_kernel, dim3(1), dim3(1), 0, cs, s.scal, slot, slot + S_LOCAL_OFFSET);
+      NSS_CHECK_LAUNCH();
+    }
+    return;
+  }
   if (d.comm == nullptr) throw Error("dist: no communicator");
-  nccl_check(d, d.AllReduce(s.scal + slot, s.scal + slot, 1, kNcclFloat64, kNcclSum, d.comm, cs), "ncclAllReduce");
+  const double* local = s.local_sums ? s.scal + slot + S_LOCAL_OFFSET : s.scal + slot;
+  nccl_check(d, d.AllReduce(local, s.scal + slot, 1, kNcclFloat64, kNcclSum, d.comm, cs), "ncclAllReduce");
 }
 
 }  // namespace nss

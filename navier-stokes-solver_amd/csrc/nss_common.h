@@ -43,7 +43,10 @@ namespace nss {
 
 constexpr int kWave = 64;
 constexpr int kBlock = 256;           // 4 waves: one per SIMD of a CU
-constexpr int kMaxStreamBlocks = 2048;  // 256 CUs x 8 resident blocks: grid-stride the rest
+#ifndef NSS_MAX_STREAM_BLOCKS
+#define NSS_MAX_STREAM_BLOCKS 2048
+#endif
+constexpr int kMaxStreamBlocks = NSS_MAX_STREAM_BLOCKS;  // 256 CUs x 8 resident blocks: grid-stride the rest
 
 void set_error(const char* fmt, ...);
 
@@ -126,5 +129,9 @@ struct Scratch {
   static constexpr int kMaxPartials = 4 * kMaxStreamBlocks;
 };
 Scratch& scratch();
+
+// y = alpha * d .* x + beta * y (blas1.hip); returns at once on the device when *done != 0 (NULL: never)
+void diag_apply(int64_t n, const double* d, double alpha, const double* x, double beta, double* y, const int32_t* done,
+                hipStream_t st);
 
 }  // namespace nss

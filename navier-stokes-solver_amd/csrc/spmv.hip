@@ -260,7 +260,13 @@ int nss_csr_info(nss_csr_t a, int32_t* nrows, int32_t* ncols, int64_t* nnz, int3
     if (nnz) *nnz = a->nnz;
     if (nblocks) *nblocks = a->nblk;
     if (lanes_per_row) *lanes_per_row = a->rg;
-    if (algorithmic_bytes) *algorithmic_bytes = 12 * a->nnz + 4 * (int64_t(a->m) + 1) + 8 * int64_t(a->n) + 8 * int64_t(a->m);
+    // bytes one y = A x launch has to move: the value and the column stream THIS matrix is stored with
+    // (2-byte window-relative columns + 16 window bases per row block, or 4-byte columns), the row
+    // pointers, x once and y once.  (The CSR fp64/int32 textbook figure is 12 nnz + ...; pricing a
+    // launch that streams 10 bytes per entry at 12 would overstate its bandwidth.)
+    if (algorithmic_bytes)
+      *algorithmic_bytes = (a->col16 ? 10 * a->nnz + int64_t(4) * kWindows * a->nblk : 12 * a->nnz) +
+                           4 * (int64_t(a->m) + 1) + 8 * int64_t(a->n) + 8 * int64_t(a->m);
   });
 }
 

@@ -133,6 +133,12 @@ class TorchComm:
     def _t(self, buf):
         return buf if isinstance(buf, self.torch.Tensor) else self.torch.from_numpy(buf)
 
+    def allreduce_sum_into(self, src, dst):
+        """dst = sum over ranks of src (out of place; the fused loop's scalars: see
+        nss_bpcg2_t.local_sums)."""
+        self.engine.copy(src, dst)
+        self.allreduce_sum(dst)
+
     def allreduce_sum(self, buf):
         if self.size == 1:
             return
@@ -684,8 +690,8 @@ class DistributedBpcg2:
                 elif kind == "halo":
                     mat, hv = self.halo[what]
                     mat.exchange(hv)
-                else:
-                    comm.allreduce_sum(loop.scal[what:what + 1])
+                else:                                    # local sum in scal[8 + what] -> global in scal[what]
+                    comm.allreduce_sum_into(loop.scal[8 + what:9 + what], loop.scal[what:what + 1])
 
     def poll(self):
         return self.loop.poll()

@@ -36,7 +36,8 @@ class Bpcg2State(C.Structure):
                 + [("ghost_mode", C.c_int32), ("ghost_n", C.c_int32), ("ghost_map", C.c_void_p),
                    ("ghost_s0", C.c_void_p), ("ghost_w0", C.c_void_p),
                    ("ghost_p_mode", C.c_int32), ("ghost_p_n", C.c_int32), ("ghost_b", C.c_void_p),
-                   ("ghost_t3", C.c_void_p), ("ghost_w1", C.c_void_p), ("ghost_minv", C.c_void_p)])
+                   ("ghost_t3", C.c_void_p), ("ghost_w1", C.c_void_p), ("ghost_minv", C.c_void_p),
+                   ("local_sums", C.c_int32)])
 
 
 class HaloStruct(C.Structure):
@@ -72,6 +73,8 @@ def native_bjac(op):
     scale = 1.0
     if isinstance(op, ScaledMatrix):
         scale, op = op.scale, op.mat
+    if isinstance(op, BlockGaussSeidel) and op.middle is not None:
+        return None                      # sweep + middle operator: protocol path
     if isinstance(op, (BlockJacobi, BlockGaussSeidel)):
         return scale, op
     return None
@@ -96,7 +99,8 @@ def native_velocity_pre(op):
             out["amg"] = part
         elif isinstance(part, DiagonalMatrix) and out["diag"] is None and out["bjac"] is None:
             out["diag"] = part
-        elif isinstance(part, (BlockJacobi, BlockGaussSeidel)) and out["diag"] is None and out["bjac"] is None:
+        elif (isinstance(part, (BlockJacobi, BlockGaussSeidel)) and out["diag"] is None and out["bjac"] is None
+              and getattr(part, "middle", None) is None):
             out["bjac"] = part
         else:
             return None
@@ -163,9 +167,9 @@ class Bpcg2Loop:
                 return None
             if not _extension_is_in_place_safe(condensed["H"]):
                 return None
-        return cls(eng, matA, matB, matBT, pa, k, pm, vecs, condensed)
+        return cls(eng, matA, matB, matBT, pa, k, pm, vecs, condensed, distributed)
 
-    def __init__(self, eng, matA, matB, matBT, pa, k, pm, vecs, condensed=None):
+    def __init__(self, eng, matA, matB, matBT, pa, k, pm, vecs, condensed=None, distributed=False):
         torch = eng.torch
         self.eng, self.lib = eng, eng.lib
         self.keep = [matA, matB, matBT, vecs, pa, pm, condensed]       # keep device memory alive
@@ -188,6 +192,7 @@ class Bpcg2Loop:
         for name in ("u0", "u1", "d0", "d1", "w0", "w1", "s0", "s1", "z0", "q", "t0", "t1", "t2", "t3", "t4"):
             setattr(st, name, vecs[name].buf.data_ptr())
         st.n_u, st.n_p = matA.height, matB.height
+        st.local_sums = 1 if distributed else 0     # the caller all-reduces scal[9], scal[10] into scal[1], scal[2]
         na, nb, nc = C.c_int64(), C.c_int64(), C.c_int64()
         eng._check(self.lib.nss_bpcg2_workspace(C.byref(st), C.byref(na), C.byref(nb), C.byref(nc)))
         self.partials = [eng.zeros(max(1, v.value)) for v in (na, nb, nc)]
@@ -301,6 +306,8 @@ class MinresLoop:
             pa_amg, pa_d, pa_b = _amg_plus_jacobi(pre[0, 0])
         if ps is None or (pa_d is None and pa_b is None and pa_amg is None):
             return None
+        if pa_b is not None and pa_b[0] != 1.0:
+            return None                  # scaled block Jacobi: the protocol path handles it
         vecs = [u, kz] + list(v_ring) + list(w_ring) + list(z_ring)
         if len(v_ring) != 3 or len(w_ring) != 3 or len(z_ring) != 2 or not all(_block2(x, n_u, n_p) for x in vecs):
             return None
@@ -322,9 +329,7 @@ class MinresLoop:
             self.dinv = scaled(pa_d)
             st.pre_diag, st.pre_bjac = self.dinv.data_ptr(), None
         elif pa_b is not None:
-            scale, op = pa_b
-            if scale != 1.0:
-                raise ValueError("scaled block-Jacobi is not supported by the fused MINRES loop")
+            scale, op = pa_b             # scale == 1.0 (try_create declines anything else)
             st.pre_diag, st.pre_bjac = None, op.handle.ptr
         else:
             st.pre_diag, st.pre_bjac = None, None
@@ -488,7 +493,7 @@ class CgLoop:
             kind = ("none", None)
         elif isinstance(pre, DiagonalMatrix):
             kind = ("diag", pre)
-        elif isinstance(pre, (BlockJacobi, BlockGaussSeidel)):
+        elif isinstance(pre, (BlockJacobi, BlockGaussSeidel)) and getattr(pre, "middle", None) is None:
             kind = ("bjac", pre)
         elif isinstance(pre, SmoothedAggregationAMG):
             kind = ("amg", pre)

@@ -544,8 +544,8 @@ class BlockJacobi(BaseMatrix):
     inverses are computed once in the engine and stored block-interleaved in HBM;
     apply is ``block_jacobi_apply_f64``.  Dofs in no block map to zero.
 
-    The multiplicative sweeps ``Smooth``/``SmoothBack`` (GS=True, :376-381) are
-    scope row N1 of SURVEY.md section 8f and not implemented."""
+    The multiplicative sweeps ``Smooth``/``SmoothBack`` (GS=True, :376-381) live in
+    `BlockGaussSeidel` (multicolour ordering, scope row N1 of SURVEY.md section 8f)."""
 
     def __init__(self, mat, blocks):
         super().__init__()
@@ -622,14 +622,19 @@ class BlockGaussSeidel(BaseMatrix):
     (``nss_bjac_smooth_f64``); the ordering differs from NGSolve's mesh-facet order (upstream,
     not visible), so iteration counts are pinned against the build's own CPU oracle only."""
 
-    def __init__(self, mat, blocks, seed=0, colors=None):
+    def __init__(self, mat, blocks, seed=0, colors=None, middle=None):
         """`colors` (one int per block) may be supplied when the system has already been
         re-ordered colour-major on the host (`coloring.colour_permutation`): the sweep then
-        touches x, y and the inverse blocks contiguously."""
+        touches x, y and the inverse blocks contiguously.
+
+        `middle` (an operator M, e.g. the auxiliary-space term ``T @ AMG @ T.T``) reproduces the
+        full ``MypreA.Mult`` of the reference with ``GS=True`` (:376-381):
+        ``y = 0; Smooth(y, x); r = x - A y; y += M r; SmoothBack(y, x)``."""
         super().__init__()
         from . import coloring
         self.engine = mat.engine
         self.mat = mat
+        self.middle = middle
         self.n = mat.height
         base = BlockJacobi._as_table(blocks)
         on_device = colors is None and hasattr(self.engine, "graph_color")
@@ -701,9 +706,17 @@ class BlockGaussSeidel(BaseMatrix):
         self.engine.bjac_smooth(self.handle, 1.0, x.buf, y.buf, True)
 
     def Mult(self, x, y):
-        self.engine.bjac_apply(self.handle, 1.0, x.buf, 0.0, y.buf)      # GS-mode handle: symmetric sweep
+        if self.middle is None:
+            self.engine.bjac_apply(self.handle, 1.0, x.buf, 0.0, y.buf)  # GS-mode handle: symmetric sweep
+            return
+        y[:] = 0.0                                                       # :377
+        self.Smooth(y, x)                                                # :378
+        res = x.CreateVector()
+        res.data = x - self.mat * y                                      # :379
+        y.data += self.middle * res                                      # :380
+        self.SmoothBack(y, x)                                            # :381
 
-    MultTrans = Mult          # forward then backward sweep: symmetric operator
+    MultTrans = Mult          # forward then backward sweep (symmetric middle term): symmetric operator
 
     @property
     def T(self):
@@ -802,6 +815,9 @@ class Projector(BaseMatrix):
     MultTransAdd = MultAdd
 
 
+_WARNED = {}
+
+
 def Preconditioner(form, kind, blocks=None, **_):
     """``Preconditioner(blf, 'local')`` -> point Jacobi; ``'blockjacobi'`` -> additive block Jacobi
     over `blocks`; ``'h1amg'`` / ``'multigrid'`` -> the smoothed-aggregation V-cycle on the assembled
@@ -820,5 +836,11 @@ def Preconditioner(form, kind, blocks=None, **_):
         return BlockJacobi(mat, blocks)
     if kind in ("h1amg", "multigrid", "bddc"):
         from .amg import SmoothedAggregationAMG
+        if kind == "bddc" and not _WARNED.get(kind):
+            _WARNED[kind] = True
+            import warnings
+            warnings.warn("Preconditioner(..., 'bddc'): NGSolve's BDDC needs its FE spaces; a smoothed-aggregation "
+                          "V-cycle on the assembled matrix is used in its place (different iteration counts than "
+                          "the reference's)", stacklevel=2)
         return SmoothedAggregationAMG(mat)
     raise NotImplementedError("preconditioner %r is outside the hot-path scope (SURVEY.md section 8f)" % (kind,))

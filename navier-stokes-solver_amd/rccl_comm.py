@@ -71,6 +71,13 @@ class RcclComm(TorchComm):
         p = buf.data_ptr()
         self._check(self.lib.ncclAllReduce(p, p, buf.shape[0], NCCL_FLOAT64, NCCL_SUM, self.comm, self._stream()))
 
+    def allreduce_sum_into(self, src, dst):
+        if self.size == 1:
+            self.engine.copy(src, dst)
+            return
+        self._check(self.lib.ncclAllReduce(src.data_ptr(), dst.data_ptr(), src.shape[0], NCCL_FLOAT64, NCCL_SUM,
+                                           self.comm, self._stream()))
+
     def exchange(self, plan, sendbuf, ext):
         if self.size == 1:
             return

@@ -16,6 +16,14 @@ from staggered_grid import mac_stokes
 pytestmark = pytest.mark.gpu
 
 
+# True residual |b - K x| / |b| the full-size solves must reach.  The stopping rules bound the
+# *preconditioned* residual functional (MINRES: sqrt<C r, r> <= 1e-7 of its start, minres.py:126;
+# BPCG: sqrt|<w, d>| <= 1e-8 of its start, bramblepasciak_new.py:246); in the Euclidean norm that is
+# what the solves reach on these systems (measured on MI355X, below), with a factor 3-10 of slack.
+CFG2_TRUE_RESIDUAL = 1e-6      # measured 8.6e-8 (10 610 iterations)
+CFG3_TRUE_RESIDUAL = 1e-5      # measured 3.6e-6 (10 341 iterations)
+
+
 class Form:
     def __init__(self, mat):
         self.mat, self.condense = mat, False
@@ -78,7 +86,9 @@ def test_cfg2_minres_1e5_dof(hip_engine):
     assert np.all(np.diff(errors) <= 1e-12)                       # MINRES residual estimates are monotone
     x = u.numpy()
     b = np.concatenate([f, g])
-    assert np.linalg.norm(b - s.saddle_matrix() @ x) <= 1e-4 * np.linalg.norm(b)
+    res = np.linalg.norm(b - s.saddle_matrix() @ x) / np.linalg.norm(b)
+    print("cfg2: %d iterations, true residual %.2e |b|" % (len(errors) - 1, res))
+    assert res <= CFG2_TRUE_RESIDUAL
 
 
 def test_cfg3_bpcg_1e6_dof(hip_engine):
@@ -98,8 +108,9 @@ def test_cfg3_bpcg_1e6_dof(hip_engine):
     assert "Warning" not in out.getvalue() and it > 100
     x = sol.numpy()
     b = np.concatenate([f, g])
-    assert np.linalg.norm(b - s.saddle_matrix() @ x) <= 1e-4 * np.linalg.norm(b)
-    print("cfg3: %d iterations, %.3f s, %.0f it/s" % (it, seconds, it / seconds))
+    res = np.linalg.norm(b - s.saddle_matrix() @ x) / np.linalg.norm(b)
+    print("cfg3: %d iterations, %.3f s, %.0f it/s, true residual %.2e |b|" % (it, seconds, it / seconds, res))
+    assert res <= CFG3_TRUE_RESIDUAL
 
 
 def test_cfg4_bpcg_1e7_dof_window_against_oracle(hip_engine):
@@ -132,20 +143,48 @@ def test_cfg4_bpcg_1e7_dof_window_against_oracle(hip_engine):
 
 @pytest.mark.skipif(os.environ.get("NSS_SKIP_HUGE") == "1", reason="NSS_SKIP_HUGE=1")
 def test_cfg5_5e7_dof_operators_and_iterations(hip_engine):
-    """BASELINE config 5: 3-D, n=232, N=49 787 200 (11.5 GB on the device).  Operator properties
-    and 20 finite, decreasing-on-average iterations of the fused loop for Re = 100, 400, 1000
-    (the viscosity only rescales A)."""
+    """BASELINE config 5: 3-D, n=232, N=49 787 200 (11.5 GB on the device), Re = 100, 400, 1000 with
+    the headline block-Jacobi (bs=3) preconditioner.  Operator properties at full size, then for
+    every Reynolds number err0 and the first iterations of the fused loop against the CPU oracle on
+    the identical matrices (the viscosity only rescales A: templates/NavierStokesSIMPLE_iterative.py
+    :66,72; sweep: templates/run_navier_stokes_parameter_sweep.py:44-70)."""
+    import time
     import hipla
+    from oracle import krylov_ref as kr
     from solvers.bramblepasciak_new import BpcgSession
-    s = mac_stokes(3, 232, 0.01)
+    nu0 = 0.01
+    s = mac_stokes(3, 232, nu0)
     assert (s.n_u, s.n_p) == (37300032, 12487168)
-    A, B, preA, preS = upload(s, pre="jacobi")
-    operator_properties(s, A, B, preA)
+    blocks = s.line_blocks(3)
     f, g = s.rhs(0)
+    B = hipla.SparseMatrix.from_scipy(s.B)
+    preS = hipla.DiagonalMatrix(1.0 / s.mass)
     fv, gv = hipla.Vector.from_numpy(f), hipla.Vector.from_numpy(g)
-    sol = hipla.BlockVector([hipla.Vector(s.n_u), hipla.Vector(s.n_p)])
-    with contextlib.redirect_stdout(io.StringIO()):
-        ses = BpcgSession(Form(A), Form(B), None, fv, gv, preA, preS, sol=sol)
-    ses.first_direction()
-    it, hist, conv = ses.fused.run(ses.wdn, ses.err0, 0.0, True, 20)
-    assert np.all(np.isfinite(hist)) and hist[-1] < hist[0]
+    pa0 = kr.block_jacobi(s.A, blocks)            # oracle block inverses for nu0; A scales linearly with nu
+    ps = kr.diag_inverse(s.mass)
+    nit = 5
+    for reynolds in (100, 400, 1000):
+        c = (1.0 / reynolds) / nu0
+        A_host = s.A if c == 1.0 else (s.A * c).tocsr()
+        A = hipla.SparseMatrix.from_scipy(A_host)
+        preA = hipla.BlockJacobi(A, blocks)
+        if reynolds == 100:
+            operator_properties(s, A, B, preA)
+        sol = hipla.BlockVector([hipla.Vector(s.n_u), hipla.Vector(s.n_p)])
+        with contextlib.redirect_stdout(io.StringIO()):
+            ses = BpcgSession(Form(A), Form(B), None, fv, gv, preA, preS, sol=sol)
+        assert ses.fused is not None
+        ses.first_direction()
+        t0 = time.perf_counter()
+        it, hist, conv = ses.fused.run(ses.wdn, ses.err0, 0.0, True, nit)
+        assert it == nit - 1 and not conv and np.all(np.isfinite(hist))
+        it_c, u_c, p_c, hist_c, err0_c = kr.bpcg_v2(A_host, s.B, lambda x: pa0(x) / c, ps, f, g, ses.k, tol=0.0,
+                                                   maxsteps=nit)
+        assert abs(ses.err0 - err0_c) <= 1e-10 * err0_c, (reynolds, ses.err0, err0_c)
+        np.testing.assert_allclose(hist, hist_c, rtol=1e-8, err_msg="Re = %d" % reynolds)
+        x = sol.numpy()
+        xc = np.concatenate([u_c, p_c])
+        assert np.linalg.norm(x - xc) <= 1e-9 * np.linalg.norm(xc)
+        print("cfg5 Re=%d: k=%.6g err0=%.6e history rel.diff %.1e (%.0f s)"
+              % (reynolds, ses.k, ses.err0, np.max(np.abs(hist - hist_c) / hist_c), time.perf_counter() - t0))
+        del A, preA, ses, sol, A_host

@@ -86,7 +86,10 @@ def main():
             pre = re.search(r"--pre\s+(\w+)", args)
             workload = "grid=%s dim=%s pre=%s" % (grid.group(1) if grid else "136", dim.group(1) if dim else "3",
                                                   pre.group(1) if pre else "bjac3")
-            json.dump({"tag": tag, "bench_args": args, "workload": workload, "kernels": traffic}, fh, indent=1)
+            sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+            from bench import csrc_digest
+            json.dump({"tag": tag, "bench_args": args, "workload": workload, "csrc_sha256": csrc_digest(),
+                       "kernels": traffic}, fh, indent=1)
     print("\n".join(out))
 
 
