@@ -392,37 +392,38 @@ def main():
     hist = loop.history(total_its - 1)
     valid = (not done) and last == total_its - 1 and bool(np.all(np.isfinite(hist)))
 
-    # ---- roofline of the dominant kernel: fused A-SpMV (K2) ---------------------------------
-    a_info, b_info, bt_info = A.handle.info(), B.handle.info(), A.handle.info()
+    # ---- roofline of the dominant kernel: C23 = rows of A and rows of B in one launch -------------
+    a_info, b_info = A.handle.info(), B.handle.info()
     bt_info = ses.matBT.handle.info()
-    k2_bytes = a_info["algorithmic_bytes"] + 24 * sysm.n_u      # + read t0, s0; write t4 (fused epilogue)
+    dual = (a_info["lanes_per_row"], a_info["index_bytes"]) == (b_info["lanes_per_row"], b_info["index_bytes"])
+    # A part: t2 = A t1 (x = t1 and y = t2 inside algorithmic_bytes) + s0, t0 read for <s0, t2 - t0>;
+    # B part: t3 = B (t1 - s0) (x, y inside algorithmic_bytes; the operand is formed from TWO gathered
+    # vectors: + 8 n_u) + s1, w1 read, s1 written (s1 = beta s1 + w1) for <s1, t3>
+    k2_bytes = (a_info["algorithmic_bytes"] + 16 * sysm.n_u
+                + b_info["algorithmic_bytes"] + 8 * sysm.n_u + 24 * sysm.n_p)
     reps = args.kernel_reps
     # Kernel durations *inside the iteration*: HIP events on the loop's stream around each phase of
     # `probe_its` further iterations.  (A kernel repeated back to back finds its operands in L2 / MALL
-    # from the previous repetition -- K2 then looks 12 % faster than it is in the loop -- so nothing is
-    # timed in isolation; the per-dispatch durations of rocprofv3 --kernel-trace for the same launches
+    # from the previous repetition -- the A SpMV then looks 12 % faster than it is in the loop -- so nothing
+    # is timed in isolation; the per-dispatch durations of rocprofv3 --kernel-trace for the same launches
     # are 2 % below these numbers: an event pair also sees the dispatch of the kernel it brackets.)
-    phase_ms = {"K1": 0.0, "K2": 0.0, "K3": 0.0, "K4": 0.0}
+    names = ("C1", "C23", "SUMA", "C4", "SUMW")
+    phase_ms = dict.fromkeys(names, 0.0)
     marks = []
     for it in range(total_its, total_its + probe_its):
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(len(names) + 1)]
         ev[0].record()
-        loop.phase("K1", it)
-        ev[1].record()
-        loop.phase("K2", it)
-        ev[2].record()
-        loop.phases("K3", "SUM1", it)
-        ev[3].record()
-        loop.phases("ALPHA", "K4", it)
-        ev[4].record()
-        loop.phases("SUM2", "K5", it)
+        for k, name in enumerate(names):
+            loop.cphases(name, name, it)
+            ev[k + 1].record()
         marks.append(ev)
     torch.cuda.synchronize()
     skip = 8                                                 # event creation, clocks
     for ev in marks[skip:]:
-        for k, name in enumerate(("K1", "K2", "K3", "K4")):
+        for k, name in enumerate(names):
             phase_ms[name] += ev[k].elapsed_time(ev[k + 1]) / (len(marks) - skip)
-    k1_ms, k2_ms, k3_ms, k4_ms = (phase_ms[n] for n in ("K1", "K2", "K3", "K4"))
+    k1_ms, k2_ms, k4_ms = phase_ms["C1"], phase_ms["C23"], phase_ms["C4"]
+    sums_ms = phase_ms["SUMA"] + phase_ms["SUMW"]
     xs, ys = eng.zeros(sysm.n_u), eng.zeros(sysm.n_u)
     xs.fill_(1.0)
     spmv_ms = event_time_ms(torch, lambda: eng.csr_spmv(A.handle, 1.0, xs, 0.0, ys), reps)
@@ -448,7 +449,11 @@ def main():
         pre_bytes = preA.handle.algorithmic_bytes() - 16 * n_u if blocks is not None else 8 * n_u
     if args.pre in ("bgs3", "bgs3p"):      # two sweeps, each walks the CSR rows of A once and applies the blocks once
         pre_bytes = 2 * (pre_bytes + 12 * a_info["nnz"] + 4 * n_u + 24 * n_u)
-    vec_bytes = 8 * (25 * n_u + 15 * n_p)
+    # vector passes of one iteration (reads + writes, each n_u resp. n_p doubles):
+    #   C1 6 + 5 (q, z0, t2, s0, w0, u0 | u0, z0, q, s0, t0) and the gathers of s1, w1;  preA 2 (t0 | t1);
+    #   C23 rows of A: gather t1, s0, t0 | t2;  rows of B: gathers of t1, s0;  s1, w1 | s1, t3;
+    #   C4 5 + 2 (t0, t1, t2, d0, w0 | d0, w0) and 6 + 3 (s1, t3, u1, d1, minv, w1 | u1, d1, w1)
+    vec_bytes = 8 * (26 * n_u + 15 * n_p)
     iter_bytes = mat_bytes + pre_bytes + vec_bytes
     iter_gbs = iter_bytes / (elapsed / K) / 1e9
 
@@ -473,8 +478,8 @@ def main():
                   "history_max_rel_diff": float(np.max(np.abs(hist[:m] - hist_c[:m]) / np.abs(hist_c[:m]))),
                   "err0_rel_diff": abs(ses.err0 - err0_c) / err0_c}
 
-    traffic, traffic_note = pmc_traffic("EpiK2", "grid=%d dim=%d pre=%s" % (args.n, args.dim, args.pre))
-    k2_bytes_int32 = k2_bytes + (2 * a_info["nnz"] if a_info["index_bytes"] == 2 else 0)
+    traffic, traffic_note = pmc_traffic("EpiK2c", "grid=%d dim=%d pre=%s" % (args.n, args.dim, args.pre))
+    k2_bytes_int32 = k2_bytes + sum(2 * i["nnz"] for i in (a_info, b_info) if i["index_bytes"] == 2)
     out = {
         "metric": "Krylov iters/sec, 3D SIMPLE Stokes solve (BPCG)", "value": K / elapsed, "unit": "iters/s",
         "n_gpus": 1, "steps": K, "warmup": W, "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True,
@@ -486,14 +491,18 @@ def main():
                    "scale_factor_k": ses.k, "device": info["arch"], "cu_count": info["cu_count"],
                    "column_index_bytes": {"A": a_info["index_bytes"], "B": b_info["index_bytes"],
                                           "BT": bt_info["index_bytes"]}},
-        "roofline": {"bound": "hbm", "kernel": "csr_stream_kernel<1, EpiK2> (A SpMV + fused t4 / <s0,v0>)",
+        "roofline": {"bound": "hbm",
+                     "kernel": ("csr_stream_dual_kernel<EpiK2c, EpiK3c>: t2 = A t1 with <s0, t2 - t0> and "
+                                "t3 = B (t1 - s0) with s1 = beta s1 + w1, <s1, t3> in one launch" if dual else
+                                "csr_stream_kernel<EpiK2c> + csr_stream_kernel<EpiK3c> (launch plans of A and B "
+                                "differ: two launches, timed together)"),
                      "achieved": k2_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k2_gbs / HBM_PEAK_GBS,
                      "traffic": traffic["bytes"] if traffic else None,
                      "traffic_source": traffic["source"] if traffic else None, "traffic_note": traffic_note,
                      "algorithmic_bytes_per_launch": k2_bytes, "avg_launch_ms": k2_ms,
-                     "bytes_accounting": "value stream 8 B + column stream %d B per non-zero (as stored), row "
-                                         "pointers, x and y once, + t0, s0 read and t4 written by the fused epilogue"
-                                         % a_info["index_bytes"],
+                     "bytes_accounting": "A and B: value stream 8 B + column stream %d B per non-zero (as stored), row "
+                                         "pointers, x and y once; + s0, t0 read (A rows); + second gathered "
+                                         "operand, s1, w1 read, s1 written (B rows)" % a_info["index_bytes"],
                      "achieved_if_priced_as_int32_csr": k2_bytes_int32 / (k2_ms * 1e-3) / 1e9,
                      "frac_of_achievable_6290": k2_gbs / HBM_ACHIEVABLE_GBS,
                      "frac_of_stream_triad": k2_gbs / triad_gbs,
@@ -501,9 +510,10 @@ def main():
         "cpu_baseline": cpu,
         "valid": valid,
         "hbm_GBs": {"whole_iteration_algorithmic": iter_gbs, "stream_triad": triad_gbs, "spmv_A_plain": spmv_gbs,
-                    "spmv_A_fused_K2": k2_gbs},
-        "kernel_ms": {"K1_BT": k1_ms, "K2_A": k2_ms, "K3_B": k3_ms, "K4_update": k4_ms, "spmv_A_plain": spmv_ms,
-                      "triad_1.6GB": triad_ms},
+                    "spmv_AB_fused_C23": k2_gbs},
+        "kernel_ms": {"C1_BT_preA": k1_ms, "C23_A_B": k2_ms, "C4_update": k4_ms, "sum_kernels": sums_ms,
+                      "spmv_A_plain": spmv_ms, "triad_1.6GB": triad_ms},
+        "launches_per_iteration": {"sums_folded_into_consumers": loop.folds_sums()},
         "bytes_per_iteration": iter_bytes,
         "parity": parity,
         "setup_s": {"assemble_host": t_asm, "upload_lanczos_initial_residual": t_setup},

@@ -209,7 +209,8 @@ NSS_API int nss_amg_apply_f64(nss_amg_t a, double bscale, const double* b, doubl
  * Vector lengths: n_u for u0,d0,w0,s0,z0,q,t0,t2 ; t1 and t4 are SpMV operands of A and B and
  * have A's / B's column count (n_u plus halo entries in a row-partitioned run); n_p for
  * u1,d1,w1,t3 ; s1 is the operand of B^T (B^T's column count).
- * scal: double[16] = { wd (even it), as_s, wdn, alpha, beta, err0, tol, rel_err(0/1), wd (odd it) };
+ * scal: double[16] = { wd (even it), as_s, wdn, alpha, beta, err0, tol, rel_err(0/1), wd (odd it),
+ *                     local as_s, local wdn (row-partitioned runs) };
  * ctrl: int32[8]  = { done, it_final, last_it, breakdown, pending, -, -, - }; `pending` = it + 1 while
  * the velocity part of `u += alpha s` of iteration it waits for K1 of the next iteration (it reads s0
  * anyway); nss_bpcg2_poll applies and clears it, so read the solution after a poll.
@@ -273,6 +274,16 @@ enum {
   NSS_BPCG2_K5 = 9     /* beta = wdn / wd, s1 = beta s1 + w1, hist[it] = sqrt|wd|, stop test          */
 };
 
+/* The single-GPU loop issues the same arithmetic in three dependent launches (+ the block-Jacobi apply):
+ * the "compact plan" (csrc/bpcg2.hip).  Bit-identical to the eight-phase form above. */
+enum {
+  NSS_BPCG2C_C1 = 1,   /* books of iteration it-1 (K5) in every workgroup, then K1 with beta*s1 + w1 on the fly; preA */
+  NSS_BPCG2C_C23 = 2,  /* rows of A (K2 without t4) and rows of B (K3 on t1 - s0, storing s1) in one launch  */
+  NSS_BPCG2C_SUMA = 3, /* stand-alone sum of the C23 partials -- only when they are too many to fold into C4 */
+  NSS_BPCG2C_C4 = 4,   /* K4 (one-shot launch), as_s summed in every workgroup when folded                   */
+  NSS_BPCG2C_SUMW = 5  /* stand-alone sum of the C4 partials -- only when not folded into C1                 */
+};
+
 NSS_API int nss_bpcg2_workspace(const nss_bpcg2_t* s, int64_t* partials_a, int64_t* partials_b,
                                 int64_t* partials_c);
 /* one phase of iteration `it` (row-partitioned runs all-reduce scal[as_s] / scal[wdn] and exchange
@@ -282,8 +293,22 @@ NSS_API int nss_bpcg2_phase(const nss_bpcg2_t* s, int32_t which, int32_t it, nss
  * between two communication points of the row-partitioned loop */
 NSS_API int nss_bpcg2_phases(const nss_bpcg2_t* s, int32_t first, int32_t last, int32_t it,
                              nss_stream_t stream);
-/* enqueue iterations [it_begin, it_end) back to back (single GPU): no host synchronisation */
+/* enqueue iterations [it_begin, it_end) back to back (single GPU, compact plan): no host
+ * synchronisation.  The books of iteration it_end - 1 (history entry, stop test) are done by the next
+ * call's first kernel or by nss_bpcg2_poll, whichever comes first. */
 NSS_API int nss_bpcg2_iterate(const nss_bpcg2_t* s, int32_t it_begin, int32_t it_end, nss_stream_t stream);
+/* the same iterations in the eight-phase form (what the row-partitioned loop issues between its
+ * collectives; kept callable on one GPU for cross-checks and measurements) */
+NSS_API int nss_bpcg2_iterate_classic(const nss_bpcg2_t* s, int32_t it_begin, int32_t it_end,
+                                      nss_stream_t stream);
+/* phases first..last (NSS_BPCG2C_*, inclusive) of iteration `it` of the compact plan */
+NSS_API int nss_bpcg2_cphases(const nss_bpcg2_t* s, int32_t first, int32_t last, int32_t it,
+                              nss_stream_t stream);
+/* 1 if the dot-product sums of this state are folded into the consuming kernels, 0 if the stand-alone
+ * sum kernels run (more than 4096 partials).  nss_bpcg2_fold_mode: process-wide override for tests and
+ * measurements: -1 automatic (default), 0 never fold, 1 always fold. */
+NSS_API int nss_bpcg2_folds_sums(const nss_bpcg2_t* s, int32_t* folds);
+NSS_API int nss_bpcg2_fold_mode(int32_t mode);
 /* wait for the stream and read ctrl: done (0 running, 1 stop test fired, 2 breakdown
  * <s, K s> == 0 where the reference raises ZeroDivisionError, :226), iteration at which it
  * happened, last iteration whose history entry was written */
@@ -359,7 +384,8 @@ NSS_API int nss_cg_poll(const nss_cg_t* s, int32_t* done, int32_t* it_final, int
  * [1] pressure, n_p).  The three-vector rotations of minres.py:131-133 are index arithmetic on
  * the rings: at iteration k (1-based)  v_old = v[(k-1)%3], v = v[k%3], v_new = v[(k+1)%3]
  * (same for w);  z = z[k%2], z_new = z[(k+1)%2].
- * scal: double[20] (see csrc/minres.hip); ctrl: int32[4] = { stop, k_stop, reason, last_k } with
+ * scal: double[64] = two sets of 32 scalars, double-buffered by the parity of k (iteration k = 1
+ * reads the first set; see csrc/minres.hip); ctrl: int32[4] = { stop, k_stop, reason, last_k } with
  * reason 1 = relative break (:126), 2 = absolute guard `ResNorm > tol` failed (:96, warns);
  * hist[k] = ResNorm_k / err0 (:125). */
 typedef struct nss_minres_s {
@@ -386,6 +412,10 @@ NSS_API int nss_minres_workspace(const nss_minres_t* s, int64_t* partials_a, int
 NSS_API int nss_minres_iterate(const nss_minres_t* s, int32_t k_begin, int32_t k_end, nss_stream_t stream);
 NSS_API int nss_minres_poll(const nss_minres_t* s, int32_t* stop, int32_t* k_stop, int32_t* reason,
                             int32_t* last_k, nss_stream_t stream);
+/* process-wide override of where the two dot-product sums of an iteration are evaluated (tests,
+ * measurements): -1 automatic (inside the consuming kernels up to 4096 partials), 0 always by the
+ * stand-alone sum kernel, 1 always inside the consumers.  Same bits either way. */
+NSS_API int nss_minres_fold_mode(int32_t mode);
 
 /* ---- fused Bramble-Pasciak CG, textbook form ------------------------------------------------
  * Replaces the loop body of bramble_pasciak_cg.py:110-143 (6 SpMV per iteration) for

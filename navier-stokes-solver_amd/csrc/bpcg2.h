@@ -16,5 +16,6 @@ void bpcg2_phase(const nss_bpcg2_t& s, int which, int it, hipStream_t st);
 // after their arrival)
 void bpcg2_spmv_phase(const nss_bpcg2_t& s, int which, int it, hipStream_t st, int b0, int b1, bool ghost_tail = true);
 void bpcg2_k1_finish(const nss_bpcg2_t& s, hipStream_t st);
+void bpcg2_cphase(const nss_bpcg2_t& s, int which, int it, hipStream_t st);
 void gather_launch(int64_t n, const int32_t* idx, const double* src, double* dst, hipStream_t st);
 }  // namespace nss

@@ -18,6 +18,22 @@
 //   K5  element-wise:  beta = wdn / wd (:236), s1 = b*s1 + w1 (:240-241, pressure part); one lane:
 //                      hist[it] = sqrt|wd| (:243), stop test (:246)
 //
+// The single-GPU loop (nss_bpcg2_iterate) issues the same arithmetic in THREE dependent launches
+// (+ the block-Jacobi apply) instead of eight -- the "compact plan", what makes the small configurations
+// (1e5 .. 1e6 DoF: bound by kernel boundaries, not bandwidth) twice as fast:
+//
+//   C1  rows of B^T :  K1, preceded in every workgroup by the books of the previous iteration (what K5
+//                      did: wdn = sum of K4's partials, beta, history entry, stop test) and multiplying
+//                      with the operand beta*s1 + w1 formed on the fly (s1 is materialised by C23)
+//   C23 rows of A and of B in ONE launch:  t2 = A t1 with <s0, t2 - t0>;  t3 = B (t1 - s0) with the
+//                      operand formed on the fly (no t4), s1 = beta*s1 + w1 stored, <s1, t3>
+//   C4  element-wise:  K4, preceded in every workgroup by as_s = sum of the partials of C23
+// Every lane performs exactly the floating-point operations of the eight-kernel form and the sums use
+// the same tree (fixed_sum_1024), so both forms -- and the row-partitioned loop, which keeps the
+// eight-kernel form because its sums are all-reduced in between -- give identical bits.  Systems with
+// more than kFoldMax partials per sum keep the two stand-alone sum kernels (C1 and C4 then read the
+// scalar instead of summing).
+//
 // alpha, beta, wd and the `done` flag live in device memory: nothing is copied to the host
 // inside the loop.  Once `done` is set every kernel returns immediately, so the state is
 // frozen exactly at the reference's `break` and the host may poll every m iterations.
@@ -38,7 +54,10 @@ enum { S_WD = 0, S_AS = 1, S_WDN = 2, S_ALPHA = 3, S_BETA = 4, S_ERR0 = 5, S_TOL
 // wd of iteration `it` lives in slot S_WD (it even) or S_WD_ODD (it odd): K5 of iteration it writes
 // the slot of it+1 while its other lanes still read the slot of it.
 __device__ __forceinline__ int wd_slot(int it) { return (it & 1) ? S_WD_ODD : S_WD; }
-enum { C_DONE = 0, C_IT_FINAL = 1, C_LAST_IT = 2, C_BREAKDOWN = 3, C_PENDING = 4 };
+enum { C_DONE = 0, C_IT_FINAL = 1, C_LAST_IT = 2, C_BREAKDOWN = 3, C_PENDING = 4, C_COMPUTED = 5, C_CLOSED = 6 };
+// compact plan: C_COMPUTED = number of iterations whose K4 has run, C_CLOSED = number of iterations whose
+// books (history entry, beta, stop test) are done.  The books of iteration it are done by C1 of iteration
+// it + 1 or, when the host looks first, by nss_bpcg2_poll (idempotent: same inputs, same values).
 // C_PENDING: the velocity part of `u += alpha s` (:228) of iteration it is not done by K4 but by K1 of
 // iteration it + 1, which reads s0 anyway (one pass over n_u less per iteration).  K4 leaves
 // C_PENDING = it + 1; K1(it + 1) applies the update iff it finds its own iteration number there;
@@ -172,51 +191,16 @@ struct EpiK3 {
   }
 };
 
-// local sum of the partials of K2 and K3 (or of K4 when nb == 0) into scal[slot].  One
-// workgroup of 1024 lanes, four independent accumulators per lane: the ~35 k partials of the
-// 1e7-DoF case are latency-, not bandwidth-bound (a 256-lane serial loop took 32 us).
-constexpr int kSumBlock = 1024;
-__global__ __launch_bounds__(kSumBlock) void bpcg2_sum_kernel(const int32_t* __restrict__ ctrl, int na,
+// local sum of the partials of K2 and K3 (or of K4 when nb == 0) into scal[slot]: one workgroup,
+// fixed_sum_1024 (nss_common.h) -- the tree the compact plan evaluates inside its kernels.
+__global__ __launch_bounds__(kSumLanes) void bpcg2_sum_kernel(const int32_t* __restrict__ ctrl, int na,
                                                                const double* __restrict__ pa, int nb,
                                                                const double* __restrict__ pb,
                                                                double* __restrict__ scal, int slot) {
-  __shared__ double lds[2 * kSumBlock / kWave];
+  __shared__ double lds[kRedDoubles];
   if (ctrl[C_DONE] != 0) return;
-  const int tid = threadIdx.x;
-  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-  int i = tid;
-  for (; i + 3 * kSumBlock < na; i += 4 * kSumBlock) {
-    a0 += pa[i];
-    a1 += pa[i + kSumBlock];
-    a2 += pa[i + 2 * kSumBlock];
-    a3 += pa[i + 3 * kSumBlock];
-  }
-  for (; i < na; i += kSumBlock) a0 += pa[i];
-  double b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
-  i = tid;
-  for (; i + 3 * kSumBlock < nb; i += 4 * kSumBlock) {
-    b0 += pb[i];
-    b1 += pb[i + kSumBlock];
-    b2 += pb[i + 2 * kSumBlock];
-    b3 += pb[i + 3 * kSumBlock];
-  }
-  for (; i < nb; i += kSumBlock) b0 += pb[i];
-  const double sa = wave_sum((a0 + a1) + (a2 + a3));
-  const double sb = wave_sum((b0 + b1) + (b2 + b3));
-  const int lane = tid & (kWave - 1), wave = tid >> 6;
-  if (lane == 0) {
-    lds[wave] = sa;
-    lds[kSumBlock / kWave + wave] = sb;
-  }
-  __syncthreads();
-  if (tid == 0) {
-    double ta = 0.0, tb = 0.0;
-    for (int w = 0; w < kSumBlock / kWave; ++w) {
-      ta += lds[w];
-      tb += lds[kSumBlock / kWave + w];
-    }
-    scal[slot] = ta + tb;
-  }
+  const double t = fixed_sum_1024<kSumLanes>(pa, na, pb, nb, lds);
+  if (threadIdx.x == 0) scal[slot] = t;
 }
 
 struct K4Args {
@@ -233,15 +217,24 @@ struct K4Args {
   const double* ghost_t3;
   const double* ghost_minv;
   double* ghost_w1;
+  int32_t gu, gp;                 // workgroups of the velocity / pressure part (one partial each)
+  int32_t fold, na, nb;           // fold != 0: as_s = fixed sum of pa[0..na) and pb[0..nb) in every workgroup
+  const double *pa, *pb;
 };
 
+// K4 is a one-shot launch: one double2 per lane, no grid-stride loop -- the form that reaches the highest
+// HBM rate for an element-wise kernel on this chip (profiles/r02_triad_variants.txt: 6.2 TB/s against
+// 5.5 TB/s for <= 2048 striding workgroups).
+constexpr int kK4PerBlock = 2 * kBlock;
+
+template <bool VEC2>
 __global__ __launch_bounds__(kBlock) void bpcg2_k4_kernel(K4Args a) {
-  __shared__ double lds[kBlock / kWave];
+  __shared__ double lds[kRedDoubles];
   if (a.ctrl[C_DONE] != 0) return;
   // alpha = wd / <s, K^ s> (:226), evaluated by every lane from the (all-)reduced sum.
   // <s, K^ s> == 0: the reference raises ZeroDivisionError in Python; freeze the state and report
   // it (ctrl[3]) so that the host can raise the same error.
-  const double as_s = a.scal[S_AS];
+  const double as_s = a.fold ? fixed_sum_1024(a.pa, a.na, a.pb, a.nb, lds) : a.scal[S_AS];
   if (as_s == 0.0) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
       a.ctrl[C_BREAKDOWN] = 1;
@@ -255,32 +248,75 @@ __global__ __launch_bounds__(kBlock) void bpcg2_k4_kernel(K4Args a) {
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     a.scal[S_ALPHA] = alpha;          // K1 of the next iteration
     a.ctrl[C_PENDING] = a.it + 1;     // ... which also applies u0 += alpha s0
+    a.ctrl[C_COMPUTED] = a.it + 1;
+    if (a.fold) a.scal[S_AS] = as_s;  // for the host's eyes only
   }
-  const int stride = gridDim.x * kBlock;
+  const int wg = blockIdx.x;
   double acc = 0.0;
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < a.n_u; i += stride) {
-    const double t0v = a.t0[i], t1v = a.t1[i], t2v = a.t2[i];
-    const double dn = fma(-alpha, t2v - t0v, a.d0[i]);
-    const double wn = fma(-alpha, t1v, a.w0[i]);
-    NSS_ST(a.d0[i], dn);
-    NSS_ST(a.w0[i], wn);
-    acc = fma(wn, dn, acc);
+  if (wg < a.gu) {
+    const int i0 = (wg * kBlock + int(threadIdx.x)) * 2;
+    if (VEC2 && i0 + 1 < a.n_u) {
+      const double2 t0v = *reinterpret_cast<const double2*>(a.t0 + i0), t1v = *reinterpret_cast<const double2*>(a.t1 + i0);
+      const double2 t2v = *reinterpret_cast<const double2*>(a.t2 + i0);
+      const double2 d = *reinterpret_cast<const double2*>(a.d0 + i0), w = *reinterpret_cast<const double2*>(a.w0 + i0);
+      double2 dn, wn;
+      dn.x = fma(-alpha, t2v.x - t0v.x, d.x);
+      dn.y = fma(-alpha, t2v.y - t0v.y, d.y);
+      wn.x = fma(-alpha, t1v.x, w.x);
+      wn.y = fma(-alpha, t1v.y, w.y);
+      store2_nt(a.d0 + i0, dn);
+      store2_nt(a.w0 + i0, wn);
+      acc = fma(wn.x, dn.x, acc);
+      acc = fma(wn.y, dn.y, acc);
+    } else {
+      for (int i = i0; i < i0 + 2 && i < a.n_u; ++i) {
+        const double dn = fma(-alpha, a.t2[i] - a.t0[i], a.d0[i]);
+        const double wn = fma(-alpha, a.t1[i], a.w0[i]);
+        NSS_ST(a.d0[i], dn);
+        NSS_ST(a.w0[i], wn);
+        acc = fma(wn, dn, acc);
+      }
+    }
+  } else if (wg < a.gu + a.gp) {
+    const int i0 = ((wg - a.gu) * kBlock + int(threadIdx.x)) * 2;
+    if (VEC2 && i0 + 1 < a.n_p) {
+      const double2 sv = *reinterpret_cast<const double2*>(a.s1 + i0), t3v = *reinterpret_cast<const double2*>(a.t3 + i0);
+      const double2 mv = *reinterpret_cast<const double2*>(a.minv + i0);
+      double2 u = *reinterpret_cast<const double2*>(a.u1 + i0);
+      const double2 d = *reinterpret_cast<const double2*>(a.d1 + i0), w = *reinterpret_cast<const double2*>(a.w1 + i0);
+      u.x = fma(alpha, sv.x, u.x);
+      u.y = fma(alpha, sv.y, u.y);
+      double2 dn, wn;
+      dn.x = fma(-alpha, t3v.x, d.x);
+      dn.y = fma(-alpha, t3v.y, d.y);
+      wn.x = fma(-alpha, mv.x * t3v.x, w.x);
+      wn.y = fma(-alpha, mv.y * t3v.y, w.y);
+      *reinterpret_cast<double2*>(a.u1 + i0) = u;
+      *reinterpret_cast<double2*>(a.d1 + i0) = dn;
+      *reinterpret_cast<double2*>(a.w1 + i0) = wn;
+      acc = fma(wn.x, dn.x, acc);
+      acc = fma(wn.y, dn.y, acc);
+    } else {
+      for (int i = i0; i < i0 + 2 && i < a.n_p; ++i) {
+        const double sv = a.s1[i], t3v = a.t3[i];
+        a.u1[i] = fma(alpha, sv, a.u1[i]);
+        const double dn = fma(-alpha, t3v, a.d1[i]);
+        const double wn = fma(-alpha, a.minv[i] * t3v, a.w1[i]);
+        a.d1[i] = dn;
+        a.w1[i] = wn;
+        acc = fma(wn, dn, acc);
+      }
+    }
+  } else {                                       // row-partitioned runs: ghost copies, same recurrences
+    const int first = wg - a.gu - a.gp, stride = (int(gridDim.x) - a.gu - a.gp) * kBlock;
+    for (int i = first * kBlock + int(threadIdx.x); i < a.ghost_n; i += stride)
+      a.ghost_w0[i] = fma(-alpha, a.t1[a.ghost_map[i]], a.ghost_w0[i]);
+    for (int i = first * kBlock + int(threadIdx.x); i < a.ghost_p_n; i += stride)
+      a.ghost_w1[i] = fma(-alpha, a.ghost_minv[i] * a.ghost_t3[i], a.ghost_w1[i]);
+    return;
   }
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < a.n_p; i += stride) {
-    const double sv = a.s1[i], t3v = a.t3[i];
-    a.u1[i] = fma(alpha, sv, a.u1[i]);
-    const double dn = fma(-alpha, t3v, a.d1[i]);
-    const double wn = fma(-alpha, a.minv[i] * t3v, a.w1[i]);
-    a.d1[i] = dn;
-    a.w1[i] = wn;
-    acc = fma(wn, dn, acc);
-  }
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < a.ghost_n; i += stride)   // ghost copies: same recurrence
-    a.ghost_w0[i] = fma(-alpha, a.t1[a.ghost_map[i]], a.ghost_w0[i]);
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < a.ghost_p_n; i += stride)
-    a.ghost_w1[i] = fma(-alpha, a.ghost_minv[i] * a.ghost_t3[i], a.ghost_w1[i]);
   const double s = block_sum(acc, lds);
-  if (threadIdx.x == 0) a.partials[blockIdx.x] = s;
+  if (threadIdx.x == 0) a.partials[wg] = s;
 }
 
 // K5: beta = wdn / wd (:236) by every lane; lane 0 of workgroup 0 also keeps the books: history
@@ -302,6 +338,7 @@ __global__ __launch_bounds__(kBlock) void bpcg2_k5_kernel(int32_t* __restrict__ 
     const double err = sqrt(fabs(wd));
     hist[it] = err;
     ctrl[C_LAST_IT] = it;
+    ctrl[C_CLOSED] = it + 1;
     const double bound = scal[S_TOL] * (scal[S_REL] != 0.0 ? scal[S_ERR0] : 1.0);
     if (err < bound) {
       ctrl[C_IT_FINAL] = it;
@@ -327,7 +364,203 @@ __global__ __launch_bounds__(kBlock) void bpcg2_flush_kernel(const int32_t* __re
 
 __global__ void bpcg2_flush_done_kernel(int32_t* __restrict__ ctrl) { ctrl[C_PENDING] = 0; }
 
-static int k4_grid(const nss_bpcg2_t& s) { return stream_grid(int64_t(s.n_u) + s.n_p, kBlock * 4); }
+// =====================================================================================================
+// compact plan (single GPU): C1, C23, C4 -- see the file header
+// =====================================================================================================
+struct CloseArgs {
+  int32_t* ctrl;
+  double* scal;
+  double* hist;
+  const double* partials_c;
+  int32_t nc;
+  int32_t fold;
+};
+
+// The books of iteration it - 1, evaluated by every workgroup of C1(it) from the same inputs (what K5
+// did with one lane): wdn, beta = wdn / wd (:236), history entry (:243), stop test (:246), wd of the next
+// iteration.  Workgroup 0 records them.  Returns false when the loop stops at iteration it - 1.
+__device__ __forceinline__ bool close_iteration(const CloseArgs& a, int it, double* lds, double* beta_out) {
+  const int prev = it - 1;
+  const double wdn = a.fold ? fixed_sum_1024(a.partials_c, a.nc, a.partials_c, 0, lds) : a.scal[S_WDN];
+  const double wd = a.scal[wd_slot(prev)];
+  const double beta = wdn / wd;
+  const double err = sqrt(fabs(wd));
+  const double bound = a.scal[S_TOL] * (a.scal[S_REL] != 0.0 ? a.scal[S_ERR0] : 1.0);
+  const bool stop = err < bound;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    a.scal[S_BETA] = beta;
+    a.scal[wd_slot(it)] = wdn;
+    if (a.fold) a.scal[S_WDN] = wdn;
+    a.hist[prev] = err;
+    a.ctrl[C_LAST_IT] = prev;
+    a.ctrl[C_CLOSED] = it;
+    if (stop) {
+      a.ctrl[C_IT_FINAL] = prev;
+      a.ctrl[C_DONE] = 1;
+    }
+  }
+  *beta_out = beta;
+  return !stop;
+}
+
+// the host looks (nss_bpcg2_poll): close the last computed iteration if C1 of its successor has not
+__global__ __launch_bounds__(kBlock) void bpcg2_close_kernel(CloseArgs a) {
+  __shared__ double lds[kRedDoubles];
+  if (a.ctrl[C_DONE] != 0) return;
+  const int computed = a.ctrl[C_COMPUTED];
+  if (a.ctrl[C_CLOSED] >= computed) return;
+  double beta;
+  close_iteration(a, computed, lds, &beta);
+}
+
+// C1: K1 with the books of the previous iteration in front and the operand beta * s1 + w1 on the fly
+struct EpiK1c {
+  CloseArgs cl;
+  double* __restrict__ u0;
+  double* __restrict__ q;
+  double* __restrict__ z0;
+  const double* __restrict__ t2;
+  double* __restrict__ s0;
+  const double* __restrict__ w0;
+  double* __restrict__ t0;
+  double* __restrict__ t1;
+  const double* __restrict__ dinv;  // nullptr when preA is not a plain point Jacobi
+  double k;
+  int it;
+  const double* __restrict__ s1;
+  const double* __restrict__ w1;
+  double alpha = 0.0, beta = 0.0;
+  bool pending = false;
+  __device__ bool skip() const { return cl.ctrl[C_DONE] != 0; }
+  __device__ bool prologue(double* lds) {
+    if (it == 0) return true;
+    alpha = cl.scal[S_ALPHA];
+    pending = cl.ctrl[C_PENDING] == it;
+    return close_iteration(cl, it, lds, &beta);
+  }
+  struct X {
+    const double* __restrict__ s1;
+    const double* __restrict__ w1;
+    double beta;
+    bool first;
+    __device__ double operator()(int c) const { return first ? s1[c] : fma(beta, s1[c], w1[c]); }   // :240-241
+  };
+  __device__ X xop(const double*) const { return X{s1, w1, beta, it == 0}; }
+  __device__ void row(int r, double bts) const {
+    double qv = q[r];
+    if (it != 0) {
+      const double zo = z0[r], t2v = t2[r], so = s0[r];
+      if (pending) NSS_ST(u0[r], fma(alpha, so, u0[r]));   // deferred u += alpha s of iteration it - 1
+      qv = fma(-alpha, t2v, fma(beta, qv, zo));
+      NSS_ST(z0[r], fma(-alpha, t2v, zo));
+      NSS_ST(q[r], qv);
+      NSS_ST3(s0[r], fma(beta, so, w0[r]));
+    }
+    const double t = qv + bts;
+    NSS_ST3(t0[r], t);
+    if (dinv) t1[r] = k * (dinv[r] * t);
+  }
+  __device__ void finish(int, double*) const {}
+};
+
+// C23, rows of A: K2 without t4
+struct EpiK2c {
+  const int32_t* __restrict__ ctrl;
+  const double* __restrict__ t0;
+  const double* __restrict__ s0;
+  double* __restrict__ t2;
+  double* __restrict__ partials;
+  double acc = 0.0;
+  __device__ bool skip() const { return ctrl[C_DONE] != 0; }
+  struct Pre { double s0 = 0.0, t0 = 0.0; };
+  __device__ Pre fetch(int r) const { return Pre{s0[r], t0[r]}; }
+  __device__ void row(int r, double at1, const Pre& p) {
+    NSS_ST(t2[r], at1);
+    acc = fma(p.s0, at1 - p.t0, acc);
+  }
+  __device__ void finish(int b, double* lds) {
+    const double s = block_sum(acc, lds);
+    if (threadIdx.x == 0 && b >= 0) partials[b] = s;
+  }
+};
+
+// C23, rows of B: K3 multiplying with t4 = t1 - s0 formed on the fly (:212-213) and storing
+// s1 = beta * s1 + w1 (:240-241, pressure part -- K5's job)
+struct EpiK3c {
+  const int32_t* __restrict__ ctrl;
+  const double* __restrict__ scal;
+  const double* __restrict__ t1;
+  const double* __restrict__ s0;
+  double* __restrict__ s1;
+  const double* __restrict__ w1;
+  double* __restrict__ t3;
+  double* __restrict__ partials;
+  int it;
+  double acc = 0.0;
+  double beta = 0.0;
+  __device__ bool skip() const { return ctrl[C_DONE] != 0; }
+  __device__ bool prologue(double*) {
+    if (it != 0) beta = scal[S_BETA];
+    return true;
+  }
+  struct X {
+    const double* __restrict__ t1;
+    const double* __restrict__ s0;
+    __device__ double operator()(int c) const { return t1[c] - s0[c]; }
+  };
+  __device__ X xop(const double*) const { return X{t1, s0}; }
+  struct Pre { double s1 = 0.0, w1 = 0.0; };
+  __device__ Pre fetch(int r) const { return Pre{s1[r], it != 0 ? w1[r] : 0.0}; }
+  __device__ void row(int r, double bt4, const Pre& p) {
+    double sv = p.s1;
+    if (it != 0) {
+      sv = fma(beta, p.s1, p.w1);
+      s1[r] = sv;
+    }
+    NSS_ST2(t3[r], bt4);
+    acc = fma(sv, bt4, acc);
+  }
+  __device__ void finish(int b, double* lds) {
+    const double s = block_sum(acc, lds);
+    if (threadIdx.x == 0 && b >= 0) partials[b] = s;
+  }
+};
+
+static int k4_gu(const nss_bpcg2_t& s) { return (s.n_u + kK4PerBlock - 1) / kK4PerBlock; }
+static int k4_gp(const nss_bpcg2_t& s) { return (s.n_p + kK4PerBlock - 1) / kK4PerBlock; }
+static int k4_partials(const nss_bpcg2_t& s) { return k4_gu(s) + k4_gp(s); }
+static int k4_ghost_blocks(const nss_bpcg2_t& s) {
+  const int64_t g = std::max<int64_t>(s.ghost_mode ? s.ghost_n : 0, s.ghost_p_mode ? s.ghost_p_n : 0);
+  return g > 0 ? stream_grid(g, kBlock) : 0;
+}
+
+// Sums with at most this many terms are evaluated inside the consuming kernel by every workgroup
+// (compact plan); longer ones by the stand-alone sum kernel.  nss_bpcg2_fold_mode() overrides (tests,
+// measurements): -1 automatic, 0 never, 1 always.
+constexpr int kFoldMax = 4096;
+static int g_fold_mode = -1;
+static bool fold_sums(const nss_bpcg2_t& s) {
+  const int forced = g_fold_mode;
+  if (s.local_sums) return false;        // row-partitioned: the sums are all-reduced between the kernels
+  if (forced >= 0) return forced != 0;
+  return s.A->nblk + s.B->nblk <= kFoldMax && k4_partials(s) <= kFoldMax;
+}
+
+static void launch_k4(const nss_bpcg2_t& s, int it, bool fold, hipStream_t st) {
+  K4Args a{s.ctrl, s.scal, s.n_u, s.n_p, it, s.u0, s.d0, s.w0, s.u1, s.d1, s.w1,
+           s.s0, s.t0, s.t1, s.t2, s.s1, s.t3, s.minv, s.partials_c, s.ghost_mode ? s.ghost_n : 0, s.ghost_map,
+           s.ghost_w0, s.ghost_p_mode ? s.ghost_p_n : 0, s.ghost_t3, s.ghost_minv, s.ghost_w1,
+           k4_gu(s), k4_gp(s), fold ? 1 : 0, s.A->nblk, s.B->nblk, s.partials_a, s.partials_b};
+  const int grid = a.gu + a.gp + k4_ghost_blocks(s);
+  bool vec = true;
+  for (const void* p : {(const void*)s.u1, (const void*)s.d0, (const void*)s.d1, (const void*)s.w0, (const void*)s.w1,
+                        (const void*)s.s1, (const void*)s.t0, (const void*)s.t1, (const void*)s.t2, (const void*)s.t3,
+                        (const void*)s.minv})
+    vec = vec && aligned16(p);
+  if (vec) hipLaunchKernelGGL(bpcg2_k4_kernel<true>, dim3(grid), dim3(kBlock), 0, st, a);
+  else hipLaunchKernelGGL(bpcg2_k4_kernel<false>, dim3(grid), dim3(kBlock), 0, st, a);
+  NSS_CHECK_LAUNCH();
+}
 
 void bpcg2_check_state(const nss_bpcg2_t* s) {
   NSS_REQUIRE(s != nullptr, "bpcg2: NULL state");
@@ -420,24 +653,19 @@ void bpcg2_phase(const nss_bpcg2_t& s, int which, int it, hipStream_t st) {
       bpcg2_spmv_phase(s, which, it, st, 0, -1);
       break;
     case NSS_BPCG2_SUM1:
-      hipLaunchKernelGGL(bpcg2_sum_kernel, dim3(1), dim3(kSumBlock), 0, st, s.ctrl, s.A->nblk, s.partials_a, s.B->nblk,
+      hipLaunchKernelGGL(bpcg2_sum_kernel, dim3(1), dim3(kSumLanes), 0, st, s.ctrl, s.A->nblk, s.partials_a, s.B->nblk,
                          s.partials_b, s.scal, int(s.local_sums ? S_AS_LOCAL : S_AS));
       NSS_CHECK_LAUNCH();
       break;
     case NSS_BPCG2_ALPHA:   // folded into K4 (kept as a phase id for callers that list all phases)
       break;
-    case NSS_BPCG2_K4: {
-      K4Args a{s.ctrl, s.scal, s.n_u, s.n_p, it, s.u0, s.d0, s.w0, s.u1, s.d1, s.w1,
-               s.s0, s.t0, s.t1, s.t2, s.s1, s.t3, s.minv, s.partials_c, s.ghost_mode ? s.ghost_n : 0, s.ghost_map,
-               s.ghost_w0, s.ghost_p_mode ? s.ghost_p_n : 0, s.ghost_t3, s.ghost_minv, s.ghost_w1};
+    case NSS_BPCG2_K4:
       if (s.ghost_p_mode && s.ghost_p_n > 0)     // t3 on the ghost pressure rows (t4 and its ghosts are complete)
         launch_csr_stream(*s.ghost_b, s.t4, EpiGuardedStore{s.ctrl, s.ghost_t3}, st);
-      hipLaunchKernelGGL(bpcg2_k4_kernel, dim3(k4_grid(s)), dim3(kBlock), 0, st, a);
-      NSS_CHECK_LAUNCH();
+      launch_k4(s, it, false, st);
       break;
-    }
     case NSS_BPCG2_SUM2:
-      hipLaunchKernelGGL(bpcg2_sum_kernel, dim3(1), dim3(kSumBlock), 0, st, s.ctrl, k4_grid(s), s.partials_c, 0,
+      hipLaunchKernelGGL(bpcg2_sum_kernel, dim3(1), dim3(kSumLanes), 0, st, s.ctrl, k4_partials(s), s.partials_c, 0,
                          s.partials_c, s.scal, int(s.local_sums ? S_WDN_LOCAL : S_WDN));
       NSS_CHECK_LAUNCH();
       break;
@@ -454,6 +682,44 @@ void bpcg2_phase(const nss_bpcg2_t& s, int which, int it, hipStream_t st) {
   }
 }
 
+// ---- phases of the compact plan ---------------------------------------------------------------------
+static CloseArgs close_args(const nss_bpcg2_t& s, bool fold) {
+  return CloseArgs{s.ctrl, s.scal, s.hist, s.partials_c, k4_partials(s), fold ? 1 : 0};
+}
+
+void bpcg2_cphase(const nss_bpcg2_t& s, int which, int it, hipStream_t st) {
+  const bool fold = fold_sums(s);
+  switch (which) {
+    case NSS_BPCG2C_C1: {
+      EpiK1c e{close_args(s, fold), s.u0, s.q, s.z0, s.t2, s.s0, s.w0, s.t0, s.t1,
+               (s.pre_amg || s.cond_HT) ? nullptr : s.pre_diag, s.k, it, s.s1, s.w1};
+      launch_csr_stream(*s.BT, s.s1, e, st);
+      bpcg2_k1_finish(s, st);
+      break;
+    }
+    case NSS_BPCG2C_C23: {
+      EpiK2c ea{s.ctrl, s.t0, s.s0, s.t2, s.partials_a};
+      EpiK3c eb{s.ctrl, s.scal, s.t1, s.s0, s.s1, s.w1, s.t3, s.partials_b, it};
+      if (!launch_csr_stream_dual(*s.A, s.t1, ea, *s.B, s.t1, eb, st)) {   // launch plans differ: two launches
+        launch_csr_stream(*s.A, s.t1, ea, st);
+        launch_csr_stream(*s.B, s.t1, eb, st);
+      }
+      break;
+    }
+    case NSS_BPCG2C_SUMA:
+      if (!fold) bpcg2_phase(s, NSS_BPCG2_SUM1, it, st);
+      break;
+    case NSS_BPCG2C_C4:
+      launch_k4(s, it, fold, st);
+      break;
+    case NSS_BPCG2C_SUMW:
+      if (!fold) bpcg2_phase(s, NSS_BPCG2_SUM2, it, st);
+      break;
+    default:
+      throw Error("bpcg2: unknown phase of the compact plan");
+  }
+}
+
 }  // namespace nss
 
 using namespace nss;
@@ -465,7 +731,7 @@ int nss_bpcg2_workspace(const nss_bpcg2_t* s, int64_t* partials_a, int64_t* part
     NSS_REQUIRE(s && s->A && s->B, "bpcg2_workspace: NULL state / matrices");
     if (partials_a) *partials_a = s->A->nblk;
     if (partials_b) *partials_b = s->B->nblk;
-    if (partials_c) *partials_c = k4_grid(*s);
+    if (partials_c) *partials_c = k4_partials(*s);
   });
 }
 
@@ -488,14 +754,52 @@ int nss_bpcg2_iterate(const nss_bpcg2_t* s, int32_t it_begin, int32_t it_end, ns
   return guarded([&] {
     bpcg2_check_state(s);
     hipStream_t st = as_stream(stream);
+    NSS_REQUIRE(!s->ghost_mode && !s->ghost_p_mode && !s->local_sums,
+                "bpcg2_iterate: a row-partitioned state takes nss_bpcg2_phase / nss_bpcg2_iterate_dist");
+    for (int it = it_begin; it < it_end; ++it)
+      for (int ph = NSS_BPCG2C_C1; ph <= NSS_BPCG2C_SUMW; ++ph) bpcg2_cphase(*s, ph, it, st);
+  });
+}
+
+int nss_bpcg2_iterate_classic(const nss_bpcg2_t* s, int32_t it_begin, int32_t it_end, nss_stream_t stream) {
+  return guarded([&] {
+    bpcg2_check_state(s);
+    hipStream_t st = as_stream(stream);
     for (int it = it_begin; it < it_end; ++it)
       for (int ph = NSS_BPCG2_K1; ph <= NSS_BPCG2_K5; ++ph) bpcg2_phase(*s, ph, it, st);
+  });
+}
+
+int nss_bpcg2_cphases(const nss_bpcg2_t* s, int32_t first, int32_t last, int32_t it, nss_stream_t stream) {
+  return guarded([&] {
+    bpcg2_check_state(s);
+    NSS_REQUIRE(first >= NSS_BPCG2C_C1 && last <= NSS_BPCG2C_SUMW && first <= last, "bpcg2_cphases: bad phase range");
+    NSS_REQUIRE(!s->ghost_mode && !s->ghost_p_mode && !s->local_sums, "bpcg2_cphases: single-GPU states only");
+    for (int ph = first; ph <= last; ++ph) bpcg2_cphase(*s, ph, it, as_stream(stream));
+  });
+}
+
+int nss_bpcg2_fold_mode(int32_t mode) {
+  return guarded([&] {
+    NSS_REQUIRE(mode >= -1 && mode <= 1, "bpcg2_fold_mode: -1 (automatic), 0 (never) or 1 (always)");
+    g_fold_mode = mode;
+  });
+}
+
+int nss_bpcg2_folds_sums(const nss_bpcg2_t* s, int32_t* folds) {
+  return guarded([&] {
+    NSS_REQUIRE(s && s->A && s->B && folds, "bpcg2_folds_sums: NULL argument");
+    *folds = fold_sums(*s) ? 1 : 0;
   });
 }
 
 int nss_bpcg2_poll(const nss_bpcg2_t* s, int32_t* done, int32_t* it_final, int32_t* last_it, nss_stream_t stream) {
   return guarded([&] {
     NSS_REQUIRE(s && s->ctrl, "bpcg2_poll: NULL state");
+    if (s->hist && s->partials_c && s->scal && s->A && s->B) {   // compact plan: the books of the last computed iteration
+      hipLaunchKernelGGL(bpcg2_close_kernel, dim3(1), dim3(kBlock), 0, as_stream(stream), close_args(*s, fold_sums(*s)));
+      NSS_CHECK_LAUNCH();
+    }
     if (s->u0 && s->s0 && s->scal && s->n_u > 0) {       // complete the solution (see C_PENDING)
       hipLaunchKernelGGL(bpcg2_flush_kernel, dim3(stream_grid(s->n_u, kBlock * 4)), dim3(kBlock), 0, as_stream(stream),
                          s->ctrl, s->scal, s->n_u, s->s0, s->u0);

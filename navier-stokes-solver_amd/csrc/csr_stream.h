@@ -118,6 +118,16 @@ void plan_row_blocks(int32_t m, int64_t nnz, const int32_t* rowptr, int32_t* rg_
 //                                                   // block of this workgroup (-1: padding), the
 //                                                   // slot of its dot partial
 //   __device__ bool skip() const;                   // e.g. solver already converged
+// optional:
+//   __device__ bool prologue(double* lds);          // called by ALL threads of the workgroup before the
+//                                                   // stream (lds: 32 doubles): e.g. sum the dot partials of
+//                                                   // the previous kernel and derive alpha / beta into the
+//                                                   // functor's registers; false -> the workgroup returns
+//   struct X;  __device__ X xop(const double* x) const;   // operand functor: X{}(c) = value of the SpMV
+//                                                   // operand at column c (default: x[c]); lets a kernel
+//                                                   // multiply with a vector that is only defined by a
+//                                                   // recurrence, e.g. beta * s[c] + w[c], without a pass
+//                                                   // that materialises it first
 template <class E, class = void>
 struct EpiPre {
   struct type {};
@@ -131,18 +141,41 @@ struct EpiPre<E, std::void_t<typename E::Pre>> {
   static __device__ void row(E& e, int r, double ax, const type& p) { e.row(r, ax, p); }
 };
 
-template <int RG, class Epi, bool C16 = false, int CH = kChunk>
-__global__ __launch_bounds__(kBlock) void csr_stream_kernel(CsrView a, const double* __restrict__ x, Epi epi) {
-  __shared__ double prod[CH];
-  __shared__ double red[kBlock / kWave];
-  __shared__ int32_t window[kWindows];
-  if (epi.skip()) return;
+struct XPlain {
+  const double* __restrict__ x;
+  __device__ double operator()(int c) const { return x[c]; }
+};
+template <class E, class = void>
+struct EpiX {
+  using type = XPlain;
+  static __device__ type get(const E&, const double* x) { return XPlain{x}; }
+};
+template <class E>
+struct EpiX<E, std::void_t<typename E::X>> {
+  using type = typename E::X;
+  static __device__ type get(const E& e, const double* x) { return e.xop(x); }
+};
+template <class E, class = void>
+struct EpiPrologue {
+  static __device__ bool run(E&, double*) { return true; }
+};
+template <class E>
+struct EpiPrologue<E, std::void_t<decltype(std::declval<E&>().prologue(static_cast<double*>(nullptr)))>> {
+  static __device__ bool run(E& e, double* lds) { return e.prologue(lds); }
+};
+
+constexpr int kRedDoubles = 32;   // per-workgroup reduction scratch (block_sum: 4, fixed_sum_1024: 32)
+
+// One workgroup = one row block: `wg` is the workgroup's index inside this launch's grid part.
+template <int RG, class Epi, bool C16, int CH, class X>
+__device__ __forceinline__ void csr_stream_body(const CsrView& a, const X& xop, Epi& epi, int wg, double* prod,
+                                                double* red, int32_t* window) {
   const int tid = threadIdx.x;
-  // XCD-aware map: workgroups with equal (blockIdx & 7) share an XCD; XCD i owns the i-th
+  // XCD-aware map: workgroups with equal (index & 7) share an XCD; XCD i owns the i-th
   // contiguous eighth of the row blocks.  One row block per workgroup: a striding
   // (persistent) loop around this body measured 9 % slower on the A SpMV (extra barrier, and
   // the hardware dispatcher balances the tail better).
-  const int lb = (blockIdx.x & (kXcds - 1)) * a.per_xcd + (blockIdx.x >> 3);
+  const int lb = (wg & (kXcds - 1)) * a.per_xcd + (wg >> 3);
   const int b = lb < a.nblk ? a.blk0 + lb : -1;
   if (b >= 0) {
     const int r0 = a.rowblk[b];
@@ -160,31 +193,6 @@ __global__ __launch_bounds__(kBlock) void csr_stream_kernel(CsrView a, const dou
 #endif
     if (cnt <= CH) {
       // ---- phase 1: coalesced stream of (col, val), gather x, stage products ---------
-#if NSS_STREAM_VEC2
-      // two consecutive entries per lane from an even-aligned base: 16-byte val / 8-byte col loads
-      constexpr int kPer = CH / (2 * kBlock);
-      const int pa = p0 & ~1;
-      const int lead = p0 - pa;                  // 0 or 1 entries in front of the row block
-      const int span = cnt + lead;
-      typedef int int2v __attribute__((ext_vector_type(2)));
-      typedef double double2v __attribute__((ext_vector_type(2)));
-      int2v c[kPer + 1];
-      double2v v[kPer + 1];
-#pragma unroll
-      for (int k = 0; k <= kPer; ++k) {
-        const int e = 2 * (tid + k * kBlock);     // entry offset from pa
-        const bool live = e < span;
-        c[k] = live ? __builtin_nontemporal_load(reinterpret_cast<const int2v*>(a.col + pa + e)) : int2v{0, 0};
-        v[k] = live ? __builtin_nontemporal_load(reinterpret_cast<const double2v*>(a.val + pa + e)) : double2v{0.0, 0.0};
-      }
-#pragma unroll
-      for (int k = 0; k <= kPer; ++k) {
-        const int e = 2 * (tid + k * kBlock);
-        const int i0 = e - lead, i1 = e + 1 - lead;          // LDS slots of the two entries
-        if (i0 >= 0 && i0 < cnt) prod[i0] = v[k].x * x[c[k].x];
-        if (i1 < cnt && e < span) prod[i1] = v[k].y * x[c[k].y];
-      }
-#else
       constexpr int kPer = CH / kBlock;
       int32_t c[kPer];
       double v[kPer];
@@ -213,11 +221,10 @@ __global__ __launch_bounds__(kBlock) void csr_stream_kernel(CsrView a, const dou
       }
       double xv[kPer];
 #pragma unroll
-      for (int k = 0; k < kPer; ++k) xv[k] = (tid + k * kBlock < cnt) ? x[c[k]] : 0.0;
+      for (int k = 0; k < kPer; ++k) xv[k] = (tid + k * kBlock < cnt) ? xop(c[k]) : 0.0;
 #pragma unroll
       for (int k = 0; k < kPer; ++k)
         if (tid + k * kBlock < cnt) prod[tid + k * kBlock] = v[k] * xv[k];
-#endif
       __syncthreads();
       // ---- phase 2: per-row reduction from LDS -----------------------------------------
       constexpr int kRowsPerPass = kBlock / RG;
@@ -251,12 +258,43 @@ __global__ __launch_bounds__(kBlock) void csr_stream_kernel(CsrView a, const dou
     } else {
       // ---- one row longer than the LDS chunk: the whole workgroup reduces it ----------
       double acc = 0.0;
-      for (int i = tid; i < cnt; i += kBlock) acc = fma(a.val[p0 + i], x[a.col[p0 + i]], acc);
+      for (int i = tid; i < cnt; i += kBlock) acc = fma(a.val[p0 + i], xop(a.col[p0 + i]), acc);
       const double sum = block_sum(acc, red);
       if (tid == 0) EpiPre<Epi>::row(epi, r0, sum, EpiPre<Epi>::fetch(epi, r0));
     }
   }
   epi.finish(b, red);  // one dot partial per row block
+}
+
+template <int RG, class Epi, bool C16 = false, int CH = kChunk>
+__global__ __launch_bounds__(kBlock) void csr_stream_kernel(CsrView a, const double* __restrict__ x, Epi epi) {
+  __shared__ double prod[CH];
+  __shared__ double red[kRedDoubles];
+  __shared__ int32_t window[kWindows];
+  if (epi.skip()) return;
+  if (!EpiPrologue<Epi>::run(epi, red)) return;
+  csr_stream_body<RG, Epi, C16, CH>(a, EpiX<Epi>::get(epi, x), epi, int(blockIdx.x), prod, red, window);
+}
+
+// Two matrices with the same launch-plan parameters in ONE launch: workgroups [0, grid_a) stream the
+// row blocks of `a` with `ea`, the rest those of `b` with `eb` -- two SpMVs that do not depend on each
+// other (the fused BPCG iteration: t2 = A t1 and t3 = B (t1 - s0)) share a kernel boundary.
+template <int RG, class EpiA, class EpiB, bool C16, int CH>
+__global__ __launch_bounds__(kBlock) void csr_stream_dual_kernel(CsrView a, CsrView b, int grid_a,
+                                                                  const double* __restrict__ xa,
+                                                                  const double* __restrict__ xb, EpiA ea, EpiB eb) {
+  __shared__ double prod[CH];
+  __shared__ double red[kRedDoubles];
+  __shared__ int32_t window[kWindows];
+  if (int(blockIdx.x) < grid_a) {
+    if (ea.skip()) return;
+    if (!EpiPrologue<EpiA>::run(ea, red)) return;
+    csr_stream_body<RG, EpiA, C16, CH>(a, EpiX<EpiA>::get(ea, xa), ea, int(blockIdx.x), prod, red, window);
+  } else {
+    if (eb.skip()) return;
+    if (!EpiPrologue<EpiB>::run(eb, red)) return;
+    csr_stream_body<RG, EpiB, C16, CH>(b, EpiX<EpiB>::get(eb, xb), eb, int(blockIdx.x) - grid_a, prod, red, window);
+  }
 }
 
 // rows of the row blocks [b0, b1) (default: all)
@@ -284,6 +322,36 @@ inline void launch_csr_stream(const nss_csr_s& A, const double* x, const Epi& ep
   }
 #undef NSS_LAUNCH_RG
   NSS_CHECK_LAUNCH();
+}
+
+// A and B in one launch when their launch plans agree (lanes per row, chunk, index width); returns
+// false (nothing launched) otherwise -- the caller then issues two launches.
+template <class EpiA, class EpiB>
+inline bool launch_csr_stream_dual(const nss_csr_s& A, const double* xa, const EpiA& ea, const nss_csr_s& B,
+                                   const double* xb, const EpiB& eb, hipStream_t st) {
+  if (A.m == 0 || B.m == 0 || A.nblk == 0 || B.nblk == 0) return false;
+  if (A.rg != B.rg || A.chunk != B.chunk || (A.col16 != nullptr) != (B.col16 != nullptr)) return false;
+  const CsrView va = A.view(0, A.nblk), vb = B.view(0, B.nblk);
+  const int ga = nss_csr_s::grid(A.nblk), gb = nss_csr_s::grid(B.nblk);
+  const dim3 grid(ga + gb), block(kBlock);
+#define NSS_LAUNCH_DUAL(N)                                                                                             \
+  case N:                                                                                                              \
+    if (A.chunk == kChunkLong) {                                                                                       \
+      if (A.col16) hipLaunchKernelGGL((csr_stream_dual_kernel<N, EpiA, EpiB, true, kChunkLong>), grid, block, 0, st, va, vb, ga, xa, xb, ea, eb);  \
+      else hipLaunchKernelGGL((csr_stream_dual_kernel<N, EpiA, EpiB, false, kChunkLong>), grid, block, 0, st, va, vb, ga, xa, xb, ea, eb);         \
+    } else {                                                                                                           \
+      if (A.col16) hipLaunchKernelGGL((csr_stream_dual_kernel<N, EpiA, EpiB, true, kChunk>), grid, block, 0, st, va, vb, ga, xa, xb, ea, eb);      \
+      else hipLaunchKernelGGL((csr_stream_dual_kernel<N, EpiA, EpiB, false, kChunk>), grid, block, 0, st, va, vb, ga, xa, xb, ea, eb);             \
+    }                                                                                                                  \
+    break;
+  switch (A.rg) {
+    NSS_LAUNCH_DUAL(1) NSS_LAUNCH_DUAL(2) NSS_LAUNCH_DUAL(4) NSS_LAUNCH_DUAL(8) NSS_LAUNCH_DUAL(16) NSS_LAUNCH_DUAL(32)
+    NSS_LAUNCH_DUAL(64)
+    default: throw Error("csr_stream: bad lanes-per-row in the launch plan");
+  }
+#undef NSS_LAUNCH_DUAL
+  NSS_CHECK_LAUNCH();
+  return true;
 }
 
 // y = alpha * A x + beta * y

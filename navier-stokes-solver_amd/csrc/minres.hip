@@ -1,19 +1,26 @@
 // Fused, device-resident iteration of preconditioned MINRES (reference loop: minres.py:96-144)
-// for K = [[A, B^T], [B, 0]] and C = diag(preA, preS).
+// for K = [[A, B^T], [B, 0]] and C = diag(preA, preS).  Four dependent launches per iteration
+// (+ one when the preconditioner of the velocity block is not fused, see M3):
 //
-//   MK1  rows of A   : kz0 = A z0                                                      (:97)
-//   MK2  rows of B^T : kz0 += B^T z1, partial <kz0, z0>                                (:97-98)
-//   MK3  rows of B   : kz1 = B z0,    partial <kz1, z1>                                (:97-98)
-//   SUM  delta
-//   MK4  element-wise: v_new = kz - delta v - gamma v_old (:99); z_new = C v_new (:101, Jacobi
-//        preA and preS fused; block-Jacobi preA as its own kernel); partial <z_new, v_new> (:103)
-//   SUM  gamma_new^2
-//   SC   one lane: Givens recurrences (:107-113), ResNorm (:122), hist, both stop rules
-//   MK5  element-wise: z_new, v_new *= 1/gamma_new (:104-105); w_new = (z - a3 w_old - a2 w)/a1
-//        (:115-116); u += c_new eta_old w_new (:118)
+//   M1  rows of B^T and rows of B in ONE launch (neither depends on the other):
+//         kz0 = B^T z1;   kz1 = B z0, partial <kz1, z1>                                 (:97-98)
+//   M2  rows of A   : kz0 += A z0, partial <kz0, z0>                                    (:97-98)
+//   M3  element-wise, delta = sum of the partials first (in every workgroup when the sum is short,
+//        else from the stand-alone sum kernel): v_new = kz - delta v - gamma v_old (:99);
+//        z_new = C v_new (:101) -- point Jacobi and preS fused; block Jacobi over runs of
+//        consecutive dofs fused too (one lane per block); anything else (index-list blocks,
+//        Gauss-Seidel mode, AMG) as its own launches -- partial <z_new, v_new> (:103)
+//   M4  element-wise, gamma_new^2 = sum of the partials first; then EVERY workgroup evaluates the
+//        Givens recurrences (:107-113), ResNorm (:122) and both stop rules from the same scalars
+//        (workgroup 0 records them, history entry and stop flag included) and applies
+//        z_new, v_new *= 1/gamma_new (:104-105); w_new = (z - a3 w_old - a2 w)/a1 (:115-116);
+//        u += c_new eta_old w_new (:118)
 //
-// Stop handling: SC of iteration k records {stop, k_stop}; kernels of iteration k' return at
-// once when stop is set and k' > k_stop, so MK5 of the stopping iteration still applies the
+// The scalars are double-buffered by the parity of k (M4 of iteration k reads one set while its
+// workgroup 0 writes the set of iteration k + 1).
+//
+// Stop handling: M4 of iteration k records {stop, k_stop}; kernels of iteration k' return at
+// once when stop is set and k' > k_stop, so M4 of the stopping iteration still applies the
 // update of u (the reference tests *after* :118) and nothing later touches the state.
 #include "bpcg2.h"
 
@@ -62,87 +69,125 @@ struct EpiMAccDot {  // y (+)= A x ; partial <y, z>
   }
 };
 
-constexpr int kMSum = 1024;
-// scal[slot] = sum(pa[0..na)) + sum(pb[0..nb)) in a fixed order
-__global__ __launch_bounds__(kMSum) void minres_sum_kernel(const int32_t* __restrict__ ctrl, int k, int na,
-                                                            const double* __restrict__ pa, int nb,
-                                                            const double* __restrict__ pb, double* __restrict__ scal,
-                                                            int slot) {
-  __shared__ double lds[2 * kMSum / kWave];
+constexpr int kMScal = 32;          // doubles per scalar set; set of iteration k at scal + ((k - 1) & 1) * kMScal
+__device__ __host__ __forceinline__ int m_set(int k) { return ((k - 1) & 1) * kMScal; }
+
+// scal_in[slot] = sum(pa[0..na)) + sum(pb[0..nb)) in the fixed order (stand-alone form of the fold)
+__global__ __launch_bounds__(kSumLanes) void minres_sum_kernel(const int32_t* __restrict__ ctrl, int k, int na,
+                                                                const double* __restrict__ pa, int nb,
+                                                                const double* __restrict__ pb,
+                                                                double* __restrict__ scal, int slot) {
+  __shared__ double lds[kRedDoubles];
   if (minres_skip(ctrl, k)) return;
-  const int tid = threadIdx.x;
-  double a = 0.0, a2 = 0.0, b = 0.0, b2 = 0.0;
-  int i = tid;
-  for (; i + kMSum < na; i += 2 * kMSum) {
-    a += pa[i];
-    a2 += pa[i + kMSum];
-  }
-  for (; i < na; i += kMSum) a += pa[i];
-  i = tid;
-  for (; i + kMSum < nb; i += 2 * kMSum) {
-    b += pb[i];
-    b2 += pb[i + kMSum];
-  }
-  for (; i < nb; i += kMSum) b += pb[i];
-  const double sa = wave_sum(a + a2), sb = wave_sum(b + b2);
-  const int lane = tid & (kWave - 1), wave = tid >> 6;
-  if (lane == 0) {
-    lds[wave] = sa;
-    lds[kMSum / kWave + wave] = sb;
-  }
-  __syncthreads();
-  if (tid == 0) {
-    double ta = 0.0, tb = 0.0;
-    for (int w = 0; w < kMSum / kWave; ++w) {
-      ta += lds[w];
-      tb += lds[kMSum / kWave + w];
-    }
-    scal[slot] = ta + tb;
-  }
+  const double t = fixed_sum_1024<kSumLanes>(pa, na, pb, nb, lds);
+  if (threadIdx.x == 0) scal[slot] = t;
 }
 
 struct MK4Args {
   const int32_t* ctrl;
-  const double* scal;
+  double* scal;                // set of iteration k
   int32_t n_u, n_p, k;
   const double *kz0, *kz1, *v0, *v1, *vo0, *vo1;
   double *vn0, *vn1, *zn0, *zn1;
-  const double *dinv, *minv;  // dinv == nullptr: block-Jacobi handles zn0 afterwards
+  const double *dinv, *minv;   // dinv == nullptr: z_new0 is not a point-Jacobi apply
   double* partials;
+  int32_t gu, gp;              // workgroups of the velocity / pressure part (one partial each)
+  int32_t fold, na, nb;        // fold: delta = fixed sum of pa[0..na), pb[0..nb) in every workgroup
+  const double *pa, *pb;
+  // fused block Jacobi over runs of consecutive dofs (BS > 0 instantiations)
+  int32_t nblocks;
+  const int32_t* run;
+  const double* packed;
 };
 
-__global__ __launch_bounds__(kBlock) void minres_k4_kernel(MK4Args a) {
-  __shared__ double lds[kBlock / kWave];
+constexpr int kMPerBlock = 2 * kBlock;     // one-shot element-wise launches: two elements per lane
+
+__device__ __forceinline__ double m3_delta(const MK4Args& a, double* lds) {
+  if (!a.fold) return a.scal[M_DELTA];
+  const double d = fixed_sum_1024(a.pa, a.na, a.pb, a.nb, lds);
+  if (blockIdx.x == 0 && threadIdx.x == 0) a.scal[M_DELTA] = d;
+  return d;
+}
+
+// BS == 0: the velocity part is element-wise (point Jacobi when a.dinv, else v_new only);
+// BS > 0: one lane per block of <= BS consecutive dofs, z_new0 = J v_new0 from the packed symmetric
+// inverse blocks (the arithmetic of bjac_apply_sym_kernel)
+template <int BS>
+__global__ __launch_bounds__(kBlock) void minres_m3_kernel(MK4Args a) {
+  __shared__ double lds[kRedDoubles];
   if (minres_skip(a.ctrl, a.k)) return;
-  const double delta = a.scal[M_DELTA], gamma = a.scal[M_GAMMA];
-  const int stride = gridDim.x * kBlock;
+  const double delta = m3_delta(a, lds), gamma = a.scal[M_GAMMA];
+  const int wg = blockIdx.x;
   double acc = 0.0;
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < a.n_u; i += stride) {
-    const double vn = fma(-gamma, a.vo0[i], fma(-delta, a.v0[i], a.kz0[i]));
-    a.vn0[i] = vn;
-    if (a.dinv) {
-      const double zn = a.dinv[i] * vn;
-      a.zn0[i] = zn;
+  if (wg < a.gu) {
+    if constexpr (BS == 0) {
+      const int i0 = (wg * kBlock + int(threadIdx.x)) * 2;
+      for (int i = i0; i < i0 + 2 && i < a.n_u; ++i) {
+        const double vn = fma(-gamma, a.vo0[i], fma(-delta, a.v0[i], a.kz0[i]));
+        a.vn0[i] = vn;
+        if (a.dinv) {
+          const double zn = a.dinv[i] * vn;
+          a.zn0[i] = zn;
+          acc = fma(zn, vn, acc);
+        }
+      }
+    } else {
+      constexpr int B = BS;
+      const int b = wg * kBlock + int(threadIdx.x);
+      if (b < a.nblocks) {
+        const int32_t w = a.run[b], first = w >> 5, len = w & 31;
+        double xv[B], sv[B];
+#pragma unroll
+        for (int c = 0; c < B; ++c) {
+          double vn = 0.0;
+          if (c < len) {
+            const int i = first + c;
+            vn = fma(-gamma, a.vo0[i], fma(-delta, a.v0[i], a.kz0[i]));
+            a.vn0[i] = vn;
+          }
+          xv[c] = vn;
+          sv[c] = 0.0;
+        }
+        int t = 0;
+#pragma unroll
+        for (int r = 0; r < B; ++r) {
+#pragma unroll
+          for (int c = r; c < B; ++c, ++t) {
+            const double m = a.packed[size_t(t) * a.nblocks + b];
+            sv[r] = fma(m, xv[c], sv[r]);
+            if (c > r) sv[c] = fma(m, xv[r], sv[c]);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < B; ++r) {
+          if (r < len) {
+            const double zn = sv[r];
+            a.zn0[first + r] = zn;
+            acc = fma(zn, xv[r], acc);
+          }
+        }
+      }
+    }
+  } else {
+    const int i0 = ((wg - a.gu) * kBlock + int(threadIdx.x)) * 2;
+    for (int i = i0; i < i0 + 2 && i < a.n_p; ++i) {
+      const double vn = fma(-gamma, a.vo1[i], fma(-delta, a.v1[i], a.kz1[i]));
+      const double zn = a.minv[i] * vn;
+      a.vn1[i] = vn;
+      a.zn1[i] = zn;
       acc = fma(zn, vn, acc);
     }
   }
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < a.n_p; i += stride) {
-    const double vn = fma(-gamma, a.vo1[i], fma(-delta, a.v1[i], a.kz1[i]));
-    const double zn = a.minv[i] * vn;
-    a.vn1[i] = vn;
-    a.zn1[i] = zn;
-    acc = fma(zn, vn, acc);
-  }
   const double s = block_sum(acc, lds);
-  if (threadIdx.x == 0) a.partials[blockIdx.x] = s;
+  if (threadIdx.x == 0) a.partials[wg] = s;
 }
 
-// partial <x, y> of the velocity block after a block-Jacobi apply
+// partial <x, y> of the velocity block after a preconditioner apply that is not fused
 __global__ __launch_bounds__(kBlock) void minres_dot_kernel(const int32_t* __restrict__ ctrl, int k, int32_t n,
                                                              const double* __restrict__ x,
                                                              const double* __restrict__ y,
                                                              double* __restrict__ partials) {
-  __shared__ double lds[kBlock / kWave];
+  __shared__ double lds[kRedDoubles];
   if (minres_skip(ctrl, k)) return;
   const int stride = gridDim.x * kBlock;
   double acc = 0.0;
@@ -151,52 +196,16 @@ __global__ __launch_bounds__(kBlock) void minres_dot_kernel(const int32_t* __res
   if (threadIdx.x == 0) partials[blockIdx.x] = s;
 }
 
-__global__ void minres_scalar_kernel(int32_t* __restrict__ ctrl, double* __restrict__ s, double* __restrict__ hist,
-                                     int k) {
-  if (threadIdx.x != 0 || minres_skip(ctrl, k)) return;
-  const double delta = s[M_DELTA], gamma = s[M_GAMMA];
-  const double gamma_new = sqrt(s[M_G2]);                              // :103
-  const double c = s[M_C], c_old = s[M_C_OLD], sn = s[M_S], s_old = s[M_S_OLD];
-  const double alpha0 = c * delta - c_old * sn * gamma;                // :107
-  const double alpha1 = sqrt(alpha0 * alpha0 + gamma_new * gamma_new);
-  const double alpha2 = sn * delta + c_old * c * gamma;
-  const double alpha3 = s_old * gamma;
-  const double c_new = alpha0 / alpha1;                                // :112
-  const double s_new = gamma_new / alpha1;
-  const double eta_old = s[M_ETA_OLD];
-  s[M_A1] = alpha1;
-  s[M_A2] = alpha2;
-  s[M_A3] = alpha3;
-  s[M_UCOEF] = c_new * eta_old;                                        // :118
-  s[M_INVG] = 1.0 / gamma_new;                                         // :104-105
-  const double res = fabs(s_new) * s[M_RES_OLD];                       // :122
-  hist[k] = res / s[M_ERR0];                                           // :125
-  ctrl[MC_LASTK] = k;
-  // shift the scalars (:135-144)
-  s[M_ETA_OLD] = -s_new * eta_old;
-  s[M_S_OLD] = sn;
-  s[M_S] = s_new;
-  s[M_C_OLD] = c;
-  s[M_C] = c_new;
-  s[M_GAMMA] = gamma_new;
-  s[M_RES_OLD] = res;
-  if (res < s[M_TOL] * s[M_ERR0]) {                                    // relative break (:126)
-    ctrl[MC_KSTOP] = k;
-    ctrl[MC_REASON] = 1;
-    ctrl[MC_STOP] = 1;
-  } else if (!(res > s[M_TOL])) {                                      // absolute guard of the while (:96)
-    ctrl[MC_KSTOP] = k;
-    ctrl[MC_REASON] = 2;
-    ctrl[MC_STOP] = 1;
-  }
-}
-
 struct MK5Args {
-  const int32_t* ctrl;
-  const double* scal;
+  int32_t* ctrl;
+  double* scal;                // base of both scalar sets
+  double* hist;
   int32_t n_u, n_p, k;
   double *zn0, *zn1, *vn0, *vn1, *wn0, *wn1, *u0, *u1;
   const double *z0, *z1, *wo0, *wo1, *w0, *w1;
+  int32_t gu;
+  int32_t fold, na, nb;        // fold: gamma_new^2 = fixed sum of pa[0..na), pb[0..nb) in every workgroup
+  const double *pa, *pb;
 };
 
 __device__ __forceinline__ void minres_k5_body(int i, double invg, double a1inv, double a2, double a3, double uc,
@@ -210,19 +219,83 @@ __device__ __forceinline__ void minres_k5_body(int i, double invg, double a1inv,
   NSS_ST(u[i], fma(uc, t, u[i]));                     // :118
 }
 
-__global__ __launch_bounds__(kBlock) void minres_k5_kernel(MK5Args a) {
+__global__ __launch_bounds__(kBlock) void minres_m4_kernel(MK5Args a) {
+  __shared__ double lds[kRedDoubles];
   if (minres_skip(a.ctrl, a.k)) return;
-  const double invg = a.scal[M_INVG], a1inv = 1.0 / a.scal[M_A1], a2 = a.scal[M_A2], a3 = a.scal[M_A3];
-  const double uc = a.scal[M_UCOEF];
-  const int stride = gridDim.x * kBlock;
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < a.n_u; i += stride)
-    minres_k5_body(i, invg, a1inv, a2, a3, uc, a.zn0, a.vn0, a.wn0, a.u0, a.z0, a.wo0, a.w0);
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < a.n_p; i += stride)
-    minres_k5_body(i, invg, a1inv, a2, a3, uc, a.zn1, a.vn1, a.wn1, a.u1, a.z1, a.wo1, a.w1);
+  const double* s = a.scal + m_set(a.k);        // this iteration's scalars (read by every workgroup)
+  double* o = a.scal + m_set(a.k + 1);          // next iteration's (written by workgroup 0 only)
+  const double g2 = a.fold ? fixed_sum_1024(a.pa, a.na, a.pb, a.nb, lds) : s[M_G2];
+  const double delta = s[M_DELTA], gamma = s[M_GAMMA];
+  const double gamma_new = sqrt(g2);                                   // :103
+  const double c = s[M_C], c_old = s[M_C_OLD], sn = s[M_S], s_old = s[M_S_OLD];
+  const double alpha0 = c * delta - c_old * sn * gamma;                // :107
+  const double alpha1 = sqrt(alpha0 * alpha0 + gamma_new * gamma_new);
+  const double alpha2 = sn * delta + c_old * c * gamma;
+  const double alpha3 = s_old * gamma;
+  const double c_new = alpha0 / alpha1;                                // :112
+  const double s_new = gamma_new / alpha1;
+  const double eta_old = s[M_ETA_OLD];
+  const double uc = c_new * eta_old;                                   // :118
+  const double invg = 1.0 / gamma_new;                                 // :104-105
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const double res = fabs(s_new) * s[M_RES_OLD];                     // :122
+    a.hist[a.k] = res / s[M_ERR0];                                     // :125
+    a.ctrl[MC_LASTK] = a.k;
+    // the scalars of iteration k + 1 (:135-144)
+    o[M_ETA_OLD] = -s_new * eta_old;
+    o[M_S_OLD] = sn;
+    o[M_S] = s_new;
+    o[M_C_OLD] = c;
+    o[M_C] = c_new;
+    o[M_GAMMA] = gamma_new;
+    o[M_RES_OLD] = res;
+    o[M_ERR0] = s[M_ERR0];
+    o[M_TOL] = s[M_TOL];
+    if (res < s[M_TOL] * s[M_ERR0]) {                                  // relative break (:126)
+      a.ctrl[MC_KSTOP] = a.k;
+      a.ctrl[MC_REASON] = 1;
+      a.ctrl[MC_STOP] = 1;
+    } else if (!(res > s[M_TOL])) {                                    // absolute guard of the while (:96)
+      a.ctrl[MC_KSTOP] = a.k;
+      a.ctrl[MC_REASON] = 2;
+      a.ctrl[MC_STOP] = 1;
+    }
+  }
+  const double a1inv = 1.0 / alpha1;
+  const int wg = blockIdx.x;
+  if (wg < a.gu) {
+    const int i0 = (wg * kBlock + int(threadIdx.x)) * 2;
+    for (int i = i0; i < i0 + 2 && i < a.n_u; ++i)
+      minres_k5_body(i, invg, a1inv, alpha2, alpha3, uc, a.zn0, a.vn0, a.wn0, a.u0, a.z0, a.wo0, a.w0);
+  } else {
+    const int i0 = ((wg - a.gu) * kBlock + int(threadIdx.x)) * 2;
+    for (int i = i0; i < i0 + 2 && i < a.n_p; ++i)
+      minres_k5_body(i, invg, a1inv, alpha2, alpha3, uc, a.zn1, a.vn1, a.wn1, a.u1, a.z1, a.wo1, a.w1);
+  }
 }
 
-static int m_grid(const nss_minres_t& s) { return stream_grid(int64_t(s.n_u) + s.n_p, kBlock * 4); }
+static int m_gu(const nss_minres_t& s) { return (s.n_u + kMPerBlock - 1) / kMPerBlock; }
+static int m_gp(const nss_minres_t& s) { return (s.n_p + kMPerBlock - 1) / kMPerBlock; }
 static int m_dot_grid(const nss_minres_t& s) { return stream_grid(s.n_u, kBlock * 4); }
+
+// block Jacobi that M3 applies itself: runs of consecutive dofs, symmetric inverse blocks, every dof covered
+static bool m_fused_bjac(const nss_minres_t& s) {
+  const nss_bjac_s* j = s.pre_bjac;
+  return j != nullptr && !s.pre_amg && !j->gs_mat && j->run != nullptr && j->inv_sym != nullptr && j->n_uncovered == 0;
+}
+static int m3_gu(const nss_minres_t& s) {
+  return m_fused_bjac(s) ? (s.pre_bjac->nblocks + kBlock - 1) / kBlock : m_gu(s);
+}
+static int m3_partials(const nss_minres_t& s) { return m3_gu(s) + m_gp(s); }
+
+constexpr int kMFoldMax = 4096;
+static int g_minres_fold_mode = -1;
+static bool m_fold(const nss_minres_t& s) {
+  if (g_minres_fold_mode >= 0) return g_minres_fold_mode != 0;
+  int64_t dotg = m_dot_grid(s);
+  if (s.pre_bjac) dotg = std::max<int64_t>(dotg, bjac_dot_grid(*s.pre_bjac));
+  return s.A->nblk + s.B->nblk <= kMFoldMax && m3_partials(s) <= kMFoldMax && dotg <= kMFoldMax;
+}
 
 static void minres_check(const nss_minres_t* s) {
   NSS_REQUIRE(s != nullptr, "minres: NULL state");
@@ -242,30 +315,56 @@ static void minres_check(const nss_minres_t* s) {
   }
 }
 
+template <int BS>
+static void launch_m3(const MK4Args& a, int grid, hipStream_t st) {
+  hipLaunchKernelGGL((minres_m3_kernel<BS>), dim3(grid), dim3(kBlock), 0, st, a);
+}
+
 static void minres_iteration(const nss_minres_t& s, int k, hipStream_t st) {
   const int io = (k + 2) % 3, ic = k % 3, in = (k + 1) % 3;   // old, current, new
   const int zc = k % 2, zn = (k + 1) % 2;
-  launch_csr_stream(*s.A, s.z[zc][0], EpiMStore{s.ctrl, k, s.kz[0]}, st);
-  launch_csr_stream(*s.BT, s.z[zc][1], EpiMAccDot{s.ctrl, k, 1, s.kz[0], s.z[zc][0], s.partials_a}, st);
-  launch_csr_stream(*s.B, s.z[zc][0], EpiMAccDot{s.ctrl, k, 0, s.kz[1], s.z[zc][1], s.partials_b}, st);
-  hipLaunchKernelGGL(minres_sum_kernel, dim3(1), dim3(kMSum), 0, st, s.ctrl, k, s.BT->nblk, s.partials_a,
-                     s.B->nblk, s.partials_b, s.scal, int(M_DELTA));
-  NSS_CHECK_LAUNCH();
-  MK4Args a4{s.ctrl, s.scal, s.n_u, s.n_p, k, s.kz[0], s.kz[1], s.v[ic][0], s.v[ic][1], s.v[io][0], s.v[io][1],
-             s.v[in][0], s.v[in][1], s.z[zn][0], s.z[zn][1], s.pre_amg ? nullptr : s.pre_diag, s.minv, s.partials_c};
-  hipLaunchKernelGGL(minres_k4_kernel, dim3(m_grid(s)), dim3(kBlock), 0, st, a4);
+  const bool fold = m_fold(s);
+  double* set = s.scal + m_set(k);
+  // M1: kz0 = B^T z1 and kz1 = B z0 with <kz1, z1>;  M2: kz0 += A z0 with <kz0, z0>
+  EpiMStore e_bt{s.ctrl, k, s.kz[0]};
+  EpiMAccDot e_b{s.ctrl, k, 0, s.kz[1], s.z[zc][1], s.partials_b};
+  if (!launch_csr_stream_dual(*s.BT, s.z[zc][1], e_bt, *s.B, s.z[zc][0], e_b, st)) {
+    launch_csr_stream(*s.BT, s.z[zc][1], e_bt, st);
+    launch_csr_stream(*s.B, s.z[zc][0], e_b, st);
+  }
+  launch_csr_stream(*s.A, s.z[zc][0], EpiMAccDot{s.ctrl, k, 1, s.kz[0], s.z[zc][0], s.partials_a}, st);
+  if (!fold) {
+    hipLaunchKernelGGL(minres_sum_kernel, dim3(1), dim3(kSumLanes), 0, st, s.ctrl, k, s.A->nblk, s.partials_a,
+                       s.B->nblk, s.partials_b, set, int(M_DELTA));
+    NSS_CHECK_LAUNCH();
+  }
+  // M3
+  const bool fused = m_fused_bjac(s);
+  MK4Args a4{s.ctrl, set, s.n_u, s.n_p, k, s.kz[0], s.kz[1], s.v[ic][0], s.v[ic][1], s.v[io][0], s.v[io][1],
+             s.v[in][0], s.v[in][1], s.z[zn][0], s.z[zn][1], (s.pre_amg || s.pre_bjac) ? nullptr : s.pre_diag, s.minv,
+             s.partials_c, m3_gu(s), m_gp(s), fold ? 1 : 0, s.A->nblk, s.B->nblk, s.partials_a, s.partials_b,
+             fused ? s.pre_bjac->nblocks : 0, fused ? s.pre_bjac->run : nullptr, fused ? s.pre_bjac->inv_sym : nullptr};
+  const int g3 = a4.gu + a4.gp;
+  if (!fused) {
+    launch_m3<0>(a4, g3, st);
+  } else {
+    switch (s.pre_bjac->bs) {
+#define NSS_M3(N) case N: launch_m3<N>(a4, g3, st); break;
+      NSS_M3(1) NSS_M3(2) NSS_M3(3) NSS_M3(4) NSS_M3(5) NSS_M3(6) NSS_M3(7) NSS_M3(8)
+      NSS_M3(9) NSS_M3(10) NSS_M3(11) NSS_M3(12) NSS_M3(13) NSS_M3(14) NSS_M3(15) NSS_M3(16)
+#undef NSS_M3
+      default: throw Error("minres: unsupported block size");
+    }
+  }
   NSS_CHECK_LAUNCH();
   int nb2 = 0;
-  if (s.pre_bjac || s.pre_amg) {
+  if (!fused && (s.pre_bjac || s.pre_amg)) {
     // z_new[0] = preA v_new[0] outside the element-wise kernel; after the stop these launches only
     // touch ring slots nobody reads any more
     if (s.pre_amg) {
       amg_apply(*s.pre_amg, 1.0, s.v[in][0], s.z[zn][0], st);
       if (s.pre_bjac) bjac_apply(*s.pre_bjac, 1.0, s.v[in][0], 1.0, s.z[zn][0], nullptr, st);
-      if (s.pre_diag) {
-        const int rc = nss_diag_apply_f64(s.n_u, s.pre_diag, 1.0, s.v[in][0], 1.0, s.z[zn][0], st);
-        if (rc != 0) throw Error(nss_last_error());
-      }
+      if (s.pre_diag) diag_apply(s.n_u, s.pre_diag, 1.0, s.v[in][0], 1.0, s.z[zn][0], nullptr, st);
     } else if (s.pre_bjac->gs_mat) {
       bjac_apply(*s.pre_bjac, 1.0, s.v[in][0], 0.0, s.z[zn][0], nullptr, st);
     } else {                          // block Jacobi: <z_new, v_new> comes out of the apply kernel
@@ -278,14 +377,16 @@ static void minres_iteration(const nss_minres_t& s, int k, hipStream_t st) {
       NSS_CHECK_LAUNCH();
     }
   }
-  hipLaunchKernelGGL(minres_sum_kernel, dim3(1), dim3(kMSum), 0, st, s.ctrl, k, nb2, s.partials_a, m_grid(s),
-                     s.partials_c, s.scal, int(M_G2));
-  NSS_CHECK_LAUNCH();
-  hipLaunchKernelGGL(minres_scalar_kernel, dim3(1), dim3(kWave), 0, st, s.ctrl, s.scal, s.hist, k);
-  NSS_CHECK_LAUNCH();
-  MK5Args a5{s.ctrl, s.scal, s.n_u, s.n_p, k, s.z[zn][0], s.z[zn][1], s.v[in][0], s.v[in][1], s.w[in][0],
-             s.w[in][1], s.u[0], s.u[1], s.z[zc][0], s.z[zc][1], s.w[io][0], s.w[io][1], s.w[ic][0], s.w[ic][1]};
-  hipLaunchKernelGGL(minres_k5_kernel, dim3(m_grid(s)), dim3(kBlock), 0, st, a5);
+  if (!fold) {
+    hipLaunchKernelGGL(minres_sum_kernel, dim3(1), dim3(kSumLanes), 0, st, s.ctrl, k, nb2, s.partials_a, g3,
+                       s.partials_c, set, int(M_G2));
+    NSS_CHECK_LAUNCH();
+  }
+  // M4
+  MK5Args a5{s.ctrl, s.scal, s.hist, s.n_u, s.n_p, k, s.z[zn][0], s.z[zn][1], s.v[in][0], s.v[in][1], s.w[in][0],
+             s.w[in][1], s.u[0], s.u[1], s.z[zc][0], s.z[zc][1], s.w[io][0], s.w[io][1], s.w[ic][0], s.w[ic][1],
+             m_gu(s), fold ? 1 : 0, nb2, g3, s.partials_a, s.partials_c};
+  hipLaunchKernelGGL(minres_m4_kernel, dim3(m_gu(s) + m_gp(s)), dim3(kBlock), 0, st, a5);
   NSS_CHECK_LAUNCH();
 }
 
@@ -300,9 +401,9 @@ int nss_minres_workspace(const nss_minres_t* s, int64_t* partials_a, int64_t* pa
     NSS_REQUIRE(s && s->A && s->B && s->BT, "minres_workspace: NULL state / matrices");
     int64_t dotg = m_dot_grid(*s);
     if (s->pre_bjac) dotg = std::max<int64_t>(dotg, bjac_dot_grid(*s->pre_bjac));
-    if (partials_a) *partials_a = std::max<int64_t>(s->BT->nblk, dotg);
+    if (partials_a) *partials_a = std::max<int64_t>(s->A->nblk, dotg);
     if (partials_b) *partials_b = s->B->nblk;
-    if (partials_c) *partials_c = m_grid(*s);
+    if (partials_c) *partials_c = m3_partials(*s);
   });
 }
 
@@ -311,6 +412,13 @@ int nss_minres_iterate(const nss_minres_t* s, int32_t k_begin, int32_t k_end, ns
     minres_check(s);
     NSS_REQUIRE(k_begin >= 1, "minres_iterate: iterations are counted from 1");
     for (int k = k_begin; k < k_end; ++k) minres_iteration(*s, k, as_stream(stream));
+  });
+}
+
+int nss_minres_fold_mode(int32_t mode) {
+  return guarded([&] {
+    NSS_REQUIRE(mode >= -1 && mode <= 1, "minres_fold_mode: -1 (automatic), 0 (never) or 1 (always)");
+    g_minres_fold_mode = mode;
   });
 }
 

@@ -97,6 +97,15 @@ inline int stream_grid(int64_t work_items, int items_per_block) {
   return static_cast<int>(g);
 }
 
+// 16-byte accesses of two consecutive doubles
+typedef double dbl2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void store2_nt(double* p, const double2& v) {
+  dbl2v t;
+  t.x = v.x;
+  t.y = v.y;
+  __builtin_nontemporal_store(t, reinterpret_cast<dbl2v*>(p));
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // ---- device-side reductions -------------------------------------------------------
@@ -119,6 +128,100 @@ __device__ __forceinline__ double block_sum(double v, double* lds) {
 #pragma unroll
   for (int w = 1; w < kBlock / kWave; ++w) t += lds[w];
   return t;
+}
+
+// Fixed-order sum of pa[0 .. na) and pb[0 .. nb), evaluated by one 256-thread workgroup; the result
+// is valid in every thread.  The tree: 1024 virtual lanes (thread t plays lanes t, t + 256, t + 512,
+// t + 768), four strided accumulators per virtual lane, a 64-lane butterfly per virtual wave, the 16
+// wave sums added in wave order, pa's total + pb's total.  Used both by the stand-alone sum kernels
+// and by the kernels that fold the sum into their prologue, so the two plans give identical bits.
+// `lds`: 32 doubles.  ~35 k partials (the 1e7-DoF case) are latency-bound: 9 dependent loads per chain.
+// THREADS = 1024 (the stand-alone sum kernel: one virtual lane per thread, shortest dependent chain) gives
+// the same bits as THREADS = 256 (inside a kernel's workgroup).
+constexpr int kSumLanes = 1024;
+template <int THREADS = kBlock>
+__device__ __forceinline__ double fixed_sum_1024(const double* __restrict__ pa, int na, const double* __restrict__ pb,
+                                                 int nb, double* lds) {
+  static_assert(THREADS % kWave == 0 && kSumLanes % THREADS == 0, "fixed_sum_1024: bad workgroup size");
+  const int tid = threadIdx.x;
+  __syncthreads();                      // protect lds reuse
+  if (na <= 4 * kSumLanes && nb <= 4 * kSumLanes) {
+    // Short sums (the launch-bound small systems): all loads are issued before the first add, so the
+    // workgroup waits for ONE memory latency instead of one per loop trip.  Same values, same order as
+    // the loops below: with at most four terms per virtual lane the strided loop runs once when all four
+    // exist -- (x0 + x1) + (x2 + x3) -- and otherwise the tail loop adds them one after the other --
+    // ((x0 + x1) + x2); absent terms are 0.0 and x + 0.0 == x.
+    constexpr int kV = kSumLanes / THREADS;
+    double xa[kV][4], xb[kV][4];
+#pragma unroll
+    for (int j = 0; j < kV; ++j) {
+      const int v = tid + j * THREADS;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        xa[j][q] = v + q * kSumLanes < na ? pa[v + q * kSumLanes] : 0.0;
+        xb[j][q] = v + q * kSumLanes < nb ? pb[v + q * kSumLanes] : 0.0;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < kV; ++j) {
+      const int v = tid + j * THREADS;
+      const double ra = v + 3 * kSumLanes < na ? (xa[j][0] + xa[j][1]) + (xa[j][2] + xa[j][3])
+                                               : (xa[j][0] + xa[j][1]) + xa[j][2];
+      const double rb = v + 3 * kSumLanes < nb ? (xb[j][0] + xb[j][1]) + (xb[j][2] + xb[j][3])
+                                               : (xb[j][0] + xb[j][1]) + xb[j][2];
+      const double sa = wave_sum(ra);
+      const double sb = wave_sum(rb);
+      if ((tid & (kWave - 1)) == 0) {
+        lds[v >> 6] = sa;
+        lds[kSumLanes / kWave + (v >> 6)] = sb;
+      }
+    }
+    __syncthreads();
+    double ta = 0.0, tb = 0.0;
+#pragma unroll
+    for (int w = 0; w < kSumLanes / kWave; ++w) {
+      ta += lds[w];
+      tb += lds[kSumLanes / kWave + w];
+    }
+    return ta + tb;
+  }
+#pragma unroll
+  for (int j = 0; j < kSumLanes / THREADS; ++j) {
+    const int v = tid + j * THREADS;    // virtual lane
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int i = v;
+    for (; i + 3 * kSumLanes < na; i += 4 * kSumLanes) {
+      a0 += pa[i];
+      a1 += pa[i + kSumLanes];
+      a2 += pa[i + 2 * kSumLanes];
+      a3 += pa[i + 3 * kSumLanes];
+    }
+    for (; i < na; i += kSumLanes) a0 += pa[i];
+    double b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
+    i = v;
+    for (; i + 3 * kSumLanes < nb; i += 4 * kSumLanes) {
+      b0 += pb[i];
+      b1 += pb[i + kSumLanes];
+      b2 += pb[i + 2 * kSumLanes];
+      b3 += pb[i + 3 * kSumLanes];
+    }
+    for (; i < nb; i += kSumLanes) b0 += pb[i];
+    const double sa = wave_sum((a0 + a1) + (a2 + a3));
+    const double sb = wave_sum((b0 + b1) + (b2 + b3));
+    if ((tid & (kWave - 1)) == 0) {
+      const int vwave = v >> 6;         // virtual wave = real wave + j * THREADS / 64: same 64 lanes
+      lds[vwave] = sa;
+      lds[kSumLanes / kWave + vwave] = sb;
+    }
+  }
+  __syncthreads();
+  double ta = 0.0, tb = 0.0;
+#pragma unroll
+  for (int w = 0; w < kSumLanes / kWave; ++w) {
+    ta += lds[w];
+    tb += lds[kSumLanes / kWave + w];
+  }
+  return ta + tb;
 }
 
 // Library-wide scratch for reductions: partial sums (device) + one pinned host slot.

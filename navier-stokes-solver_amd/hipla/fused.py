@@ -50,6 +50,7 @@ class HaloStruct(C.Structure):
 
 
 PHASE = {"K1": 1, "K2": 2, "K3": 3, "SUM1": 4, "ALPHA": 5, "K4": 6, "SUM2": 7, "BETA": 8, "K5": 9}
+CPHASE = {"C1": 1, "C23": 2, "SUMA": 3, "C4": 4, "SUMW": 5}      # compact plan (NSS_BPCG2C_*)
 S_WD, S_AS, S_WDN, S_ALPHA, S_BETA, S_ERR0, S_TOL, S_REL = range(8)
 
 
@@ -226,6 +227,21 @@ class Bpcg2Loop:
         self.eng._check(self.lib.nss_bpcg2_phases(C.byref(self.state), PHASE[first], PHASE[last], int(it),
                                                   self.eng.stream))
 
+    def cphases(self, first, last, it):
+        """Phases first..last of iteration `it` of the compact plan (what `enqueue` issues)."""
+        self.eng._check(self.lib.nss_bpcg2_cphases(C.byref(self.state), CPHASE[first], CPHASE[last], int(it),
+                                                   self.eng.stream))
+
+    def enqueue_classic(self, it_begin, it_end):
+        """The same iterations in the eight-phase form (cross-checks, measurements)."""
+        self.eng._check(self.lib.nss_bpcg2_iterate_classic(C.byref(self.state), int(it_begin), int(it_end),
+                                                           self.eng.stream))
+
+    def folds_sums(self):
+        out = C.c_int32()
+        self.eng._check(self.lib.nss_bpcg2_folds_sums(C.byref(self.state), C.byref(out)))
+        return bool(out.value)
+
     def enqueue_dist(self, dist_handle, halos, overlap, it_begin, it_end):
         """Row-partitioned iterations issued natively (nss_bpcg2_iterate_dist)."""
         self.eng._check(self.lib.nss_bpcg2_iterate_dist(C.byref(self.state), dist_handle, C.byref(halos[0]),
@@ -348,7 +364,7 @@ class MinresLoop:
         eng._check(self.lib.nss_minres_workspace(C.byref(st), C.byref(na), C.byref(nb), C.byref(nc)))
         self.partials = [eng.zeros(max(1, x.value)) for x in (na, nb, nc)]
         st.partials_a, st.partials_b, st.partials_c = (p.data_ptr() for p in self.partials)
-        self.scal = eng.zeros(20)
+        self.scal = eng.zeros(64)           # two sets of 32 scalars, double-buffered by the parity of k
         self.ctrl = torch.zeros(4, dtype=torch.int32, device=eng.device)
         st.scal, st.ctrl = self.scal.data_ptr(), self.ctrl.data_ptr()
         self.state = st
@@ -360,7 +376,7 @@ class MinresLoop:
         poll_every = poll_every or POLL_EVERY
         self.hist = eng.zeros(maxsteps + 2)
         st.hist = self.hist.data_ptr()
-        scal = np.zeros(20)
+        scal = np.zeros(64)                 # iteration k = 1 reads the first set
         scal[M_GAMMA], scal[M_ETA_OLD], scal[M_C_OLD], scal[M_C] = gamma, gamma, 1.0, 1.0
         scal[M_RES_OLD], scal[M_ERR0], scal[M_TOL] = gamma, gamma, tol
         eng.upload(scal, self.scal)

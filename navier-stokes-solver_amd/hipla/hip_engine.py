@@ -79,6 +79,10 @@ def _signatures():
         "nss_bpcg2_phase": (C.c_int, [vp, i32, i32, vp]),
         "nss_bpcg2_phases": (C.c_int, [vp, i32, i32, i32, vp]),
         "nss_bpcg2_iterate": (C.c_int, [vp, i32, i32, vp]),
+        "nss_bpcg2_iterate_classic": (C.c_int, [vp, i32, i32, vp]),
+        "nss_bpcg2_cphases": (C.c_int, [vp, i32, i32, i32, vp]),
+        "nss_bpcg2_folds_sums": (C.c_int, [vp, c_i32_p]),
+        "nss_bpcg2_fold_mode": (C.c_int, [i32]),
         "nss_bpcg2_poll": (C.c_int, [vp, c_i32_p, c_i32_p, c_i32_p, vp]),
         "nss_bpcg1_workspace": (C.c_int, [vp, c_i64_p, c_i64_p, c_i64_p]),
         "nss_bpcg1_iterate": (C.c_int, [vp, i32, i32, vp]),
@@ -86,6 +90,7 @@ def _signatures():
         "nss_minres_workspace": (C.c_int, [vp, c_i64_p, c_i64_p, c_i64_p]),
         "nss_minres_iterate": (C.c_int, [vp, i32, i32, vp]),
         "nss_minres_poll": (C.c_int, [vp, c_i32_p, c_i32_p, c_i32_p, c_i32_p, vp]),
+        "nss_minres_fold_mode": (C.c_int, [i32]),
     }
 
 

@@ -400,6 +400,65 @@ def test_fused_bpcg2_frozen_at_break_and_maxsteps_warning(hip_engine):
     assert it == 8 and "Warning: BPCG did not converge" in out.getvalue()
 
 
+@pytest.mark.parametrize("case", ["stokes3d_n10_bjac_bpcg2", "stokes2d_n24_jacobi_bpcg2",
+                                  "stokes3d_n5_facet_x12_bpcg2", "stokes2d_n16_facet_x5_bpcg2",
+                                  "stokes3d_n8_bjac_cond_bpcg2"])
+def test_compact_plan_equals_eight_phase_form_bit_for_bit(hip_engine, case):
+    """The single-GPU loop issues three dependent launches per iteration (C1, C23, C4: books of the
+    previous iteration and the dot-product sums folded into the consuming kernels, A and B rows in
+    one launch, operands beta*s1 + w1 and t1 - s0 formed on the fly) where the eight-phase form -- which
+    the row-partitioned loop keeps -- issues eight.  Same floating-point operations per lane and
+    the same summation tree: identical bits, with the sums folded or in their stand-alone kernels,
+    including the iteration at which the stop test fires."""
+    import hipla
+    from solvers.bramblepasciak_new import BpcgSession
+    d = np.load(golden_path(case))
+    c, blfA, A, B, preA, preS = case_operands(d)
+    s = c.system
+    lib = hip_engine.lib
+
+    def run(form, nit, tol):
+        sol = hipla.BlockVector([hipla.Vector(s.n_u), hipla.Vector(s.n_p)])
+        with contextlib.redirect_stdout(io.StringIO()):
+            ses = BpcgSession(blfA, Form(B), None, hipla.Vector.from_numpy(c.f), hipla.Vector.from_numpy(c.g),
+                              preA, preS, sol=sol)
+        loop = ses.fused
+        assert loop is not None
+        ses.first_direction()
+        loop.start(ses.wdn, ses.err0, tol, True, nit)
+        it = 0
+        while it < nit:                            # uneven chunks: the books of a chunk's last iteration
+            end = min(nit, it + 1 + (it % 5))      # are done by the poll, the others by the next C1
+            (loop.enqueue_classic if form == "classic" else loop.enqueue)(it, end)
+            it = end
+            done, it_final, last = loop.poll()
+            if done:
+                break
+        final = it_final if done else nit - 1
+        return done, final, loop.history(final).copy(), sol.numpy(), hip_engine.to_host(loop.scal).copy()
+
+    try:
+        free = run("classic", 40, 0.0)
+        k_stop = int(np.argmin(free[2][:30]))              # the stop test fires first at this iteration ...
+        tol_stop = free[2][k_stop] * (1.0 + 1e-12) / float(d["err0"]) if k_stop > 0 else 0.0
+        for tol in (tol_stop, 0.0):
+            ref = run("classic", 40, tol)
+            if tol > 0.0:
+                assert ref[0] and 0 < ref[1] <= k_stop + 1, (ref[:2], k_stop)   # ... (tested one iteration late, :243-247)
+            assert np.all(np.isfinite(ref[2])) and len(ref[2]) == ref[1] + 1
+            for mode in (1, 0, -1):
+                assert lib.nss_bpcg2_fold_mode(mode) == 0
+                got = run("compact", 40, tol)
+                assert got[0] == ref[0] and got[1] == ref[1], (mode, tol, got[:2], ref[:2])
+                np.testing.assert_array_equal(got[2], ref[2])           # history
+                np.testing.assert_array_equal(got[3], ref[3])           # solution
+                np.testing.assert_array_equal(got[4][:5], ref[4][:5])   # wd, as_s, wdn, alpha, beta
+        w = min(int(d["window"]), 40)
+        np.testing.assert_allclose(ref[2][:w], d["history"][:w], rtol=1e-8)
+    finally:
+        lib.nss_bpcg2_fold_mode(-1)
+
+
 def test_drivers_on_gpu(hip_engine, tmp_path):
     """Harness / driver shape on the product engine: NavierStokes.SolveInitial takes the fused
     loop, run.py writes the reference's CSV columns, stokes_hcurldiv's call converges."""

@@ -7,6 +7,6 @@ for r in $(seq 1 $ROUNDS); do
     NSS_LIB_PATH=$REPO/build/ab/libnss_$v.so python $REPO/bench.py $ARGS 2>/dev/null | python -c "
 import json,sys
 d=json.load(sys.stdin); k=d['kernel_ms']; h=d['hbm_GBs']
-print('$v r$r it/s %.1f ms %.4f | K1 %.4f K2 %.4f K3 %.4f K4 %.4f spmvA %.4f triad %.4f | K2/triad %.3f' % (d['value'], d['ms_per_step'], k['K1_BT'], k['K2_A'], k['K3_B'], k['K4_update'], k['spmv_A_plain'], k['triad_1.6GB'], h['spmv_A_fused_K2']/h['stream_triad']))"
+print('$v r$r it/s %.1f ms %.4f | C1 %.4f C23 %.4f C4 %.4f sums %.4f spmvA %.4f triad %.4f | C23/triad %.3f' % (d['value'], d['ms_per_step'], k['C1_BT_preA'], k['C23_A_B'], k['C4_update'], k['sum_kernels'], k['spmv_A_plain'], k['triad_1.6GB'], h['spmv_AB_fused_C23']/h['stream_triad']))"
   done
 done

@@ -18,5 +18,5 @@ for n in grids:
     d = json.loads(out.decode().strip().splitlines()[-1])
     h = d["hbm_GBs"]
     print("| %d | %d | %.0f | %.4f | %.0f | %.0f | %.0f |" % (n, d["config"]["n_u"] + d["config"]["n_p"], d["value"], d["ms_per_step"],
-                                                           h["whole_iteration_algorithmic"], h["spmv_A_fused_K2"],
+                                                           h["whole_iteration_algorithmic"], h["spmv_AB_fused_C23"],
                                                            h["stream_triad"]), flush=True)
