@@ -416,6 +416,10 @@ NSS_API int nss_minres_poll(const nss_minres_t* s, int32_t* stop, int32_t* k_sto
  * measurements): -1 automatic (inside the consuming kernels up to 4096 partials), 0 always by the
  * stand-alone sum kernel, 1 always inside the consumers.  Same bits either way. */
 NSS_API int nss_minres_fold_mode(int32_t mode);
+/* the same kind of override for applying a block-Jacobi preA (runs of consecutive dofs) inside the
+ * element-wise kernel M3 instead of as its own launch: automatic = in the launch-bound regime only.
+ * The dot partials are grouped differently in the two forms: results agree to rounding, not bitwise. */
+NSS_API int nss_minres_fuse_mode(int32_t mode);
 
 /* ---- fused Bramble-Pasciak CG, textbook form ------------------------------------------------
  * Replaces the loop body of bramble_pasciak_cg.py:110-143 (6 SpMV per iteration) for

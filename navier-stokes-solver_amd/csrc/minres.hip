@@ -98,6 +98,7 @@ struct MK4Args {
   int32_t nblocks;
   const int32_t* run;
   const double* packed;
+  int32_t vec;                 // all vectors 16-byte aligned: two doubles per access
 };
 
 constexpr int kMPerBlock = 2 * kBlock;     // one-shot element-wise launches: two elements per lane
@@ -122,13 +123,30 @@ __global__ __launch_bounds__(kBlock) void minres_m3_kernel(MK4Args a) {
   if (wg < a.gu) {
     if constexpr (BS == 0) {
       const int i0 = (wg * kBlock + int(threadIdx.x)) * 2;
-      for (int i = i0; i < i0 + 2 && i < a.n_u; ++i) {
-        const double vn = fma(-gamma, a.vo0[i], fma(-delta, a.v0[i], a.kz0[i]));
-        a.vn0[i] = vn;
+      if (a.vec && i0 + 1 < a.n_u) {
+        const double2 kz = ld2(a.kz0 + i0), v = ld2(a.v0 + i0), vo = ld2(a.vo0 + i0);
+        double2 vn;
+        vn.x = fma(-gamma, vo.x, fma(-delta, v.x, kz.x));
+        vn.y = fma(-gamma, vo.y, fma(-delta, v.y, kz.y));
+        st2(a.vn0 + i0, vn);
         if (a.dinv) {
-          const double zn = a.dinv[i] * vn;
-          a.zn0[i] = zn;
-          acc = fma(zn, vn, acc);
+          const double2 dv = ld2(a.dinv + i0);
+          double2 zn;
+          zn.x = dv.x * vn.x;
+          zn.y = dv.y * vn.y;
+          st2(a.zn0 + i0, zn);
+          acc = fma(zn.x, vn.x, acc);
+          acc = fma(zn.y, vn.y, acc);
+        }
+      } else {
+        for (int i = i0; i < i0 + 2 && i < a.n_u; ++i) {
+          const double vn = fma(-gamma, a.vo0[i], fma(-delta, a.v0[i], a.kz0[i]));
+          a.vn0[i] = vn;
+          if (a.dinv) {
+            const double zn = a.dinv[i] * vn;
+            a.zn0[i] = zn;
+            acc = fma(zn, vn, acc);
+          }
         }
       }
     } else {
@@ -170,12 +188,25 @@ __global__ __launch_bounds__(kBlock) void minres_m3_kernel(MK4Args a) {
     }
   } else {
     const int i0 = ((wg - a.gu) * kBlock + int(threadIdx.x)) * 2;
-    for (int i = i0; i < i0 + 2 && i < a.n_p; ++i) {
-      const double vn = fma(-gamma, a.vo1[i], fma(-delta, a.v1[i], a.kz1[i]));
-      const double zn = a.minv[i] * vn;
-      a.vn1[i] = vn;
-      a.zn1[i] = zn;
-      acc = fma(zn, vn, acc);
+    if (a.vec && i0 + 1 < a.n_p) {
+      const double2 kz = ld2(a.kz1 + i0), v = ld2(a.v1 + i0), vo = ld2(a.vo1 + i0), mv = ld2(a.minv + i0);
+      double2 vn, zn;
+      vn.x = fma(-gamma, vo.x, fma(-delta, v.x, kz.x));
+      vn.y = fma(-gamma, vo.y, fma(-delta, v.y, kz.y));
+      zn.x = mv.x * vn.x;
+      zn.y = mv.y * vn.y;
+      st2(a.vn1 + i0, vn);
+      st2(a.zn1 + i0, zn);
+      acc = fma(zn.x, vn.x, acc);
+      acc = fma(zn.y, vn.y, acc);
+    } else {
+      for (int i = i0; i < i0 + 2 && i < a.n_p; ++i) {
+        const double vn = fma(-gamma, a.vo1[i], fma(-delta, a.v1[i], a.kz1[i]));
+        const double zn = a.minv[i] * vn;
+        a.vn1[i] = vn;
+        a.zn1[i] = zn;
+        acc = fma(zn, vn, acc);
+      }
     }
   }
   const double s = block_sum(acc, lds);
@@ -206,7 +237,30 @@ struct MK5Args {
   int32_t gu;
   int32_t fold, na, nb;        // fold: gamma_new^2 = fixed sum of pa[0..na), pb[0..nb) in every workgroup
   const double *pa, *pb;
+  int32_t vec;
 };
+
+// the same update for two consecutive entries with 16-byte accesses
+__device__ __forceinline__ void minres_k5_body2(int i, double invg, double a1inv, double a2, double a3, double uc,
+                                                 double* zn, double* vn, double* wn, double* u, const double* z,
+                                                 const double* wo, const double* w) {
+  double2 znv = ld2(zn + i), vnv = ld2(vn + i);
+  const double2 wv = ld2(w + i), wov = ld2(wo + i), zv = ld2(z + i);
+  double2 uv = ld2(u + i);
+  znv.x *= invg;
+  znv.y *= invg;
+  vnv.x *= invg;
+  vnv.y *= invg;
+  double2 t;
+  t.x = fma(-a2, wv.x, fma(-a3, wov.x, zv.x)) * a1inv;
+  t.y = fma(-a2, wv.y, fma(-a3, wov.y, zv.y)) * a1inv;
+  uv.x = fma(uc, t.x, uv.x);
+  uv.y = fma(uc, t.y, uv.y);
+  st2(zn + i, znv);
+  store2_nt(vn + i, vnv);
+  store2_nt(wn + i, t);
+  store2_nt(u + i, uv);
+}
 
 __device__ __forceinline__ void minres_k5_body(int i, double invg, double a1inv, double a2, double a3, double uc,
                                                 double* zn, double* vn, double* wn, double* u, const double* z,
@@ -265,12 +319,20 @@ __global__ __launch_bounds__(kBlock) void minres_m4_kernel(MK5Args a) {
   const int wg = blockIdx.x;
   if (wg < a.gu) {
     const int i0 = (wg * kBlock + int(threadIdx.x)) * 2;
-    for (int i = i0; i < i0 + 2 && i < a.n_u; ++i)
-      minres_k5_body(i, invg, a1inv, alpha2, alpha3, uc, a.zn0, a.vn0, a.wn0, a.u0, a.z0, a.wo0, a.w0);
+    if (a.vec && i0 + 1 < a.n_u) {
+      minres_k5_body2(i0, invg, a1inv, alpha2, alpha3, uc, a.zn0, a.vn0, a.wn0, a.u0, a.z0, a.wo0, a.w0);
+    } else {
+      for (int i = i0; i < i0 + 2 && i < a.n_u; ++i)
+        minres_k5_body(i, invg, a1inv, alpha2, alpha3, uc, a.zn0, a.vn0, a.wn0, a.u0, a.z0, a.wo0, a.w0);
+    }
   } else {
     const int i0 = ((wg - a.gu) * kBlock + int(threadIdx.x)) * 2;
-    for (int i = i0; i < i0 + 2 && i < a.n_p; ++i)
-      minres_k5_body(i, invg, a1inv, alpha2, alpha3, uc, a.zn1, a.vn1, a.wn1, a.u1, a.z1, a.wo1, a.w1);
+    if (a.vec && i0 + 1 < a.n_p) {
+      minres_k5_body2(i0, invg, a1inv, alpha2, alpha3, uc, a.zn1, a.vn1, a.wn1, a.u1, a.z1, a.wo1, a.w1);
+    } else {
+      for (int i = i0; i < i0 + 2 && i < a.n_p; ++i)
+        minres_k5_body(i, invg, a1inv, alpha2, alpha3, uc, a.zn1, a.vn1, a.wn1, a.u1, a.z1, a.wo1, a.w1);
+    }
   }
 }
 
@@ -278,11 +340,13 @@ static int m_gu(const nss_minres_t& s) { return (s.n_u + kMPerBlock - 1) / kMPer
 static int m_gp(const nss_minres_t& s) { return (s.n_p + kMPerBlock - 1) / kMPerBlock; }
 static int m_dot_grid(const nss_minres_t& s) { return stream_grid(s.n_u, kBlock * 4); }
 
-// block Jacobi that M3 applies itself: runs of consecutive dofs, symmetric inverse blocks, every dof covered
-static bool m_fused_bjac(const nss_minres_t& s) {
+// block Jacobi that M3 can apply itself: runs of consecutive dofs, symmetric inverse blocks, every dof covered
+static bool m_fusable_bjac(const nss_minres_t& s) {
   const nss_bjac_s* j = s.pre_bjac;
   return j != nullptr && !s.pre_amg && !j->gs_mat && j->run != nullptr && j->inv_sym != nullptr && j->n_uncovered == 0;
 }
+static int g_minres_fuse_mode = -1;
+static bool m_fused_bjac(const nss_minres_t& s);
 static int m3_gu(const nss_minres_t& s) {
   return m_fused_bjac(s) ? (s.pre_bjac->nblocks + kBlock - 1) / kBlock : m_gu(s);
 }
@@ -290,11 +354,23 @@ static int m3_partials(const nss_minres_t& s) { return m3_gu(s) + m_gp(s); }
 
 constexpr int kMFoldMax = 4096;
 static int g_minres_fold_mode = -1;
-static bool m_fold(const nss_minres_t& s) {
-  if (g_minres_fold_mode >= 0) return g_minres_fold_mode != 0;
+static bool m_small(const nss_minres_t& s) {       // launch-bound regime: every sum of the iteration is short
   int64_t dotg = m_dot_grid(s);
   if (s.pre_bjac) dotg = std::max<int64_t>(dotg, bjac_dot_grid(*s.pre_bjac));
-  return s.A->nblk + s.B->nblk <= kMFoldMax && m3_partials(s) <= kMFoldMax && dotg <= kMFoldMax;
+  const int64_t m3 = std::max<int64_t>((s.pre_bjac ? (s.pre_bjac->nblocks + kBlock - 1) / kBlock : 0), m_gu(s)) + m_gp(s);
+  return s.A->nblk + s.B->nblk <= kMFoldMax && m3 <= kMFoldMax && dotg <= kMFoldMax;
+}
+static bool m_fold(const nss_minres_t& s) {
+  if (g_minres_fold_mode >= 0) return g_minres_fold_mode != 0;
+  return m_small(s);
+}
+// Fusing the block-Jacobi apply into M3 saves a launch and the re-read of v_new, but turns M3's three
+// input streams into 24-byte-strided per-lane accesses: a win where launches dominate, a loss where
+// bandwidth does (1e7 DoF: -6 %).  Automatic: fuse exactly in the launch-bound regime.
+static bool m_fused_bjac(const nss_minres_t& s) {
+  if (!m_fusable_bjac(s)) return false;
+  if (g_minres_fuse_mode >= 0) return g_minres_fuse_mode != 0;
+  return m_small(s);
 }
 
 static void minres_check(const nss_minres_t* s) {
@@ -340,10 +416,16 @@ static void minres_iteration(const nss_minres_t& s, int k, hipStream_t st) {
   }
   // M3
   const bool fused = m_fused_bjac(s);
+  bool vec = aligned16(s.minv) && (!s.pre_diag || aligned16(s.pre_diag));
+  for (int c = 0; c < 2; ++c) {
+    vec = vec && aligned16(s.u[c]) && aligned16(s.kz[c]) && aligned16(s.z[0][c]) && aligned16(s.z[1][c]);
+    for (int j = 0; j < 3; ++j) vec = vec && aligned16(s.v[j][c]) && aligned16(s.w[j][c]);
+  }
   MK4Args a4{s.ctrl, set, s.n_u, s.n_p, k, s.kz[0], s.kz[1], s.v[ic][0], s.v[ic][1], s.v[io][0], s.v[io][1],
              s.v[in][0], s.v[in][1], s.z[zn][0], s.z[zn][1], (s.pre_amg || s.pre_bjac) ? nullptr : s.pre_diag, s.minv,
              s.partials_c, m3_gu(s), m_gp(s), fold ? 1 : 0, s.A->nblk, s.B->nblk, s.partials_a, s.partials_b,
-             fused ? s.pre_bjac->nblocks : 0, fused ? s.pre_bjac->run : nullptr, fused ? s.pre_bjac->inv_sym : nullptr};
+             fused ? s.pre_bjac->nblocks : 0, fused ? s.pre_bjac->run : nullptr, fused ? s.pre_bjac->inv_sym : nullptr,
+             vec ? 1 : 0};
   const int g3 = a4.gu + a4.gp;
   if (!fused) {
     launch_m3<0>(a4, g3, st);
@@ -385,7 +467,7 @@ static void minres_iteration(const nss_minres_t& s, int k, hipStream_t st) {
   // M4
   MK5Args a5{s.ctrl, s.scal, s.hist, s.n_u, s.n_p, k, s.z[zn][0], s.z[zn][1], s.v[in][0], s.v[in][1], s.w[in][0],
              s.w[in][1], s.u[0], s.u[1], s.z[zc][0], s.z[zc][1], s.w[io][0], s.w[io][1], s.w[ic][0], s.w[ic][1],
-             m_gu(s), fold ? 1 : 0, nb2, g3, s.partials_a, s.partials_c};
+             m_gu(s), fold ? 1 : 0, nb2, g3, s.partials_a, s.partials_c, vec ? 1 : 0};
   hipLaunchKernelGGL(minres_m4_kernel, dim3(m_gu(s) + m_gp(s)), dim3(kBlock), 0, st, a5);
   NSS_CHECK_LAUNCH();
 }
@@ -403,7 +485,9 @@ int nss_minres_workspace(const nss_minres_t* s, int64_t* partials_a, int64_t* pa
     if (s->pre_bjac) dotg = std::max<int64_t>(dotg, bjac_dot_grid(*s->pre_bjac));
     if (partials_a) *partials_a = std::max<int64_t>(s->A->nblk, dotg);
     if (partials_b) *partials_b = s->B->nblk;
-    if (partials_c) *partials_c = m3_partials(*s);
+    // M3 in either form (block Jacobi fused: one lane per block; else two entries per lane)
+    const int64_t gu_fused = s->pre_bjac ? (s->pre_bjac->nblocks + kBlock - 1) / kBlock : 0;
+    if (partials_c) *partials_c = std::max<int64_t>(gu_fused, m_gu(*s)) + m_gp(*s);
   });
 }
 
@@ -419,6 +503,13 @@ int nss_minres_fold_mode(int32_t mode) {
   return guarded([&] {
     NSS_REQUIRE(mode >= -1 && mode <= 1, "minres_fold_mode: -1 (automatic), 0 (never) or 1 (always)");
     g_minres_fold_mode = mode;
+  });
+}
+
+int nss_minres_fuse_mode(int32_t mode) {
+  return guarded([&] {
+    NSS_REQUIRE(mode >= -1 && mode <= 1, "minres_fuse_mode: -1 (automatic), 0 (never) or 1 (always)");
+    g_minres_fuse_mode = mode;
   });
 }
 

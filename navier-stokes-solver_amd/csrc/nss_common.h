@@ -106,6 +106,9 @@ __device__ __forceinline__ void store2_nt(double* p, const double2& v) {
   __builtin_nontemporal_store(t, reinterpret_cast<dbl2v*>(p));
 }
 
+__device__ __forceinline__ double2 ld2(const double* p) { return *reinterpret_cast<const double2*>(p); }
+__device__ __forceinline__ void st2(double* p, const double2& v) { *reinterpret_cast<double2*>(p) = v; }
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // ---- device-side reductions -------------------------------------------------------

@@ -459,6 +459,37 @@ def test_compact_plan_equals_eight_phase_form_bit_for_bit(hip_engine, case):
         lib.nss_bpcg2_fold_mode(-1)
 
 
+@pytest.mark.parametrize("case", ["stokes3d_n10_bjac_minres", "stokes2d_n24_jacobi_minres",
+                                  "stokes3d_n5_facet_x12_minres"])
+def test_minres_sum_placement_gives_identical_bits(hip_engine, case):
+    """The fused MINRES loop evaluates its two dot-product sums either inside the consuming kernels
+    (short sums: the launch-bound small systems) or in a stand-alone kernel (long sums) -- the same
+    reduction tree, so errors and solution agree bit for bit; and both match the golden."""
+    import hipla
+    from minres import MinRes
+    d = np.load(golden_path(case))
+    c, _, A, B, preA, preS = case_operands(d)
+    K = hipla.BlockMatrix([[A, B.T], [B, None]])
+    Cm = hipla.BlockMatrix([[preA, None], [None, preS]])
+    lib = hip_engine.lib
+    outs = []
+    try:
+        for mode in (1, 0):
+            assert lib.nss_minres_fold_mode(mode) == 0
+            with contextlib.redirect_stdout(io.StringIO()), fused_loops_counted() as counts:
+                u, errors = MinRes(mat=K, pre=Cm, rhs=hipla.BlockVector([hipla.Vector.from_numpy(c.f),
+                                                                         hipla.Vector.from_numpy(c.g)]),
+                                   maxsteps=int(d["maxsteps"]), tol=float(d["tol"]), printrates=False)
+            assert counts["minres"] == 1
+            outs.append((np.array(errors), u.numpy()))
+    finally:
+        lib.nss_minres_fold_mode(-1)
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+    check_history(outs[0][0], d["errors"], d["window"])
+    check_iterations(len(outs[0][0]) - 1, d["iterations"], d)
+
+
 def test_drivers_on_gpu(hip_engine, tmp_path):
     """Harness / driver shape on the product engine: NavierStokes.SolveInitial takes the fused
     loop, run.py writes the reference's CSV columns, stokes_hcurldiv's call converges."""
