@@ -70,6 +70,11 @@ NSS_API int nss_dot_host_f64(int32_t npairs, const int64_t* h_n, const double* c
  * reference is single-process).  idx is a DEVICE int32 array. */
 NSS_API int nss_gather_f64(int64_t n, const int32_t* idx, const double* src, double* dst,
                            nss_stream_t stream);
+/* flux[i] = adv[i] * avg[i] - 1/2 |adv[i]| * diff[i]: the donor-cell (upwind) numerical flux of the explicit
+ * convection term of the IMEX step (templates/NavierStokesSIMPLE_iterative.py:106-113,427-431: `conv_operator *
+ * gfu`), between the SpMVs that form adv / avg / diff and the one that takes the divergence. */
+NSS_API int nss_upwind_flux_f64(int64_t n, const double* adv, const double* avg, const double* diff, double* flux,
+                                nss_stream_t stream);
 /* z = x + a*y : STREAM-triad, the roofline denominator measured in the same run
  *  */
 NSS_API int nss_stream_triad_f64(int64_t n, double a, const double* x, const double* y,
@@ -196,6 +201,14 @@ typedef struct nss_amg_level_s {
 typedef struct nss_amg_s* nss_amg_t;
 NSS_API int nss_amg_create(int32_t nlevels, const nss_amg_level_t* h_levels, nss_csr_t coarse_inverse,
                            double omega, nss_amg_t* out);
+/* Auxiliary-space preconditioner term  x -> T (sum_c E_c V_c E_c^T) T^T x  as an nss_amg_t: the
+ * `transform @ preAh1 @ transform.T` of the reference's MypreA
+ * (templates/NavierStokesSIMPLE_iterative.py:291,320-357,380,383).  T (rows: velocity dofs, columns: the
+ * stacked per-component auxiliary spaces) and its explicit transpose TT; comps[c] = V-cycle handle of
+ * component c's auxiliary operator (nss_amg_create), sizes adding up to the columns of T.  Accepted
+ * wherever a V-cycle handle is (nss_amg_apply_f64, pre_amg of the fused loops). */
+NSS_API int nss_amg_create_auxiliary(nss_csr_t T, nss_csr_t TT, int32_t ncomp, const nss_amg_t* h_comps,
+                                     nss_amg_t* out);
 NSS_API int nss_amg_destroy(nss_amg_t a);
 /* x = V(bscale * b);  b and x have the finest level's size and must not alias */
 NSS_API int nss_amg_apply_f64(nss_amg_t a, double bscale, const double* b, double* x, nss_stream_t stream);

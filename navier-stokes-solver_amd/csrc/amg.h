@@ -21,11 +21,21 @@ struct nss_amg_s {
   std::vector<nss::AmgLevel> levels;
   const nss_csr_s* coarse_inverse = nullptr;
   double omega = 2.0 / 3.0;
+  // Auxiliary-space mode (nss_amg_create_auxiliary): x -> T (sum_c E_c V_c E_c^T) T^T x, the term
+  // `transform @ preAh1 @ transform.T` of the reference's MypreA
+  // (templates/NavierStokesSIMPLE_iterative.py:291,320-357,380,383): T maps the auxiliary space (one
+  // P1-like scalar space per velocity component, stacked) to the velocity dofs, V_c is the V-cycle of
+  // component c's Laplacian.  levels[0].n = rows of T, so the fused loops' size checks hold.
+  const nss_csr_s* T = nullptr;
+  const nss_csr_s* TT = nullptr;
+  std::vector<const nss_amg_s*> comps;
+  std::vector<int32_t> comp_off;     // comps.size() + 1 offsets into the stacked auxiliary vector
+  double *aux_r = nullptr, *aux_z = nullptr;
 };
 
 namespace nss {
 // x = V(bscale * b); every kernel of the cycle returns at once when `done` (device int, may be NULL)
-// is non-zero: a solver that has stopped leaves x untouched
+// is non-zero: a solver that has stopped leaves x untouched.  `accumulate`: x += V(bscale * b).
 void amg_apply(const nss_amg_s& a, double bscale, const double* b, double* x, hipStream_t st,
-               const int32_t* done = nullptr);
+               const int32_t* done = nullptr, bool accumulate = false);
 }  // namespace nss

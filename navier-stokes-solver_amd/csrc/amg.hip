@@ -28,7 +28,7 @@ struct EpiResidual {   // r = b - A x
   __device__ void finish(int, double*) const {}
 };
 
-struct EpiJacobi {     // y = scale * (x + w dinv (b - A x))
+struct EpiJacobi {     // y (+)= scale * (x + w dinv (b - A x))
   const double* __restrict__ b;
   const double* __restrict__ x;
   const double* __restrict__ dinv;
@@ -36,10 +36,14 @@ struct EpiJacobi {     // y = scale * (x + w dinv (b - A x))
   double w;
   double scale;
   const int32_t* __restrict__ done;
+  bool accumulate = false;
   __device__ bool skip() const { return done != nullptr && *done != 0; }
-  struct Pre { double b = 0.0, x = 0.0, dinv = 0.0; };
-  __device__ Pre fetch(int i) const { return Pre{b[i], x[i], dinv[i]}; }
-  __device__ void row(int i, double ax, const Pre& p) const { y[i] = scale * fma(w * p.dinv, p.b - ax, p.x); }
+  struct Pre { double b = 0.0, x = 0.0, dinv = 0.0, y = 0.0; };
+  __device__ Pre fetch(int i) const { return Pre{b[i], x[i], dinv[i], accumulate ? y[i] : 0.0}; }
+  __device__ void row(int i, double ax, const Pre& p) const {
+    const double t = scale * fma(w * p.dinv, p.b - ax, p.x);
+    y[i] = accumulate ? p.y + t : t;
+  }
   __device__ void finish(int, double*) const {}
 };
 
@@ -55,10 +59,10 @@ __global__ __launch_bounds__(kBlock) void amg_diag_kernel(int32_t n, double s, c
 // out = scale * V_l(b); the cycle is linear, so the scale factor of the outermost call (preA = k V)
 // rides in the last kernel instead of a pass over the right-hand side
 static void cycle(const nss_amg_s& a, int l, const double* b, double* out, hipStream_t st, const int32_t* done,
-                  double scale = 1.0) {
+                  double scale = 1.0, bool accumulate = false) {
   const AmgLevel& lv = a.levels[l];
   if (l == int(a.levels.size()) - 1) {
-    launch_csr_stream(*a.coarse_inverse, b, EpiAxpby{scale, 0.0, out, done}, st);   // x = A^-1 b
+    launch_csr_stream(*a.coarse_inverse, b, EpiAxpby{scale, accumulate ? 1.0 : 0.0, out, done}, st);   // x = A^-1 b
     return;
   }
   const int n = lv.n;
@@ -70,11 +74,19 @@ static void cycle(const nss_amg_s& a, int l, const double* b, double* out, hipSt
   launch_csr_stream(*lv.R, lv.r, EpiAxpby{1.0, 0.0, next.b, done}, st);
   cycle(a, l + 1, next.b, next.y, st, done);
   launch_csr_stream(*lv.P, next.y, EpiAxpby{1.0, 1.0, lv.x, done}, st);
-  launch_csr_stream(*lv.A, lv.x, EpiJacobi{b, lv.x, lv.dinv, out, a.omega, scale, done}, st);
+  launch_csr_stream(*lv.A, lv.x, EpiJacobi{b, lv.x, lv.dinv, out, a.omega, scale, done, accumulate}, st);
 }
 
-void amg_apply(const nss_amg_s& a, double bscale, const double* b, double* x, hipStream_t st, const int32_t* done) {
-  cycle(a, 0, b, x, st, done, bscale);
+void amg_apply(const nss_amg_s& a, double bscale, const double* b, double* x, hipStream_t st, const int32_t* done,
+               bool accumulate) {
+  if (a.T) {                                         // auxiliary-space mode: x (+)= T (sum_c V_c) T^T (bscale b)
+    launch_csr_stream(*a.TT, b, EpiAxpby{bscale, 0.0, a.aux_r, done}, st);
+    for (size_t c = 0; c < a.comps.size(); ++c)
+      cycle(*a.comps[c], 0, a.aux_r + a.comp_off[c], a.aux_z + a.comp_off[c], st, done, 1.0);
+    launch_csr_stream(*a.T, a.aux_z, EpiAxpby{1.0, accumulate ? 1.0 : 0.0, x, done}, st);
+    return;
+  }
+  cycle(a, 0, b, x, st, done, bscale, accumulate);
 }
 
 }  // namespace nss
@@ -127,9 +139,44 @@ int nss_amg_create(int32_t nlevels, const nss_amg_level_t* h_levels, nss_csr_t c
   });
 }
 
+int nss_amg_create_auxiliary(nss_csr_t T, nss_csr_t TT, int32_t ncomp, const nss_amg_t* h_comps, nss_amg_t* out) {
+  return guarded([&] {
+    NSS_REQUIRE(out && T && TT && h_comps, "amg_create_auxiliary: NULL argument");
+    NSS_REQUIRE(ncomp >= 1 && ncomp <= 16, "amg_create_auxiliary: 1 <= ncomp <= 16");
+    NSS_REQUIRE(TT->m == T->n && TT->n == T->m, "amg_create_auxiliary: TT is not the transpose shape of T");
+    nss_amg_s* a = new nss_amg_s;
+    try {
+      a->T = T;
+      a->TT = TT;
+      int64_t off = 0;
+      a->comp_off.push_back(0);
+      for (int c = 0; c < ncomp; ++c) {
+        NSS_REQUIRE(h_comps[c] != nullptr && h_comps[c]->T == nullptr && !h_comps[c]->levels.empty(),
+                    "amg_create_auxiliary: components must be plain V-cycle handles");
+        a->comps.push_back(h_comps[c]);
+        off += h_comps[c]->levels[0].n;
+        a->comp_off.push_back(int32_t(off));
+      }
+      NSS_REQUIRE(off == T->n, "amg_create_auxiliary: component sizes do not add up to the columns of T");
+      AmgLevel lv;
+      lv.n = T->m;
+      a->levels.push_back(lv);
+      const size_t bytes = sizeof(double) * size_t(std::max<int64_t>(1, off));
+      NSS_HIP(hipMalloc(&a->aux_r, bytes));
+      NSS_HIP(hipMalloc(&a->aux_z, bytes));
+    } catch (...) {
+      nss_amg_destroy(a);
+      throw;
+    }
+    *out = a;
+  });
+}
+
 int nss_amg_destroy(nss_amg_t a) {
   return guarded([&] {
     if (!a) return;
+    (void)hipFree(a->aux_r);
+    (void)hipFree(a->aux_z);
     for (auto& lv : a->levels) {
       (void)hipFree(lv.x);
       (void)hipFree(lv.r);

@@ -143,6 +143,17 @@ __global__ __launch_bounds__(kBlock) void diag_kernel(int64_t n, const double* _
   }
 }
 
+// donor-cell flux of the explicit convection term: f = adv * avg - 1/2 |adv| * diff
+__global__ __launch_bounds__(kBlock) void upwind_flux_kernel(int64_t n, const double* __restrict__ adv,
+                                                              const double* __restrict__ avg,
+                                                              const double* __restrict__ diff, double* __restrict__ f) {
+  const int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+  if (i < n) {
+    const double a = adv[i];
+    f[i] = fma(a, avg[i], -0.5 * (fabs(a) * diff[i]));
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void gather_kernel(int64_t n, const int32_t* __restrict__ idx,
                                                          const double* __restrict__ src, double* __restrict__ dst) {
   const int64_t stride = int64_t(gridDim.x) * kBlock;
@@ -359,6 +370,17 @@ int nss_gather_f64(int64_t n, const int32_t* idx, const double* src, double* dst
     if (n <= 0) return;
     hipLaunchKernelGGL(gather_kernel, dim3(stream_grid(n, kBlock)), dim3(kBlock), 0, as_stream(stream), n, idx, src,
                        dst);
+    NSS_CHECK_LAUNCH();
+  });
+}
+
+int nss_upwind_flux_f64(int64_t n, const double* adv, const double* avg, const double* diff, double* flux,
+                        nss_stream_t stream) {
+  return guarded([&] {
+    if (n <= 0) return;
+    NSS_REQUIRE(adv && avg && diff && flux, "upwind_flux: NULL argument");
+    hipLaunchKernelGGL(upwind_flux_kernel, dim3(unsigned((n + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                       as_stream(stream), n, adv, avg, diff, flux);
     NSS_CHECK_LAUNCH();
   });
 }

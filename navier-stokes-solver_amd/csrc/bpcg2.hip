@@ -127,6 +127,26 @@ struct EpiK2 {
   }
 };
 
+// r = scale * x - A y  (multiplicative MypreA: residual between the two sweeps, :379)
+struct EpiScaledResidual {
+  const int32_t* __restrict__ ctrl;
+  double scale;
+  const double* __restrict__ x;
+  double* __restrict__ r;
+  __device__ bool skip() const { return ctrl[C_DONE] != 0; }
+  struct Pre { double x = 0.0; };
+  __device__ Pre fetch(int i) const { return Pre{x[i]}; }
+  __device__ void row(int i, double ay, const Pre& p) const { r[i] = fma(scale, p.x, -ay); }
+  __device__ void finish(int, double*) const {}
+};
+
+__global__ __launch_bounds__(kBlock) void bpcg2_zero_kernel(const int32_t* __restrict__ ctrl, int32_t n,
+                                                             double* __restrict__ y) {
+  if (ctrl[C_DONE] != 0) return;
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) y[i] = 0.0;
+}
+
 // condensed form: f = t0 + H^T t0
 struct EpiLift {
   const int32_t* __restrict__ ctrl;
@@ -569,7 +589,11 @@ void bpcg2_check_state(const nss_bpcg2_t* s) {
   NSS_REQUIRE(!(s->pre_diag && s->pre_bjac), "bpcg2: pre_diag and pre_bjac are exclusive");
   NSS_REQUIRE(s->pre_diag || s->pre_bjac || s->pre_amg, "bpcg2: no preconditioner for the velocity block");
   NSS_REQUIRE(!s->pre_amg || s->pre_amg->levels[0].n == s->n_u, "bpcg2: AMG size mismatch");
-  NSS_REQUIRE(!(s->pre_amg && s->pre_bjac && s->pre_bjac->gs_mat), "bpcg2: AMG + Gauss-Seidel mode is not additive");
+  // AMG (or auxiliary-space) term + a block-Jacobi handle in Gauss-Seidel mode = the MULTIPLICATIVE MypreA
+  // (GS=True, :376-381): sweep, residual, correction, back sweep.  Not with the condensed form.
+  NSS_REQUIRE(!(s->pre_amg && s->pre_bjac && s->pre_bjac->gs_mat && (s->cond_HT || s->pre_diag)),
+              "bpcg2: the multiplicative preconditioner (Gauss-Seidel sweeps around an AMG term) takes neither a "
+              "condensed form nor a point-Jacobi part");
   NSS_REQUIRE(!s->pre_bjac || s->pre_bjac->n == s->n_u, "bpcg2: block-Jacobi size mismatch");
   NSS_REQUIRE(s->minv && s->scal && s->ctrl && s->hist && s->partials_a && s->partials_b && s->partials_c,
               "bpcg2: NULL work buffer");
@@ -627,7 +651,17 @@ void bpcg2_k1_finish(const nss_bpcg2_t& s, hipStream_t st) {
     src = s.cond_f;
   }
   auto diag = [&](double beta) { diag_apply(s.n_u, s.pre_diag, s.k, src, beta, s.t1, s.ctrl, st); };
-  if (s.pre_amg) {
+  if (s.pre_amg && s.pre_bjac && s.pre_bjac->gs_mat) {
+    // multiplicative MypreA (GS=True, :376-381) applied to k * t0:
+    //   y = 0; J.Smooth(y, x); r = x - A y; y += M r; J.SmoothBack(y, x)        (t2 is free here: the
+    //   previous iteration's t2 was consumed by K1 / C1 and the A-SpMV has not written the new one yet)
+    hipLaunchKernelGGL(bpcg2_zero_kernel, dim3((s.n_u + kBlock - 1) / kBlock), dim3(kBlock), 0, st, s.ctrl, s.n_u, s.t1);
+    NSS_CHECK_LAUNCH();
+    bjac_smooth(*s.pre_bjac, s.k, src, s.t1, false, s.ctrl, st);
+    launch_csr_stream(*s.A, s.t1, EpiScaledResidual{s.ctrl, s.k, src, s.t2}, st);
+    amg_apply(*s.pre_amg, 1.0, s.t2, s.t1, st, s.ctrl, true);
+    bjac_smooth(*s.pre_bjac, s.k, src, s.t1, true, s.ctrl, st);
+  } else if (s.pre_amg) {
     amg_apply(*s.pre_amg, s.k, src, s.t1, st, s.ctrl);
     if (s.pre_bjac) bjac_apply(*s.pre_bjac, s.k, src, 1.0, s.t1, s.ctrl, st);
     if (s.pre_diag) diag(1.0);

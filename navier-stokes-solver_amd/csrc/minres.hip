@@ -350,7 +350,6 @@ static bool m_fused_bjac(const nss_minres_t& s);
 static int m3_gu(const nss_minres_t& s) {
   return m_fused_bjac(s) ? (s.pre_bjac->nblocks + kBlock - 1) / kBlock : m_gu(s);
 }
-static int m3_partials(const nss_minres_t& s) { return m3_gu(s) + m_gp(s); }
 
 constexpr int kMFoldMax = 4096;
 static int g_minres_fold_mode = -1;

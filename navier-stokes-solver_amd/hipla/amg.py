@@ -117,3 +117,31 @@ class SmoothedAggregationAMG(BaseMatrix):
     @property
     def T(self):
         return self
+
+
+class AuxiliarySpaceAMG(SmoothedAggregationAMG):
+    """``y = T (sum_c E_c V_c E_c^T) T^T x`` -- the auxiliary-space term of the reference's ``MypreA``,
+    ``transform @ preAh1 @ transform.T`` with ``preAh1 = sum_c emb_c @ Preconditioner(aH1_c, 'h1amg') @
+    emb_c.T`` (templates/NavierStokesSIMPLE_iterative.py:291,320-357,380,383).
+
+    `transform`: `SparseMatrix` (velocity dofs x stacked auxiliary dofs); `components`: one
+    `SmoothedAggregationAMG` per velocity component, built on that component's auxiliary Laplacian, in
+    the order in which their spaces are stacked.  One native handle (``nss_amg_create_auxiliary``): the
+    fused Krylov loops apply it wherever they accept a V-cycle, alone or added to a (block) Jacobi
+    (the additive ``MypreA``, :383)."""
+
+    def __init__(self, transform, components):
+        BaseMatrix.__init__(self)
+        if not isinstance(transform, SparseMatrix) or not all(type(c) is SmoothedAggregationAMG for c in components):
+            raise TypeError("AuxiliarySpaceAMG needs a SparseMatrix transform and plain V-cycles")
+        if sum(c.n for c in components) != transform.width:
+            raise ValueError("component sizes do not add up to the columns of the transform")
+        self.engine = transform.engine
+        self.transform, self.components = transform, list(components)
+        self.transform_t = transform.CreateTranspose()
+        self.n = transform.height
+        self.mat = None
+        self.levels = []
+        self.level_sizes = [c.level_sizes for c in components]
+        self.handle = self.engine.amg_create_auxiliary(transform.handle, self.transform_t.handle,
+                                                       [c.handle for c in components])

@@ -94,7 +94,12 @@ def native_velocity_pre(op):
         if op.sb != 1.0:
             return None
         parts = [op.a, op.b]
-    out = {"scale": scale, "amg": None, "diag": None, "bjac": None}
+    out = {"scale": scale, "amg": None, "diag": None, "bjac": None, "multiplicative": False}
+    if (len(parts) == 1 and isinstance(op, BlockGaussSeidel) and isinstance(op.middle, SmoothedAggregationAMG)):
+        # the multiplicative MypreA (GS=True, :376-381): sweep, residual, (auxiliary-space) AMG correction,
+        # back sweep -- composed natively by the fused BPCG loop
+        out.update(bjac=op, amg=op.middle, multiplicative=True)
+        return out
     for part in parts:
         if isinstance(part, SmoothedAggregationAMG) and out["amg"] is None:
             out["amg"] = part
@@ -114,7 +119,7 @@ def _amg_plus_jacobi(op):
     """(amg, (1.0, diag) | None, (1.0, bjac) | None) when `op` is an unscaled AMG V-cycle, optionally
     plus a point / block Jacobi (the additive MypreA); (None, None, None) otherwise."""
     parts = native_velocity_pre(op)
-    if parts is None or parts["amg"] is None or parts["scale"] != 1.0:
+    if parts is None or parts["amg"] is None or parts["scale"] != 1.0 or parts["multiplicative"]:
         return None, None, None
     diag = (1.0, parts["diag"]) if parts["diag"] is not None else None
     bjac = (1.0, parts["bjac"]) if parts["bjac"] is not None else None
@@ -158,6 +163,8 @@ class Bpcg2Loop:
         pa = native_velocity_pre(preA_unscaled)
         if pm is None or pa is None:
             return None
+        if pa["multiplicative"] and (condensed is not None or distributed or pa["bjac"].mat is not matA):
+            return None                  # the sweeps' residual is formed with the loop's own A
         sizes = {"u0": n_u, "d0": n_u, "w0": n_u, "s0": n_u, "z0": n_u, "q": n_u, "t0": n_u, "t1": n_u,
                  "t2": n_u, "t4": n_u, "u1": n_p, "d1": n_p, "w1": n_p, "s1": n_p, "t3": n_p}
         if any(not _plain(vecs.get(name), n) for name, n in sizes.items()):

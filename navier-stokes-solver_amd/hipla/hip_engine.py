@@ -40,6 +40,7 @@ def _signatures():
         "nss_dot_host_f64": (C.c_int, [i32, c_i64_p, C.POINTER(vp), C.POINTER(vp), c_double_p, vp]),
         "nss_stream_triad_f64": (C.c_int, [i64, dbl, vp, vp, vp, vp]),
         "nss_gather_f64": (C.c_int, [i64, vp, vp, vp, vp]),
+        "nss_upwind_flux_f64": (C.c_int, [i64, vp, vp, vp, vp, vp]),
         "nss_csr_create": (C.c_int, [i32, i32, i64, vp, vp, vp, C.POINTER(vp)]),
         "nss_csr_transpose": (C.c_int, [vp, C.POINTER(vp)]),
         "nss_csr_spgemm": (C.c_int, [vp, vp, i64, C.POINTER(vp), vp]),
@@ -70,6 +71,7 @@ def _signatures():
         "nss_bjac_smooth_f64": (C.c_int, [vp, dbl, vp, vp, i32, vp]),
         "nss_bjac_symgs_apply_f64": (C.c_int, [vp, dbl, vp, vp, vp]),
         "nss_amg_create": (C.c_int, [i32, vp, vp, dbl, C.POINTER(vp)]),
+        "nss_amg_create_auxiliary": (C.c_int, [vp, vp, i32, C.POINTER(vp), C.POINTER(vp)]),
         "nss_amg_destroy": (C.c_int, [vp]),
         "nss_amg_apply_f64": (C.c_int, [vp, dbl, vp, vp, vp]),
         "nss_cg_workspace": (C.c_int, [vp, c_i64_p, c_i64_p]),
@@ -424,6 +426,17 @@ class HipEngine:
         out = C.c_void_p()
         self._check(self.lib.nss_amg_create(len(levels), arr, levels[-1]["inv"].handle.ptr, float(omega), C.byref(out)))
         return _AmgHandle(self, out, levels)
+
+    def upwind_flux(self, adv, avg, diff, out):
+        self._check(self.lib.nss_upwind_flux_f64(adv.shape[0], adv.data_ptr(), avg.data_ptr(), diff.data_ptr(),
+                                                 out.data_ptr(), self.stream))
+
+    def amg_create_auxiliary(self, T, TT, comps):
+        """`nss_amg_create_auxiliary`: T / TT are `_CsrHandle`s, `comps` V-cycle handles."""
+        arr = (C.c_void_p * len(comps))(*[c.ptr for c in comps])
+        out = C.c_void_p()
+        self._check(self.lib.nss_amg_create_auxiliary(T.ptr, TT.ptr, len(comps), arr, C.byref(out)))
+        return _AmgHandle(self, out, (T, TT, list(comps)))
 
     def amg_apply(self, h, bscale, b, x):
         self._check(self.lib.nss_amg_apply_f64(h.ptr, float(bscale), b.data_ptr(), x.data_ptr(), self.stream))

@@ -791,6 +791,43 @@ class CGSolver(BaseMatrix):
         return self
 
 
+class Embedding(BaseMatrix):
+    """``Embedding(height, range)``: places a vector of ``len(range)`` entries at rows
+    ``range.start .. range.stop`` of a zero vector of ``height`` entries; ``.T`` restricts.  The reference
+    stacks the per-component auxiliary preconditioners with it
+    (templates/NavierStokesSIMPLE_iterative.py:334-337,353-357)."""
+
+    def __init__(self, height, rng):
+        super().__init__()
+        self.h = int(height)
+        self.start, self.stop = int(rng.start), int(rng.stop)
+        if not 0 <= self.start <= self.stop <= self.h:
+            raise ValueError("Embedding: range outside the target")
+
+    def Height(self):
+        return self.h
+
+    def Width(self):
+        return self.stop - self.start
+
+    def _piece(self, v):
+        from .vector import Vector
+        return Vector(buf=v.engine.view(v.buf, self.start, self.stop), engine=v.engine, comm=getattr(v, "comm", None))
+
+    def MultAdd(self, s, x, y):
+        self._piece(y).data += s * x
+
+    def Mult(self, x, y):
+        y[:] = 0.0
+        self._piece(y).data = x
+
+    def MultTransAdd(self, s, x, y):
+        y.data += s * self._piece(x)
+
+    def MultTrans(self, x, y):
+        y.data = self._piece(x)
+
+
 class Projector(BaseMatrix):
     """``Projector(mask, range)``: keeps entries where ``mask == range``."""
 

@@ -154,6 +154,195 @@ class StokesSystem:
         out.velocity_permutation = perm
         return out
 
+    def convection_operators(self):
+        """Sparse operators of the explicit convection term of the IMEX step
+        (templates/NavierStokesSIMPLE_iterative.py:106-113,403,427-431: ``conv_operator * gfu`` = the weak
+        form of -div(u (x) u) with upwind numerical fluxes) restated on the staggered grid: conservative
+        donor-cell (first-order upwind) fluxes of every velocity component c through the faces of its
+        control volume in every direction d,
+
+            F = adv * avg - 1/2 |adv| * diff,      conv(u) = - D F,
+
+        with adv = (I_adv u) the advecting velocity at the flux point, avg = (Avg u), diff = (Diff u) the
+        mean and the jump of the transported component across it, and D the (cell-volume-integrated)
+        divergence of the fluxes; wall fluxes vanish (no-slip).  Returns dict(adv, avg, diff, div) of CSR
+        matrices (flux points x n_u, n_u x flux points).  In an inflated system every one of the
+        `block_size` copies of the field is advected by itself (operators (x) I)."""
+        dim, n = self.dim, self.n
+        hface = self.h ** (dim - 1)
+        rows_a, cols_a, vals_a = [], [], []        # I_adv
+        rows_m, cols_m, vals_m = [], [], []        # Avg
+        rows_j, cols_j, vals_j = [], [], []        # Diff
+        rows_d, cols_d, vals_d = [], [], []        # D
+        nflux = 0
+
+        def sl(ax, a, b):
+            out = [slice(None)] * dim
+            out[ax] = slice(a, b)
+            return tuple(out)
+
+        for c, g in enumerate(self.component_ids):
+            axc = _axis_of_component(dim, c)
+            for axd in range(dim):
+                if axd == axc:
+                    # flux points = the n cell centres along the normal axis; faces -1 and n-1 are walls
+                    shape = list(g.shape)
+                    shape[axc] = n
+                    fid = nflux + np.arange(int(np.prod(shape)), dtype=np.int64).reshape(shape)
+                    nflux += fid.size
+                    lo_f, lo_u = fid[sl(axc, 1, n)], g                        # cell i >= 1: lower face i - 1
+                    hi_f, hi_u = fid[sl(axc, 0, n - 1)], g                    # cell i <= n-2: upper face i
+                    for f_, u_, w_avg, w_diff in ((lo_f, lo_u, 0.5, -1.0), (hi_f, hi_u, 0.5, 1.0)):
+                        rows_a.append(f_.ravel()); cols_a.append(u_.ravel()); vals_a.append(np.full(u_.size, 0.5))
+                        rows_m.append(f_.ravel()); cols_m.append(u_.ravel()); vals_m.append(np.full(u_.size, w_avg))
+                        rows_j.append(f_.ravel()); cols_j.append(u_.ravel()); vals_j.append(np.full(u_.size, w_diff))
+                    # face m gets (F_{m+1} - F_m) h^(d-1)
+                    rows_d += [g.ravel(), g.ravel()]
+                    cols_d += [fid[sl(axc, 1, n)].ravel(), fid[sl(axc, 0, n - 1)].ravel()]
+                    vals_d += [np.full(g.size, hface), np.full(g.size, -hface)]
+                else:
+                    # flux points between cells j-1 | j along axd, j = 1 .. n-1 (walls carry no flux)
+                    shape = list(g.shape)
+                    shape[axd] = n - 1
+                    fid = nflux + np.arange(int(np.prod(shape)), dtype=np.int64).reshape(shape)
+                    nflux += fid.size
+                    u_lo, u_hi = g[sl(axd, 0, n - 1)], g[sl(axd, 1, n)]
+                    for u_, w_avg, w_diff in ((u_lo, 0.5, -1.0), (u_hi, 0.5, 1.0)):
+                        rows_m.append(fid.ravel()); cols_m.append(u_.ravel()); vals_m.append(np.full(u_.size, w_avg))
+                        rows_j.append(fid.ravel()); cols_j.append(u_.ravel()); vals_j.append(np.full(u_.size, w_diff))
+                    # advecting component e (normal to axd) at face j-1, mean over the cells m, m+1 along axc
+                    e = next(k for k in range(dim) if _axis_of_component(dim, k) == axd)
+                    ge = self.component_ids[e]
+                    for part in (ge[sl(axc, 0, n - 1)], ge[sl(axc, 1, n)]):
+                        rows_a.append(fid.ravel()); cols_a.append(part.ravel()); vals_a.append(np.full(part.size, 0.5))
+                    # dof (m, j) gets (F_{j+1} - F_j) h^(d-1); F_0 = F_n = 0
+                    rows_d += [g[sl(axd, 0, n - 1)].ravel(), g[sl(axd, 1, n)].ravel()]
+                    cols_d += [fid.ravel(), fid.ravel()]
+                    vals_d += [np.full(fid.size, hface), np.full(fid.size, -hface)]
+
+        def csr(rows, cols, vals, shape):
+            m = sp.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=shape).tocsr()
+            m.sort_indices()
+            return m
+
+        n0 = self.n_u // self.block_size
+        ops = {"adv": csr(rows_a, cols_a, vals_a, (nflux, n0)), "avg": csr(rows_m, cols_m, vals_m, (nflux, n0)),
+               "diff": csr(rows_j, cols_j, vals_j, (nflux, n0)), "div": csr(rows_d, cols_d, vals_d, (n0, nflux))}
+        if self.block_size > 1:
+            eye = sp.identity(self.block_size, format="csr")
+            for key in ops:
+                ops[key] = sp.kron(ops[key], eye, format="csr")
+                ops[key].sort_indices()
+        return ops
+
+    def convection_reference(self, u):
+        """conv(u) by direct loops over the grid (small plain cases; the check of `convection_operators`)."""
+        if self.block_size != 1:
+            raise ValueError("convection_reference: plain (not inflated) systems only")
+        dim, n = self.dim, self.n
+        hface = self.h ** (dim - 1)
+        out = np.zeros(self.n_u)
+        comps = self.component_ids
+        axes = [_axis_of_component(dim, c) for c in range(dim)]
+
+        def val(c, idx):                                   # u_c at face multi-index idx, 0 outside (walls)
+            g = comps[c]
+            if any(i < 0 or i >= g.shape[a] for a, i in enumerate(idx)):
+                return 0.0
+            return u[g[tuple(idx)]]
+
+        for c, g in enumerate(comps):
+            axc = axes[c]
+            for idx in np.ndindex(*g.shape):
+                total = 0.0
+                for axd in range(dim):
+                    for side in (1, -1):                   # upper / lower face of the control volume along axd
+                        nb = list(idx)
+                        nb[axd] += side
+                        lo, hi = (idx, nb) if side == 1 else (nb, idx)
+                        u_lo, u_hi = val(c, lo), val(c, hi)
+                        if axd == axc:
+                            adv = 0.5 * (u_lo + u_hi)
+                        else:
+                            e = axes.index(axd)
+                            j = idx[axd] + (1 if side == 1 else 0)        # flux point between cells j-1 | j
+                            if j <= 0 or j >= n:
+                                continue                   # wall: no flux
+                            ie = [0] * dim
+                            for a in range(dim):
+                                ie[a] = idx[a]
+                            ie[axd] = j - 1
+                            i2 = list(ie)
+                            ie[axc], i2[axc] = idx[axc], idx[axc] + 1
+                            adv = 0.5 * (val(e, ie) + val(e, i2))
+                        flux = adv * 0.5 * (u_lo + u_hi) - 0.5 * abs(adv) * (u_hi - u_lo)
+                        total += side * flux
+                out[g[idx]] = -hface * total
+        return out
+
+    def auxiliary_space(self):
+        """The auxiliary space of the reference's ``MypreA`` restated on the grid
+        (templates/NavierStokesSIMPLE_iterative.py:150-157,208-357): one P1-like *nodal* scalar space
+        per velocity component on the (n+1)^d grid vertices with homogeneous Dirichlet data on the walls
+        (``fesh1_c``), the component's ``nu``-scaled 5-/7-point Laplacian on it (``aH1_c``, :322-351) and
+        the ``transform`` that carries nodal vector fields to the face unknowns (:291; there a facet-wise
+        L2 projection ``einv @ amixed``, here the average of the component over the 2^(d-1) vertices of
+        the face).  For an inflated system every nodal unknown carries the `block_size` copies of its
+        site (operator ``L_c (x) S``, transform ``T (x) I``).
+
+        Returns dict(transform = CSR n_u x sum_c n_c, laplacians = [CSR per component],
+        ranges = [range per component in the stacked auxiliary vector])."""
+        dim, n, b = self.dim, self.n, self.block_size
+        m = n - 1                                           # interior vertices per direction
+        nodes = np.arange(m ** dim, dtype=np.int64).reshape((m,) * dim)
+        ca = self.nu * self.h ** (dim - 2)
+        one = sp.identity(m, format="csr")
+        lap1 = sp.diags([-1.0, 2.0, -1.0], [-1, 0, 1], shape=(m, m), format="csr")
+        lap = None
+        for ax in range(dim):
+            term = None
+            for k in range(dim):
+                f = lap1 if k == ax else one
+                term = f if term is None else sp.kron(term, f, format="csr")
+            lap = term if lap is None else lap + term
+        lap = (ca * lap).tocsr()
+        blocks, lapl, ranges = [], [], []
+        off = 0
+        n_nodes = m ** dim
+        for c, g in enumerate(self.component_ids):
+            normal = _axis_of_component(dim, c)
+            rows, cols = [], []
+            tang = [ax for ax in range(dim) if ax != normal]
+            for corner in np.ndindex(*(2,) * len(tang)):     # the 2^(d-1) vertices of a face
+                sel_face = [slice(None)] * dim
+                sel_node = [slice(None)] * dim
+                ok = True
+                for ax, hi in zip(tang, corner):
+                    # cell j touches vertices j and j + 1, i.e. interior nodes j - 1 and j
+                    if hi:
+                        sel_face[ax], sel_node[ax] = slice(0, n - 1), slice(0, m)
+                    else:
+                        sel_face[ax], sel_node[ax] = slice(1, n), slice(0, m)
+                if ok:
+                    rows.append(g[tuple(sel_face)].ravel())
+                    cols.append(nodes[tuple(sel_node)].ravel())
+            r, cc = np.concatenate(rows), np.concatenate(cols)
+            w = np.full(r.size, 1.0 / 2 ** (dim - 1))
+            blocks.append(sp.csr_matrix((w, (r, cc)), shape=(self.n_u // b, n_nodes)))
+            lapl.append(lap)
+            ranges.append(range(off * b, (off + n_nodes) * b))
+            off += n_nodes
+        T = sp.hstack(blocks, format="csr")
+        if b > 1:
+            eye_b = sp.identity(b, format="csr")
+            T = sp.kron(T, eye_b, format="csr")
+            S = sp.csr_matrix(self.inflation_block)
+            lapl = [sp.kron(L, S, format="csr") for L in lapl]
+        T.sort_indices()
+        for L in lapl:
+            L.sort_indices()
+        return {"transform": T, "laplacians": lapl, "ranges": ranges}
+
     def condense(self, seed=0):
         """Static condensation of A: split the velocity dofs into an
         *interior* set I (a maximal independent set of A's graph, so A_ii is diagonal -- the role
@@ -202,9 +391,11 @@ class StokesSystem:
         B = sp.kron(self.B, sp.csr_matrix(r_blk), format="csr")
         A.sort_indices()
         B.sort_indices()
-        return StokesSystem(self.dim, self.n, self.nu, self.h, A, B, self.mass.copy(),
-                            self.velocity_slab_offsets * bs, self.pressure_slab_offsets.copy(),
-                            self.component_ids, block_size=self.block_size * bs)
+        out = StokesSystem(self.dim, self.n, self.nu, self.h, A, B, self.mass.copy(),
+                           self.velocity_slab_offsets * bs, self.pressure_slab_offsets.copy(),
+                           self.component_ids, block_size=self.block_size * bs)
+        out.inflation_block = s_blk if self.block_size == 1 else np.kron(self.inflation_block, s_blk)
+        return out
 
 
 def mac_stokes(dim, n, nu=0.01):

@@ -5,18 +5,28 @@ drivers exercise: the *iterative Stokes initial solve*, i.e. the hand-off
     BramblePasciakCG(blfA, blfB, None, f.vec, g.vec, preA, preM, sol,
                      initialize=False, tol=1e-10, maxsteps=100000, rel_err=True)          (:397)
 
-with ``preA`` = facet-block Jacobi (``MypreA`` with ``GS=False`` minus the AMG term, :364-391) and
-``preM`` = ``Preconditioner(mass, 'local')`` (:197-200).
+with ``preA = MypreA(X2, blfA, blocks, GS)`` (:364-391) and ``preM = Preconditioner(mass, 'local')``
+(:197-200).  ``MypreA`` is built the way the reference builds it:
 
-``GS=True`` (the reference's default) selects the symmetric multiplicative block Gauss-Seidel
-sweep (:376-381) over a multicolour block ordering, ``GS=False`` the additive block Jacobi.
+* ``blocks`` = the free dofs of every mesh facet (:360-362) -> ``a.mat.CreateBlockSmoother(blocks)``;
+* the auxiliary space (:150-157): one P1-like nodal space per velocity component, its ``nu``-scaled
+  Laplacian ``aH1_c`` with ``Preconditioner(aH1_c, 'h1amg')`` (:320-351), stacked by ``Embedding``
+  (:334-337,353-357) to ``preAh1``, and the ``transform`` from nodal fields to the facet unknowns
+  (:208-291) -- FE machinery in the reference, here their grid restatement
+  (``StokesSystem.auxiliary_space``);
+* ``GS=False``: ``y = ((transform @ preAh1 @ transform.T) + jacobi) * x`` (:383);
+  ``GS=True`` (the reference's default): ``y = 0; jacobi.Smooth(y, x); temp = x - mat*y;
+  y += (transform @ preAh1 @ transform.T) * temp; jacobi.SmoothBack(y, x)`` (:376-381), the sweeps over a
+  multicolour block ordering (scope row N1).
+  Both forms are applied natively inside the fused BPCG loop (one ``nss_amg_create_auxiliary`` handle
+  for the auxiliary term); ``aux=False`` drops the auxiliary term (block smoother only).
 
 ``DoTimeStep`` / ``Project`` / ``SolveInitial(timesteps=N)`` (:400-443, scope row N4) are the
 reference's orchestration restated on the staggered-grid operators: ``invmstar`` = CG on
 ``M_u + timestep * A`` (:85-96), ``Project`` = pressure projection through CG on ``B M_u^-1 B^T``
-(:115-144,440-443), explicit Euler update ``u += timestep * temp2`` (:438).  The convection term
-(:106-113, JIT-compiled nonlinear form) is not modelled: ``conv_operator`` is ``None`` unless the
-caller installs an operator.
+(:115-144,440-443), explicit Euler update ``u += timestep * temp2`` (:438), and the explicit
+convection term ``conv_operator * gfu`` (:106-113,427-431): conservative upwind fluxes
+(``ConvectionOperator``: three SpMVs, the donor-cell flux kernel, one SpMV).
 
 Out of scope: the MCS/HDG assembly itself and the sparse direct branch
 ``iterative=False`` (raises ``NotImplementedError``)."""
@@ -32,52 +42,73 @@ from solvers.bramblepasciak_new import BramblePasciakCG
 __all__ = ["NavierStokes", "SyntheticMesh", "MypreA"]
 
 
-class _MultiplicativePreA(hipla.BaseMatrix):
-    """``y = 0; J.Smooth(y, x); r = x - A y; y += AMG r; J.SmoothBack(y, x)`` -- the
-    ``GS=True`` branch of the reference's MypreA.Mult
-    (templates/NavierStokesSIMPLE_iterative.py:376-381) with the build's AMG V-cycle in the place
-    of ``transform @ preAh1 @ transform.T``.  Runs through the protocol (sweeps, SpMV, V-cycle are
-    device kernels; the composition is host-driven)."""
+class ConvectionOperator(hipla.BaseMatrix):
+    """``conv_operator`` of the reference (templates/NavierStokesSIMPLE_iterative.py:106-113): the
+    *nonlinear* map u -> conv(u), weak form of -div(u (x) u) with upwind fluxes, used as
+    ``temp.data = conv_operator * gfu.vec`` (:429).  On the staggered grid: donor-cell fluxes
+    ``F = adv*avg - |adv|*diff/2`` with ``adv = I_adv u``, ``avg = Avg u``, ``diff = Diff u`` (three
+    SpMVs), then ``conv = -D F`` (one SpMV); all on the device."""
 
-    def __init__(self, space, a, jacblocks):
+    def __init__(self, system):
         super().__init__()
-        self.space, self.mat, self.GS = space, a.mat, True
-        self.jacobi = hipla.BlockGaussSeidel(a.mat, jacblocks)
-        self.amg = hipla.SmoothedAggregationAMG(a.mat)
-        self.temp = a.mat.CreateColVector()
-
-    def Mult(self, x, y):
-        y[:] = 0
-        self.jacobi.Smooth(y, x)
-        self.temp.data = x - self.mat * y
-        y.data += self.amg * self.temp
-        self.jacobi.SmoothBack(y, x)
+        ops = system.convection_operators()
+        self.n = system.n_u
+        self.adv, self.avg, self.diff, self.div = (hipla.SparseMatrix.from_scipy(ops[k])
+                                                   for k in ("adv", "avg", "diff", "div"))
+        self._work = [self.adv.CreateColVector() for _ in range(4)]
 
     def Height(self):
-        return self.mat.height
+        return self.n
 
     def Width(self):
-        return self.mat.width
+        return self.n
+
+    def Mult(self, x, y):
+        adv, avg, diff, flux = self._work
+        adv.data = self.adv * x
+        avg.data = self.avg * x
+        diff.data = self.diff * x
+        flux.engine.upwind_flux(adv.buf, avg.buf, diff.buf, flux.buf)
+        y.data = -self.div * flux
 
 
-def MypreA(space, a, jacblocks, GS, amg=False):
+def auxiliary_space_preconditioner(system):
+    """``transform`` and ``preAh1`` of the reference (:208-357) on the grid restatement of the auxiliary
+    space: returns (transform, preAh1, aux) with ``preAh1 = sum_c emb_c @ Preconditioner(aH1_c, 'h1amg') @
+    emb_c.T`` as the protocol composition the reference writes (:336-337,357) and ``aux`` = the same
+    operator ``transform @ preAh1 @ transform.T`` as one native handle (`hipla.AuxiliarySpaceAMG`)."""
+    space = system.auxiliary_space()
+    transform = hipla.SparseMatrix.from_scipy(space["transform"])
+    ndof = transform.width
+    comps, preAh1 = [], None
+    for lap, rng in zip(space["laplacians"], space["ranges"]):
+        aH1 = AssembledForm(hipla.SparseMatrix.from_scipy(lap))
+        pre_c = hipla.Preconditioner(aH1, "h1amg")                       # :326-329,340-349
+        emb = hipla.Embedding(ndof, rng)                                 # :334-335,353-355
+        term = emb @ pre_c @ emb.T
+        preAh1 = term if preAh1 is None else preAh1 + term               # :337,357
+        comps.append(pre_c)
+    return transform, preAh1, hipla.AuxiliarySpaceAMG(transform, comps)
+
+
+def MypreA(space, a, jacblocks, GS, aux=None):
     """``MypreA(space, a, jacblocks, GS)`` of the reference
-    (templates/NavierStokesSIMPLE_iterative.py:364-391).  Its auxiliary-space term
-    ``transform @ preAh1 @ transform.T`` (:380,383) is NGSolve FE machinery; ``amg=True`` puts the
-    build's smoothed-aggregation V-cycle on ``a.mat`` in its place (scope row N3):
+    (templates/NavierStokesSIMPLE_iterative.py:364-391); `aux` is the auxiliary-space term
+    ``transform @ preAh1 @ transform.T`` (an `hipla.AuxiliarySpaceAMG`, or any operator), ``None`` = block
+    smoother only.
 
-    * ``GS=False`` -> additive ``y = (AMG + J) x`` with ``J = a.mat.CreateBlockSmoother(jacblocks)``
-      (:383); without ``amg`` just ``J``.  Native: applied inside the fused loops.
-    * ``GS=True``  -> ``y = 0; J.Smooth(y, x); [r = x - A y; y += AMG r;] J.SmoothBack(y, x)``
-      (:376-381) over a multicolour block ordering (scope row N1).  Without ``amg`` native (fused
-      loops); with ``amg`` the multiplicative composition runs through the protocol."""
-    if GS and amg:
-        return _MultiplicativePreA(space, a, jacblocks)
-    op = hipla.BlockGaussSeidel(a.mat, jacblocks) if GS else hipla.BlockJacobi(a.mat, jacblocks)
-    op.space, op.GS = space, GS
-    if amg:
-        return hipla.SmoothedAggregationAMG(a.mat) + op
-    return op
+    * ``GS=False`` -> additive ``y = (aux + J) x`` with ``J = a.mat.CreateBlockSmoother(jacblocks)`` (:383);
+    * ``GS=True``  -> ``y = 0; J.Smooth(y, x); r = x - A y; y += aux r; J.SmoothBack(y, x)`` (:376-381)
+      over a multicolour block ordering (scope row N1).
+    Both are native operands of the fused BPCG loop when `aux` is an `AuxiliarySpaceAMG` (or a
+    `SmoothedAggregationAMG`); other operators run through the protocol."""
+    if GS:
+        op = hipla.BlockGaussSeidel(a.mat, jacblocks, middle=aux)
+        op.space, op.GS = space, True
+        return op
+    op = hipla.BlockJacobi(a.mat, jacblocks)
+    op.space, op.GS = space, False
+    return op if aux is None else aux + op
 
 
 class NavierStokes:
@@ -90,8 +121,18 @@ class NavierStokes:
         self.gfup = hipla.Vector(self.Q.ndof)
         self.stokes_bpcg_iterations = None
         self.stokes_bpcg_time = None
-        self.conv_operator = None
+        self._conv_operator = None        # explicit convection term of the IMEX step (:106-113), built on first use
         self._stepping = None
+
+    @property
+    def conv_operator(self):
+        if self._conv_operator is None:
+            self._conv_operator = ConvectionOperator(self.system)
+        return self._conv_operator
+
+    @conv_operator.setter
+    def conv_operator(self, op):
+        self._conv_operator = op
 
     def _time_stepping_operators(self):
         """mstar = M_u + timestep*A with its CG inverse (:85-96) and the projection operators
@@ -122,7 +163,10 @@ class NavierStokes:
         return out
 
     def SolveInitial(self, timesteps=None, iterative=True, GS=True, tol=1e-10, maxsteps=100000, printrates=False,
-                     amg=False):
+                     aux=True, amg=False):
+        """`aux`: build the auxiliary-space term of MypreA (:208-357) -- the reference always does; False
+        keeps the block smoother alone.  `amg=True` (kept from round 1) puts a smoothed-aggregation
+        V-cycle on a.mat itself in the place of the auxiliary term."""
         if timesteps:                                     # pseudo time stepping to the Stokes state (:406-417)
             ops = self._time_stepping_operators()
             self.Project(self.gfu)
@@ -141,7 +185,12 @@ class NavierStokes:
         blfA = AssembledForm(self.a.mat)
         blfB = AssembledForm(self.b.mat)
         preM = hipla.Preconditioner(self.mp, "local")
-        preA = MypreA(self.V, blfA, self.system.facet_blocks(), GS=GS, amg=amg)
+        middle = None
+        if amg:
+            middle = hipla.SmoothedAggregationAMG(blfA.mat)
+        elif aux:
+            self.transform, self.preAh1, middle = auxiliary_space_preconditioner(self.system)
+        preA = MypreA(self.V, blfA, self.system.facet_blocks(), GS=GS, aux=middle)
         sol = BlockVector([self.gfu, self.gfup])       # aliases the grid-function storage (:206)
         out = BramblePasciakCG(blfA, blfB, None, self.f.vec, self.g.vec, preA, preM, sol, initialize=False,
                                tol=tol, maxsteps=maxsteps, rel_err=True, printrates=printrates)
@@ -160,10 +209,7 @@ class NavierStokes:
         ops = self._time_stepping_operators()
         temp = self.a.mat.CreateColVector()
         temp2 = self.a.mat.CreateColVector()
-        if self.conv_operator is not None:
-            temp.data = self.conv_operator * self.gfu
-        else:
-            temp[:] = 0.0
+        temp.data = self.conv_operator * self.gfu        # :429
         temp.data += self.f.vec
         temp.data += -self.a.mat * self.gfu
         temp2.data = ops["invmstar"] * temp

@@ -144,7 +144,24 @@ class NumpyEngine:
     def amg_create(self, levels, omega):
         return {"levels": levels, "omega": float(omega)}
 
+    def upwind_flux(self, adv, avg, diff, out):
+        out[:] = adv * avg - 0.5 * (np.abs(adv) * diff)
+
+    def amg_create_auxiliary(self, T, TT, comps):
+        """Auxiliary-space term T (sum_c E_c V_c E_c^T) T^T (nss_amg_create_auxiliary)."""
+        return {"T": T.mat, "TT": TT.mat, "comps": list(comps)}
+
     def amg_apply(self, h, bscale, b, x):
+        if "T" in h:
+            r = h["TT"] @ (bscale * b)
+            z = np.zeros_like(r)
+            off = 0
+            for comp in h["comps"]:
+                n = comp["levels"][0]["n"]
+                z[off:off + n] = self._vcycle(comp, 0, r[off:off + n])
+                off += n
+            x[:] = h["T"] @ z
+            return
         x[:] = self._vcycle(h, 0, bscale * b)
 
     def _vcycle(self, h, l, b):

@@ -5,10 +5,10 @@ import torch
 from templates.NavierStokesSIMPLE_iterative import NavierStokes, SyntheticMesh
 for dim, h, order in ((3, 1/40, 1), (2, 1/128, 2)):
     for gs in (False, True):
-        for amg in (False, True):
+        for amg in (False, True):          # aux = the auxiliary-space term of MypreA
             ns = NavierStokes(SyntheticMesh(h, dim=dim), nu=0.001, inflow="inlet", outflow="outlet", wall="wall|cyl", uin=None, timestep=0.002, order=order)
             torch.cuda.synchronize(); t0 = time.perf_counter()
             with contextlib.redirect_stdout(io.StringIO()):
-                ns.SolveInitial(iterative=True, GS=gs, amg=amg, tol=1e-8)
+                ns.SolveInitial(iterative=True, GS=gs, aux=amg, tol=1e-8)
             torch.cuda.synchronize(); t = time.perf_counter() - t0
-            print("dim %d ndof %d GS=%s amg=%s: iterations %d loop %.3fs total %.2fs" % (dim, ns.V.ndof + ns.Q.ndof, gs, amg, ns.stokes_bpcg_iterations, ns.stokes_bpcg_time, t))
+            print("dim %d ndof %d GS=%s aux=%s: iterations %d loop %.3fs total %.2fs" % (dim, ns.V.ndof + ns.Q.ndof, gs, amg, ns.stokes_bpcg_iterations, ns.stokes_bpcg_time, t))
