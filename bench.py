@@ -60,7 +60,66 @@ def parse_args():
                          "(12 -> ~84 nnz per row as the reference's order-2 3-D spaces); preA = facet blocks")
     ap.add_argument("--cpu-iters", type=int, default=-1, help="oracle iterations to time (-1: auto, 0: skip)")
     ap.add_argument("--kernel-reps", type=int, default=30)
+    ap.add_argument("--hdg", type=int, default=28,
+                    help="grid of the secondary HDG-like measurement (facet blocks of 12 dofs, ~84 non-zeros per "
+                         "row: the reference's row regime, SURVEY.md A7); 0 skips it")
     return ap.parse_args()
+
+
+def hdg_like_roofline(torch, eng, grid, reps=40):
+    """Secondary measurement in the reference's row regime (order-2 3-D HDG spaces: ~84 non-zeros per row
+    in facet blocks of 12 dofs; templates/NavierStokesSIMPLE_iterative.py:24-26,360-362): the headline
+    operator Kronecker-inflated with a 12 x 12 SPD block, facet-block Jacobi preA, same fused loop.  Returns
+    the iteration rate and the roofline of its dominant launch (rows of A and B, C23), timed with HIP events
+    inside the running loop."""
+    import contextlib
+    import io
+    import hipla
+    from solvers.bramblepasciak_new import BpcgSession
+    from staggered_grid import mac_stokes
+    sysm = mac_stokes(3, grid, 0.01).inflate(12)
+    f, g = sysm.rhs(0)
+    A, B = hipla.SparseMatrix.from_scipy(sysm.A), hipla.SparseMatrix.from_scipy(sysm.B)
+    preA = hipla.BlockJacobi(A, sysm.line_blocks(1))              # the 12 dofs of one facet
+    preM = hipla.DiagonalMatrix(1.0 / sysm.mass)
+    sol = hipla.BlockVector([hipla.Vector(sysm.n_u), hipla.Vector(sysm.n_p)])
+    with contextlib.redirect_stdout(io.StringIO()):
+        ses = BpcgSession(Form(A), Form(B), None, hipla.Vector.from_numpy(f), hipla.Vector.from_numpy(g), preA, preM,
+                          sol=sol)
+    loop = ses.fused
+    ses.first_direction()
+    warm, timed_its = 10, 60
+    loop.start(ses.wdn, ses.err0, 0.0, True, warm + timed_its + reps)
+    loop.enqueue(0, warm)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    loop.enqueue(warm, warm + timed_its)
+    torch.cuda.synchronize()
+    per_it = (time.perf_counter() - t0) / timed_its
+    marks = []
+    for it in range(warm + timed_its, warm + timed_its + reps):
+        loop.cphases("C1", "C1", it)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        loop.cphases("C23", "C23", it)
+        e1.record()
+        loop.cphases("SUMA", "SUMW", it)
+        marks.append((e0, e1))
+    torch.cuda.synchronize()
+    ms = sum(a.elapsed_time(b) for a, b in marks[8:]) / (len(marks) - 8)
+    a_info, b_info = A.handle.info(), B.handle.info()
+    nbytes = (a_info["algorithmic_bytes"] + 16 * sysm.n_u + b_info["algorithmic_bytes"] + 8 * sysm.n_u + 24 * sysm.n_p)
+    gbs = nbytes / (ms * 1e-3) / 1e9
+    done, _, last = loop.poll()
+    return {"workload": "3-D MAC Stokes n=%d inflated with 12 x 12 blocks: %d velocity dofs, %.1f non-zeros per row of A, "
+                        "facet-block Jacobi (bs=12), BPCG v2" % (grid, sysm.n_u, a_info["nnz"] / sysm.n_u),
+            "iters_per_s": 1.0 / per_it, "ms_per_iteration": 1e3 * per_it, "bound": "hbm",
+            "kernel": "csr_stream_dual_kernel<EpiK2c, EpiK3c> (rows of A and B, grouped 16-bit column stream: one "
+                      "index per %d entries)" % a_info["index_group"],
+            "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+            "frac_of_achievable_6290": gbs / HBM_ACHIEVABLE_GBS, "algorithmic_bytes_per_launch": nbytes,
+            "avg_launch_ms": ms, "bytes_per_nonzero": {"values": 8, "column_index": 2.0 / a_info["index_group"]},
+            "valid": bool((not done) and last == warm + timed_its + reps - 1)}
 
 
 class Form:
@@ -437,7 +496,8 @@ def main():
 
     # per-iteration algorithmic bytes (DESIGN.md section "bytes per iteration")
     n_u, n_p = sysm.n_u, sysm.n_p
-    mat_bytes = sum((8 + i["index_bytes"]) * i["nnz"] + 4 * (i["rows"] + 1) for i in (a_info, b_info, bt_info))
+    mat_bytes = sum(8 * i["nnz"] + i["index_bytes"] * (i["nnz"] // i["index_group"]) + 4 * (i["rows"] + 1)
+                    for i in (a_info, b_info, bt_info))
     if args.pre == "amg":      # per level: two SpMVs with A_l (residual, post-smoothing), one each with P_l, R_l
         spmv_bytes = lambda i: 12 * i["nnz"] + 4 * (i["rows"] + 1) + 8 * (i["rows"] + i["cols"])
         pre_bytes = 0
@@ -478,8 +538,15 @@ def main():
                   "history_max_rel_diff": float(np.max(np.abs(hist[:m] - hist_c[:m]) / np.abs(hist_c[:m]))),
                   "err0_rel_diff": abs(ses.err0 - err0_c) / err0_c}
 
+    hdg = None
+    scale_k, folds = ses.k, loop.folds_sums()
+    if args.hdg > 0 and args.inflate == 1:
+        del ses, loop, sol, A, B, preA                      # the headline system's device memory
+        torch.cuda.empty_cache()
+        hdg = hdg_like_roofline(torch, eng, args.hdg)
     traffic, traffic_note = pmc_traffic("EpiK2c", "grid=%d dim=%d pre=%s" % (args.n, args.dim, args.pre))
-    k2_bytes_int32 = k2_bytes + sum(2 * i["nnz"] for i in (a_info, b_info) if i["index_bytes"] == 2)
+    k2_bytes_int32 = k2_bytes + sum(4 * i["nnz"] - 2 * (i["nnz"] // i["index_group"]) for i in (a_info, b_info)
+                                    if i["index_bytes"] == 2)
     out = {
         "metric": "Krylov iters/sec, 3D SIMPLE Stokes solve (BPCG)", "value": K / elapsed, "unit": "iters/s",
         "n_gpus": 1, "steps": K, "warmup": W, "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True,
@@ -488,9 +555,11 @@ def main():
                                "BPCG v2 (solvers/bramblepasciak_new.py), %s preA, lumped-mass preM, Re=%g"
                                % (args.dim, args.n, sysm.ndof, args.pre, 1.0 / args.nu),
                    "n_u": n_u, "n_p": n_p, "nnz_A": a_info["nnz"], "nnz_B": b_info["nnz"],
-                   "scale_factor_k": ses.k, "device": info["arch"], "cu_count": info["cu_count"],
+                   "scale_factor_k": scale_k, "device": info["arch"], "cu_count": info["cu_count"],
                    "column_index_bytes": {"A": a_info["index_bytes"], "B": b_info["index_bytes"],
-                                          "BT": bt_info["index_bytes"]}},
+                                          "BT": bt_info["index_bytes"]},
+                   "entries_per_column_index": {"A": a_info["index_group"], "B": b_info["index_group"],
+                                                "BT": bt_info["index_group"]}},
         "roofline": {"bound": "hbm",
                      "kernel": ("csr_stream_dual_kernel<EpiK2c, EpiK3c>: t2 = A t1 with <s0, t2 - t0> and "
                                 "t3 = B (t1 - s0) with s1 = beta s1 + w1, <s1, t3> in one launch" if dual else
@@ -500,20 +569,22 @@ def main():
                      "traffic": traffic["bytes"] if traffic else None,
                      "traffic_source": traffic["source"] if traffic else None, "traffic_note": traffic_note,
                      "algorithmic_bytes_per_launch": k2_bytes, "avg_launch_ms": k2_ms,
-                     "bytes_accounting": "A and B: value stream 8 B + column stream %d B per non-zero (as stored), row "
-                                         "pointers, x and y once; + s0, t0 read (A rows); + second gathered "
-                                         "operand, s1, w1 read, s1 written (B rows)" % a_info["index_bytes"],
+                     "bytes_accounting": "A and B: value stream 8 B per non-zero + column stream %d B per %d non-zeros "
+                                         "(as stored), row pointers, x and y once; + s0, t0 read (A rows); + second "
+                                         "gathered operand, s1, w1 read, s1 written (B rows)"
+                                         % (a_info["index_bytes"], a_info["index_group"]),
                      "achieved_if_priced_as_int32_csr": k2_bytes_int32 / (k2_ms * 1e-3) / 1e9,
                      "frac_of_achievable_6290": k2_gbs / HBM_ACHIEVABLE_GBS,
                      "frac_of_stream_triad": k2_gbs / triad_gbs,
                      "timing": "HIP events around the kernel inside %d iterations of the running loop" % (probe_its - 8)},
         "cpu_baseline": cpu,
+        "roofline_hdg_like": hdg,
         "valid": valid,
         "hbm_GBs": {"whole_iteration_algorithmic": iter_gbs, "stream_triad": triad_gbs, "spmv_A_plain": spmv_gbs,
                     "spmv_AB_fused_C23": k2_gbs},
         "kernel_ms": {"C1_BT_preA": k1_ms, "C23_A_B": k2_ms, "C4_update": k4_ms, "sum_kernels": sums_ms,
                       "spmv_A_plain": spmv_ms, "triad_1.6GB": triad_ms},
-        "launches_per_iteration": {"sums_folded_into_consumers": loop.folds_sums()},
+        "launches_per_iteration": {"sums_folded_into_consumers": folds},
         "bytes_per_iteration": iter_bytes,
         "parity": parity,
         "setup_s": {"assemble_host": t_asm, "upload_lanczos_initial_residual": t_setup},

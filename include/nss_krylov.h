@@ -128,6 +128,10 @@ NSS_API int nss_csr_destroy(nss_csr_t a);
 /* y = alpha * A x + beta * y   (beta == 0: y is not read).  x must not alias y. */
 NSS_API int nss_csr_spmv_f64(nss_csr_t a, double alpha, const double* x, double beta, double* y,
                              nss_stream_t stream);
+/* entries that share one stored column index: 1 for plain CSR streams; g > 1 when the matrix consists of
+ * aligned runs of g consecutive columns (block-structured operators, e.g. facet blocks of 5 / 12 dofs) and
+ * the SpMV kernel streams one 16-bit index per run -- 8 + 2/g bytes per non-zero. */
+NSS_API int nss_csr_index_group(nss_csr_t a, int32_t* entries_per_index);
 /* shape, nnz, launch plan (row blocks, lanes per row) and algorithmic bytes of one
  * SpMV: 12*nnz + 4*(rows+1) + 8*cols + 8*rows */
 NSS_API int nss_csr_info(nss_csr_t a, int32_t* nrows, int32_t* ncols, int64_t* nnz,

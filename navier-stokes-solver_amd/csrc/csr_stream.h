@@ -66,6 +66,9 @@ struct CsrView {
   const uint16_t* __restrict__ col16;   // (window << 12 | offset) per entry, or NULL (see nss_csr_s)
   const int32_t* __restrict__ blkbase;  // kWindows window bases per row block
   const double* __restrict__ val;
+  uint32_t gb;      // entries per column group of the 16-bit stream (1: one index per entry)
+  uint32_t gstep, sstep;   // kBlock / gb, kBlock % gb: a lane's next entry is kBlock further down the stream
+  uint64_t gmagic;  // ceil(2^64 / gb) (gb > 1): p / gb == __umul64hi(p, gmagic) for p < 2^32
   int32_t blk0;     // first row block of this launch (sub-range launches: interior / boundary)
   int32_t nblk;     // row blocks in this launch
   int32_t per_xcd;  // ceil(nblk / 8)
@@ -91,9 +94,18 @@ struct nss_csr_s {
   // products in the same order.  `col` is kept for the set-up kernels and rows longer than a chunk.
   uint16_t* col16 = nullptr;
   int32_t* blkbase = nullptr;
+  // Grouped column stream (block-structured operators: the facet blocks of the HDG-like spaces, ~84
+  // non-zeros per row in runs of 12 consecutive columns): when every row length is a multiple of `gb`
+  // and every aligned group of `gb` consecutive entries has consecutive columns, col16 holds ONE 16-bit
+  // index per group -- 8 + 2/gb bytes per non-zero instead of 10 -- and entry p has column
+  // decode(col16[p / gb]) + p % gb.  The value order stays CSR (rows contiguous), so the kernel, its
+  // reduction order and its results are unchanged.  gb == 1: one index per entry.
+  int32_t gb = 1;
   // launch view of the row blocks [b0, b1)
   nss::CsrView view(int b0, int b1) const {
-    return nss::CsrView{rowblk, rowptr, col, col16, blkbase, val, b0, b1 - b0,
+    const uint64_t magic = gb > 1 ? ~uint64_t(0) / uint64_t(gb) + 1 : 0;    // ceil(2^64 / gb)
+    return nss::CsrView{rowblk, rowptr, col, col16, blkbase, val, uint32_t(gb), uint32_t(nss::kBlock / gb),
+                        uint32_t(nss::kBlock % gb), magic, b0, b1 - b0,
                         (b1 - b0 + nss::kXcds - 1) / nss::kXcds};
   }
   // one workgroup per row block, padded to a multiple of the XCD count
@@ -167,7 +179,7 @@ struct EpiPrologue<E, std::void_t<decltype(std::declval<E&>().prologue(static_ca
 constexpr int kRedDoubles = 32;   // per-workgroup reduction scratch (block_sum: 4, fixed_sum_1024: 32)
 
 // One workgroup = one row block: `wg` is the workgroup's index inside this launch's grid part.
-template <int RG, class Epi, bool C16, int CH, class X>
+template <int RG, class Epi, bool C16, int CH, bool GRP, class X>
 __device__ __forceinline__ void csr_stream_body(const CsrView& a, const X& xop, Epi& epi, int wg, double* prod,
                                                 double* red, int32_t* window) {
   const int tid = threadIdx.x;
@@ -200,24 +212,38 @@ __device__ __forceinline__ void csr_stream_body(const CsrView& a, const X& xop, 
       if (C16) {
         if (tid < kWindows) window[tid] = a.blkbase[b * kWindows + tid];
       }
+      uint32_t grp = 0, gsub = 0;                          // group of this lane's entry, position inside it
+      if (C16 && GRP) {
+        const uint32_t p = uint32_t(p0 + tid);
+        grp = a.gb > 1 ? uint32_t(__umul64hi(uint64_t(p), a.gmagic)) : p;   // one division per lane, then incremental
+        gsub = p - grp * a.gb;
+      }
 #pragma unroll
       for (int k = 0; k < kPer; ++k) {
         const int i = tid + k * kBlock;
         const bool live = i < cnt;
+        if (C16 && GRP) {                                  // one index per group of a.gb entries
+          c16[k] = live ? a.col16[grp] : uint16_t(0);      // shared by a.gb neighbouring lanes
+          c[k] = int32_t(gsub);
+          gsub += a.sstep;
+          grp += a.gstep + (gsub >= a.gb ? 1u : 0u);
+          gsub -= gsub >= a.gb ? a.gb : 0u;
+        }
 #if NSS_STREAM_NT
-        if (C16) c16[k] = live ? __builtin_nontemporal_load(&a.col16[p0 + i]) : uint16_t(0);
-        else c[k] = live ? __builtin_nontemporal_load(&a.col[p0 + i]) : 0;
+        if (C16 && !GRP) c16[k] = live ? __builtin_nontemporal_load(&a.col16[p0 + i]) : uint16_t(0);
+        if (!C16) c[k] = live ? __builtin_nontemporal_load(&a.col[p0 + i]) : 0;
         v[k] = live ? __builtin_nontemporal_load(&a.val[p0 + i]) : 0.0;
 #else
-        if (C16) c16[k] = live ? a.col16[p0 + i] : uint16_t(0);
-        else c[k] = live ? a.col[p0 + i] : 0;
+        if (C16 && !GRP) c16[k] = live ? a.col16[p0 + i] : uint16_t(0);
+        if (!C16) c[k] = live ? a.col[p0 + i] : 0;
         v[k] = live ? a.val[p0 + i] : 0.0;
 #endif
       }
       if (C16) {
         __syncthreads();                                   // window bases in LDS
 #pragma unroll
-        for (int k = 0; k < kPer; ++k) c[k] = window[c16[k] >> kWindowBits] + int32_t(c16[k] & ((1 << kWindowBits) - 1));
+        for (int k = 0; k < kPer; ++k)
+          c[k] = window[c16[k] >> kWindowBits] + int32_t(c16[k] & ((1 << kWindowBits) - 1)) + (GRP ? c[k] : 0);
       }
       double xv[kPer];
 #pragma unroll
@@ -266,20 +292,20 @@ __device__ __forceinline__ void csr_stream_body(const CsrView& a, const X& xop, 
   epi.finish(b, red);  // one dot partial per row block
 }
 
-template <int RG, class Epi, bool C16 = false, int CH = kChunk>
+template <int RG, class Epi, bool C16 = false, int CH = kChunk, bool GRP = false>
 __global__ __launch_bounds__(kBlock) void csr_stream_kernel(CsrView a, const double* __restrict__ x, Epi epi) {
   __shared__ double prod[CH];
   __shared__ double red[kRedDoubles];
   __shared__ int32_t window[kWindows];
   if (epi.skip()) return;
   if (!EpiPrologue<Epi>::run(epi, red)) return;
-  csr_stream_body<RG, Epi, C16, CH>(a, EpiX<Epi>::get(epi, x), epi, int(blockIdx.x), prod, red, window);
+  csr_stream_body<RG, Epi, C16, CH, GRP>(a, EpiX<Epi>::get(epi, x), epi, int(blockIdx.x), prod, red, window);
 }
 
 // Two matrices with the same launch-plan parameters in ONE launch: workgroups [0, grid_a) stream the
 // row blocks of `a` with `ea`, the rest those of `b` with `eb` -- two SpMVs that do not depend on each
 // other (the fused BPCG iteration: t2 = A t1 and t3 = B (t1 - s0)) share a kernel boundary.
-template <int RG, class EpiA, class EpiB, bool C16, int CH>
+template <int RG, class EpiA, class EpiB, bool C16, int CH, bool GRP = false>
 __global__ __launch_bounds__(kBlock) void csr_stream_dual_kernel(CsrView a, CsrView b, int grid_a,
                                                                   const double* __restrict__ xa,
                                                                   const double* __restrict__ xb, EpiA ea, EpiB eb) {
@@ -289,11 +315,11 @@ __global__ __launch_bounds__(kBlock) void csr_stream_dual_kernel(CsrView a, CsrV
   if (int(blockIdx.x) < grid_a) {
     if (ea.skip()) return;
     if (!EpiPrologue<EpiA>::run(ea, red)) return;
-    csr_stream_body<RG, EpiA, C16, CH>(a, EpiX<EpiA>::get(ea, xa), ea, int(blockIdx.x), prod, red, window);
+    csr_stream_body<RG, EpiA, C16, CH, GRP>(a, EpiX<EpiA>::get(ea, xa), ea, int(blockIdx.x), prod, red, window);
   } else {
     if (eb.skip()) return;
     if (!EpiPrologue<EpiB>::run(eb, red)) return;
-    csr_stream_body<RG, EpiB, C16, CH>(b, EpiX<EpiB>::get(eb, xb), eb, int(blockIdx.x) - grid_a, prod, red, window);
+    csr_stream_body<RG, EpiB, C16, CH, GRP>(b, EpiX<EpiB>::get(eb, xb), eb, int(blockIdx.x) - grid_a, prod, red, window);
   }
 }
 
@@ -308,10 +334,12 @@ inline void launch_csr_stream(const nss_csr_s& A, const double* x, const Epi& ep
 #define NSS_LAUNCH_RG(N)                                                                                      \
   case N:                                                                                                      \
     if (A.chunk == kChunkLong) {                                                                               \
-      if (A.col16) hipLaunchKernelGGL((csr_stream_kernel<N, Epi, true, kChunkLong>), grid, block, 0, st, v, x, epi);   \
+      if (A.col16 && A.gb > 1) hipLaunchKernelGGL((csr_stream_kernel<N, Epi, true, kChunkLong, true>), grid, block, 0, st, v, x, epi);   \
+      else if (A.col16) hipLaunchKernelGGL((csr_stream_kernel<N, Epi, true, kChunkLong>), grid, block, 0, st, v, x, epi);   \
       else hipLaunchKernelGGL((csr_stream_kernel<N, Epi, false, kChunkLong>), grid, block, 0, st, v, x, epi);          \
     } else {                                                                                                   \
-      if (A.col16) hipLaunchKernelGGL((csr_stream_kernel<N, Epi, true>), grid, block, 0, st, v, x, epi);       \
+      if (A.col16 && A.gb > 1) hipLaunchKernelGGL((csr_stream_kernel<N, Epi, true, kChunk, true>), grid, block, 0, st, v, x, epi);       \
+      else if (A.col16) hipLaunchKernelGGL((csr_stream_kernel<N, Epi, true>), grid, block, 0, st, v, x, epi);  \
       else hipLaunchKernelGGL((csr_stream_kernel<N, Epi, false>), grid, block, 0, st, v, x, epi);              \
     }                                                                                                          \
     break;
@@ -331,16 +359,19 @@ inline bool launch_csr_stream_dual(const nss_csr_s& A, const double* xa, const E
                                    const double* xb, const EpiB& eb, hipStream_t st) {
   if (A.m == 0 || B.m == 0 || A.nblk == 0 || B.nblk == 0) return false;
   if (A.rg != B.rg || A.chunk != B.chunk || (A.col16 != nullptr) != (B.col16 != nullptr)) return false;
+  const bool grp = A.gb > 1 || B.gb > 1;      // the grouped decode also reads a one-per-entry stream (gb == 1)
   const CsrView va = A.view(0, A.nblk), vb = B.view(0, B.nblk);
   const int ga = nss_csr_s::grid(A.nblk), gb = nss_csr_s::grid(B.nblk);
   const dim3 grid(ga + gb), block(kBlock);
 #define NSS_LAUNCH_DUAL(N)                                                                                             \
   case N:                                                                                                              \
     if (A.chunk == kChunkLong) {                                                                                       \
-      if (A.col16) hipLaunchKernelGGL((csr_stream_dual_kernel<N, EpiA, EpiB, true, kChunkLong>), grid, block, 0, st, va, vb, ga, xa, xb, ea, eb);  \
+      if (A.col16 && grp) hipLaunchKernelGGL((csr_stream_dual_kernel<N, EpiA, EpiB, true, kChunkLong, true>), grid, block, 0, st, va, vb, ga, xa, xb, ea, eb);  \
+      else if (A.col16) hipLaunchKernelGGL((csr_stream_dual_kernel<N, EpiA, EpiB, true, kChunkLong>), grid, block, 0, st, va, vb, ga, xa, xb, ea, eb);  \
       else hipLaunchKernelGGL((csr_stream_dual_kernel<N, EpiA, EpiB, false, kChunkLong>), grid, block, 0, st, va, vb, ga, xa, xb, ea, eb);         \
     } else {                                                                                                           \
-      if (A.col16) hipLaunchKernelGGL((csr_stream_dual_kernel<N, EpiA, EpiB, true, kChunk>), grid, block, 0, st, va, vb, ga, xa, xb, ea, eb);      \
+      if (A.col16 && grp) hipLaunchKernelGGL((csr_stream_dual_kernel<N, EpiA, EpiB, true, kChunk, true>), grid, block, 0, st, va, vb, ga, xa, xb, ea, eb);      \
+      else if (A.col16) hipLaunchKernelGGL((csr_stream_dual_kernel<N, EpiA, EpiB, true, kChunk>), grid, block, 0, st, va, vb, ga, xa, xb, ea, eb);      \
       else hipLaunchKernelGGL((csr_stream_dual_kernel<N, EpiA, EpiB, false, kChunk>), grid, block, 0, st, va, vb, ga, xa, xb, ea, eb);             \
     }                                                                                                                  \
     break;

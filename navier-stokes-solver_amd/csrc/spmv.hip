@@ -114,6 +114,74 @@ __global__ __launch_bounds__(kBlock) void col_pack16_kernel(int32_t nblk, const 
   }
 }
 
+// ---- grouped column stream ----------------------------------------------------------------------
+// bad[0] != 0 unless every row start is a multiple of gb and every entry that is not the first of its
+// aligned group of gb continues the column run of its predecessor
+__global__ __launch_bounds__(kBlock) void col_group_check_kernel(int32_t m, int64_t nnz, const int32_t* __restrict__ rowptr,
+                                                                  const int32_t* __restrict__ col, int32_t gb,
+                                                                  int32_t* __restrict__ bad) {
+  const int64_t stride = int64_t(gridDim.x) * kBlock;
+  bool b = false;
+  for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i <= m; i += stride) b = b || (rowptr[i] % gb != 0);
+  for (int64_t p = int64_t(blockIdx.x) * kBlock + threadIdx.x; p < nnz; p += stride)
+    if (p % gb != 0) b = b || (col[p] != col[p - 1] + 1);
+  if (b) atomicOr(bad, 1);
+}
+
+__global__ __launch_bounds__(kBlock) void col_group_pack_kernel(int64_t ngroups, int32_t gb, const uint16_t* __restrict__ c16,
+                                                                 uint16_t* __restrict__ out) {
+  const int64_t stride = int64_t(gridDim.x) * kBlock;
+  for (int64_t g = int64_t(blockIdx.x) * kBlock + threadIdx.x; g < ngroups; g += stride) out[g] = c16[g * gb];
+}
+
+#ifndef NSS_COL_GROUPS
+#define NSS_COL_GROUPS 1
+#endif
+
+// Largest gb in 16 .. 2 for which the matrix is made of aligned runs of gb consecutive columns: keep one
+// 16-bit index per run (see nss_csr_s::gb).  Every row block starts at a row start, hence at a multiple of gb.
+static void group_columns(nss_csr_s& A, hipStream_t st) {
+#if NSS_COL_GROUPS
+  if (!A.col16 || A.nnz < 16) return;
+  int32_t* bad = nullptr;
+  uint16_t* packed = nullptr;
+  try {
+    NSS_HIP(hipMalloc(&bad, sizeof(int32_t)));
+    for (int gb = 16; gb >= 2; --gb) {
+      if (A.nnz % gb != 0) continue;
+      NSS_HIP(hipMemsetAsync(bad, 0, sizeof(int32_t), st));
+      hipLaunchKernelGGL(col_group_check_kernel, dim3(stream_grid(A.nnz, kBlock * 4)), dim3(kBlock), 0, st, A.m, A.nnz,
+                         A.rowptr, A.col, gb, bad);
+      NSS_CHECK_LAUNCH();
+      int32_t h_bad = 1;
+      NSS_HIP(hipMemcpyAsync(&h_bad, bad, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+      NSS_HIP(hipStreamSynchronize(st));
+      if (h_bad != 0) continue;
+      const int64_t ngroups = A.nnz / gb;
+      NSS_HIP(hipMalloc(&packed, sizeof(uint16_t) * (size_t(ngroups) + 8)));
+      NSS_HIP(hipMemsetAsync(packed, 0, sizeof(uint16_t) * (size_t(ngroups) + 8), st));
+      hipLaunchKernelGGL(col_group_pack_kernel, dim3(stream_grid(ngroups, kBlock * 4)), dim3(kBlock), 0, st, ngroups, gb,
+                         A.col16, packed);
+      NSS_CHECK_LAUNCH();
+      NSS_HIP(hipStreamSynchronize(st));
+      (void)hipFree(A.col16);
+      A.col16 = packed;
+      packed = nullptr;
+      A.gb = gb;
+      break;
+    }
+  } catch (...) {
+    (void)hipFree(bad);
+    (void)hipFree(packed);
+    throw;
+  }
+  (void)hipFree(bad);
+#else
+  (void)A;
+  (void)st;
+#endif
+}
+
 void compress_columns(nss_csr_s& A, hipStream_t st) {
 #if NSS_COL16
   if (A.nnz == 0 || A.nblk == 0) return;
@@ -141,6 +209,7 @@ void compress_columns(nss_csr_s& A, hipStream_t st) {
       A.blkbase = base;
       c16 = nullptr;
       base = nullptr;
+      group_columns(A, st);
     }
   } catch (...) {
     (void)hipFree(base);
@@ -251,6 +320,13 @@ int nss_csr_index_width(nss_csr_t a, int32_t* bytes) {
   });
 }
 
+int nss_csr_index_group(nss_csr_t a, int32_t* entries_per_index) {
+  return guarded([&] {
+    NSS_REQUIRE(a != nullptr && entries_per_index != nullptr, "csr_index_group: NULL argument");
+    *entries_per_index = a->col16 ? a->gb : 1;
+  });
+}
+
 int nss_csr_info(nss_csr_t a, int32_t* nrows, int32_t* ncols, int64_t* nnz, int32_t* nblocks,
                  int32_t* lanes_per_row, int64_t* algorithmic_bytes) {
   return guarded([&] {
@@ -265,7 +341,7 @@ int nss_csr_info(nss_csr_t a, int32_t* nrows, int32_t* ncols, int64_t* nnz, int3
     // pointers, x once and y once.  (The CSR fp64/int32 textbook figure is 12 nnz + ...; pricing a
     // launch that streams 10 bytes per entry at 12 would overstate its bandwidth.)
     if (algorithmic_bytes)
-      *algorithmic_bytes = (a->col16 ? 10 * a->nnz + int64_t(4) * kWindows * a->nblk : 12 * a->nnz) +
+      *algorithmic_bytes = (a->col16 ? 8 * a->nnz + 2 * (a->nnz / a->gb) + int64_t(4) * kWindows * a->nblk : 12 * a->nnz) +
                            4 * (int64_t(a->m) + 1) + 8 * int64_t(a->n) + 8 * int64_t(a->m);
   });
 }

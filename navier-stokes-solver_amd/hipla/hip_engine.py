@@ -46,6 +46,7 @@ def _signatures():
         "nss_csr_spgemm": (C.c_int, [vp, vp, i64, C.POINTER(vp), vp]),
         "nss_csr_download": (C.c_int, [vp, vp, vp, vp]),
         "nss_csr_index_width": (C.c_int, [vp, c_i32_p]),
+        "nss_csr_index_group": (C.c_int, [vp, c_i32_p]),
         "nss_scratch_trim": (C.c_int, []),
         "nss_csr_ones_like": (C.c_int, [vp, C.POINTER(vp), vp]),
         "nss_graph_color": (C.c_int, [vp, vp, vp, vp, c_i32_p, vp]),
@@ -137,10 +138,12 @@ class _CsrHandle:
         m, n, nb, rg = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
         nnz, nbytes = C.c_int64(), C.c_int64()
         self.engine._check(lib.nss_csr_info(self.ptr, m, n, nnz, nb, rg, nbytes))
-        width = C.c_int32()
+        width, group = C.c_int32(), C.c_int32()
         self.engine._check(lib.nss_csr_index_width(self.ptr, width))
+        self.engine._check(lib.nss_csr_index_group(self.ptr, group))
         return {"rows": m.value, "cols": n.value, "nnz": nnz.value, "row_blocks": nb.value,
-                "lanes_per_row": rg.value, "algorithmic_bytes": nbytes.value, "index_bytes": width.value}
+                "lanes_per_row": rg.value, "algorithmic_bytes": nbytes.value, "index_bytes": width.value,
+                "index_group": group.value}
 
     def __del__(self):
         try:

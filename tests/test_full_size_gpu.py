@@ -188,3 +188,31 @@ def test_cfg5_5e7_dof_operators_and_iterations(hip_engine):
         print("cfg5 Re=%d: k=%.6g err0=%.6e history rel.diff %.1e (%.0f s)"
               % (reynolds, ses.k, ses.err0, np.max(np.abs(hist - hist_c) / hist_c), time.perf_counter() - t0))
         del A, preA, ses, sol, A_host
+
+
+@pytest.mark.skipif(os.environ.get("NSS_SKIP_HUGE") == "1", reason="NSS_SKIP_HUGE=1")
+def test_grouped_column_stream_beyond_2e8_entries(hip_engine):
+    """Block-structured operator with more than 2^27.6 stored entries (the index arithmetic of the grouped
+    16-bit column stream -- entry / group size by multiplication -- must hold up to 2^31 entries): rows of
+    64 consecutive columns, one stored index per 16 entries; SpMV against numpy on the dense row blocks."""
+    import hipla
+    import scipy.sparse as sp
+    m, w, ncols = 3_400_000, 64, 3_400_000 + 64
+    rng = np.random.default_rng(4)
+    first = ((np.arange(m, dtype=np.int64) * 7919) % (ncols - w)).astype(np.int32)
+    first.sort()                                            # banded: windows of the 16-bit stream stay few
+    indices = (first[:, None] + np.arange(w, dtype=np.int32)[None, :]).ravel()
+    indptr = (np.arange(m + 1, dtype=np.int64) * w).astype(np.int32)
+    vals = rng.standard_normal(m * w)
+    assert vals.size > 2.1e8
+    mat = sp.csr_matrix((vals, indices, indptr), shape=(m, ncols))
+    M = hipla.SparseMatrix.from_scipy(mat)
+    info = M.handle.info()
+    assert info["index_bytes"] == 2 and info["index_group"] == 16, info
+    x = rng.standard_normal(ncols)
+    y = hipla.Vector(m)
+    y.data = M * hipla.Vector.from_numpy(x)
+    xw = np.lib.stride_tricks.sliding_window_view(x, w)[first]          # (m, w) operand windows
+    ref = np.einsum("ij,ij->i", vals.reshape(m, w), xw)
+    scale = np.einsum("ij,ij->i", np.abs(vals.reshape(m, w)), np.abs(xw))
+    assert np.max(np.abs(y.numpy() - ref) / scale) < 1e-13

@@ -132,7 +132,13 @@ def test_spmv_row_length_regimes(hip_engine):
         infl = s.inflate(bs) if bs > 1 else s
         M = _spmv_check(hip_engine, infl.A)
         mean = infl.A.nnz / infl.A.shape[0]
-        assert M.handle.info()["lanes_per_row"] == _plan_lanes(mean)
+        info = M.handle.info()
+        assert info["lanes_per_row"] == _plan_lanes(mean)
+        if info["index_bytes"] == 2:                 # block-structured operator: one 16-bit index per run of columns
+            expect = {1: 1, 3: 3, 6: 6, 9: 9, 12: 12, 22: 11, 44: 11, 90: 15}[bs]
+            assert info["index_group"] == expect, (bs, info)
+            assert info["algorithmic_bytes"] == (8 * infl.A.nnz + 2 * (infl.A.nnz // expect) + 64 * info["row_blocks"]
+                                                 + 4 * (infl.A.shape[0] + 1) + 16 * infl.A.shape[0])
         seen.add((mean >= 32, _plan_lanes(mean)))
         if bs <= 12:
             _spmv_check(hip_engine, infl.B, seed=5, alpha=2.0, beta=-1.0)

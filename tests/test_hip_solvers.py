@@ -1040,7 +1040,10 @@ def test_time_stepping_on_gpu(hip_engine):
     import scipy.sparse as sp
     import scipy.sparse.linalg as spl
     m_u = np.full(s.n_u, s.h ** s.dim)
-    t2 = spl.spsolve((sp.diags(m_u) + ns.timestep * s.A).tocsc(), ns.f.vec.numpy() - s.A @ u0)
+    cops = s.convection_operators()                       # temp = conv(u) + f - A u (:429-431)
+    adv, avg, dif = cops["adv"] @ u0, cops["avg"] @ u0, cops["diff"] @ u0
+    conv = -(cops["div"] @ (adv * avg - 0.5 * np.abs(adv) * dif))
+    t2 = spl.spsolve((sp.diags(m_u) + ns.timestep * s.A).tocsc(), conv + ns.f.vec.numpy() - s.A @ u0)
     du = (ns.gfu.numpy() - u0) / ns.timestep
     assert np.linalg.norm(s.B @ ns.gfu.numpy()) < 1e-5 * np.linalg.norm(ns.gfu.numpy()) * abs(s.B).max()
     # du is the divergence-free part of t2: their difference is a discrete gradient M_u^-1 B^T phi
