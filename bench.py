@@ -362,7 +362,8 @@ def main():
         if run.native is not None:
             comm_kind += " + native loop (%s)" % ("exchange overlapped with the interior rows" if run.overlap
                                                   else "exchange, then SpMV, on one stream")
-        run.start(tol=0.0, maxsteps=total_its)
+        prof_its = 30
+        run.start(tol=0.0, maxsteps=total_its + prof_its)
         run.iterate(0, W)
         torch.cuda.synchronize()
         dist.barrier()
@@ -396,6 +397,9 @@ def main():
         k2_ms = sum(a.elapsed_time(b) for a, b in marks[4:]) / (len(marks) - 4)
         k2_gbs = k2_bytes / (k2_ms * 1e-3) / 1e9
         dist.barrier()
+        # which collective costs what: per-phase device times of further iterations of the SAME loop
+        phase_ms, phase_n = run.profile(total_its, prof_its)
+        dist.barrier()
         if rank == 0:
             out = {
                 "metric": "Krylov iters/sec, 3D SIMPLE Stokes solve (BPCG)", "value": K / elapsed, "unit": "iters/s",
@@ -412,6 +416,7 @@ def main():
                 "cpu_baseline": None,
                 "valid": ok, "halo_doubles_per_rank": run.halo_summary(), "comm": comm_kind,
                 "ms_per_iteration_by_path_rank0": crosscheck_ms or None, "rehearsed_best_path": TIERS[tier_level],
+                "phase_ms_rank0": phase_ms, "phase_iterations": phase_n,
             }
             emit(result_fd, out)
         dist.destroy_process_group()

@@ -369,6 +369,16 @@ NSS_API int nss_dist_destroy(nss_dist_t d);
 NSS_API int nss_bpcg2_iterate_dist(const nss_bpcg2_t* s, nss_dist_t d, const nss_halo_t* halo_s1,
                                    const nss_halo_t* halo_t1, const nss_halo_t* halo_t4, int32_t overlap,
                                    int32_t it_begin, int32_t it_end, nss_stream_t stream);
+/* Per-phase device times of the native partitioned loop: between _begin and _end every iteration issued by
+ * nss_bpcg2_iterate_dist (up to max_iterations) records 9 HIP events on the compute stream; _end waits for them
+ * and returns the average duration (ms) of the 8 segments between them:
+ *   0 K1 (B^T rows; + the s1 exchange unless that operand is kept by recurrence) + preA,  1 t1 halo exchange,
+ *   2 K2 (A rows),  3 K3 (B rows; + the t4 exchange if any) + local sum,  4 all-reduce <s, K s>,
+ *   5 K4 + local sum,  6 all-reduce <w, d>,  7 K5.   (Non-overlapped mode; what tells WHICH collective costs
+ * what on a real node.) */
+NSS_API int nss_dist_profile_begin(nss_dist_t d, int32_t max_iterations);
+NSS_API int nss_dist_profile_end(nss_dist_t d, double* h_segment_ms /* 8 */, int32_t* iterations);
+
 
 /* ---- fused preconditioned conjugate gradients -------------------------------------------------
  * The inner solver of the reference's time stepping (`CGSolver(mstar.mat, pre=..)`,

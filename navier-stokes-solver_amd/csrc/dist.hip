@@ -17,6 +17,8 @@
 
 #include <dlfcn.h>
 
+#include <vector>
+
 struct nss_dist_s {
   void* comm = nullptr;
   int nranks = 1, rank = 0;
@@ -30,9 +32,18 @@ struct nss_dist_s {
   int (*GroupStart)() = nullptr;
   int (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
+  // per-phase profile of the native loop (nss_dist_profile_begin / _end): kProfMarks events per iteration
+  std::vector<hipEvent_t> prof_ev;
+  int prof_cap = 0, prof_iters = 0;
 };
 
 namespace nss {
+
+// marks of one profiled iteration: segment i = [mark i, mark i + 1)
+//   0 K1 (B^T rows, incl. the s1 exchange when that operand is not kept by recurrence) + preA
+//   1 halo exchange of t1      2 K2 (A rows)      3 K3 (B rows, incl. the t4 exchange if any) + local sum
+//   4 all-reduce <s, K s>      5 K4 (+ ghost rows of B) + local sum      6 all-reduce <w, d>      7 K5
+constexpr int kProfMarks = 9;
 
 constexpr int kNcclFloat64 = 8;
 constexpr int kNcclSum = 0;
@@ -91,20 +102,24 @@ static void exchange(const nss_dist_s& d, const nss_halo_t& h, hipStream_t st) {
   nccl_check(d, d.GroupEnd(), "ncclGroupEnd");
 }
 
-// one SpMV phase with its operand exchange, optionally overlapped
+// one SpMV phase with its operand exchange, optionally overlapped.  `mark` (profiling, non-overlapped
+// path only) is recorded between the exchange and the SpMV.
 static void spmv_with_halo(const nss_bpcg2_t& s, const nss_dist_s& d, const nss_halo_t& h, int slot, int which,
-                           int it, const nss_csr_s& mat, int overlap_mode, hipStream_t cs) {
+                           int it, const nss_csr_s& mat, int overlap_mode, hipStream_t cs, hipEvent_t mark = nullptr) {
   const bool talks = d.nranks > 1 && (h.n_send > 0 || h.n_recv > 0);
   const bool overlap = overlap_mode != 0;
   if (!talks && overlap_mode < 2) {   // modes 2, 3: keep the split path without peers (tests, measurements)
+    if (mark) NSS_HIP(hipEventRecord(mark, cs));
     bpcg2_spmv_phase(s, which, it, cs, 0, -1);
     return;
   }
   if (!overlap) {
     exchange(d, h, cs);
+    if (mark) NSS_HIP(hipEventRecord(mark, cs));
     bpcg2_spmv_phase(s, which, it, cs, 0, -1);
     return;
   }
+  if (mark) NSS_HIP(hipEventRecord(mark, cs));
   if (overlap_mode == 3) {             // measurement only: the split launches without the second stream
     exchange(d, h, cs);
     const bool has_suffix = h.int_end < mat.nblk;
@@ -196,7 +211,38 @@ int nss_dist_destroy(nss_dist_t d) {
       if (d->ev_halo[i]) (void)hipEventDestroy(d->ev_halo[i]);
     }
     if (d->xstream) (void)hipStreamDestroy(d->xstream);
+    for (hipEvent_t e : d->prof_ev) (void)hipEventDestroy(e);
     delete d;   // the library handle stays loaded (it is the process-wide librccl)
+  });
+}
+
+int nss_dist_profile_begin(nss_dist_t d, int32_t max_iterations) {
+  return guarded([&] {
+    NSS_REQUIRE(d != nullptr && max_iterations >= 1 && max_iterations <= 4096, "dist_profile_begin: bad argument");
+    for (hipEvent_t e : d->prof_ev) (void)hipEventDestroy(e);
+    d->prof_ev.assign(size_t(max_iterations) * kProfMarks, nullptr);
+    for (hipEvent_t& e : d->prof_ev) NSS_HIP(hipEventCreate(&e));
+    d->prof_cap = max_iterations;
+    d->prof_iters = 0;
+  });
+}
+
+int nss_dist_profile_end(nss_dist_t d, double* h_segment_ms, int32_t* iterations) {
+  return guarded([&] {
+    NSS_REQUIRE(d != nullptr && h_segment_ms != nullptr, "dist_profile_end: NULL argument");
+    const int n = d->prof_iters;
+    for (int sgm = 0; sgm < kProfMarks - 1; ++sgm) h_segment_ms[sgm] = 0.0;
+    if (n > 0) NSS_HIP(hipEventSynchronize(d->prof_ev[size_t(n) * kProfMarks - 1]));
+    for (int it = 0; it < n; ++it)
+      for (int sgm = 0; sgm < kProfMarks - 1; ++sgm) {
+        float ms = 0.0f;
+        NSS_HIP(hipEventElapsedTime(&ms, d->prof_ev[size_t(it) * kProfMarks + sgm], d->prof_ev[size_t(it) * kProfMarks + sgm + 1]));
+        h_segment_ms[sgm] += double(ms) / n;
+      }
+    if (iterations) *iterations = n;
+    for (hipEvent_t e : d->prof_ev) (void)hipEventDestroy(e);
+    d->prof_ev.clear();
+    d->prof_cap = d->prof_iters = 0;
   });
 }
 
@@ -215,18 +261,31 @@ int nss_bpcg2_iterate_dist(const nss_bpcg2_t* s, nss_dist_t d, const nss_halo_t*
     hipStream_t cs = as_stream(stream);
     const int ov = overlap;
     for (int it = it_begin; it < it_end; ++it) {
+      hipEvent_t* ev = d->prof_iters < d->prof_cap ? &d->prof_ev[size_t(d->prof_iters) * kProfMarks] : nullptr;
+      auto mark = [&](int i) {
+        if (ev) NSS_HIP(hipEventRecord(ev[i], cs));
+      };
+      mark(0);
       if (s->ghost_p_mode) bpcg2_spmv_phase(*s, NSS_BPCG2_K1, it, cs, 0, -1);   // s1's ghosts are kept up to date locally
       else spmv_with_halo(*s, *d, *halo_s1, 0, NSS_BPCG2_K1, it, *s->BT, ov, cs);
       bpcg2_k1_finish(*s, cs);
-      spmv_with_halo(*s, *d, *halo_t1, 1, NSS_BPCG2_K2, it, *s->A, ov, cs);
+      mark(1);
+      spmv_with_halo(*s, *d, *halo_t1, 1, NSS_BPCG2_K2, it, *s->A, ov, cs, ev ? ev[2] : nullptr);
+      mark(3);
       if (s->ghost_mode) bpcg2_spmv_phase(*s, NSS_BPCG2_K3, it, cs, 0, -1);   // t4's ghosts were computed in K2
       else spmv_with_halo(*s, *d, *halo_t4, 2, NSS_BPCG2_K3, it, *s->B, ov, cs);
       bpcg2_phase(*s, NSS_BPCG2_SUM1, it, cs);
+      mark(4);
       allreduce_slot(*s, *d, S_AS_SLOT, cs);
+      mark(5);
       bpcg2_phase(*s, NSS_BPCG2_K4, it, cs);       // alpha inside
       bpcg2_phase(*s, NSS_BPCG2_SUM2, it, cs);
+      mark(6);
       allreduce_slot(*s, *d, S_WDN_SLOT, cs);
+      mark(7);
       bpcg2_phase(*s, NSS_BPCG2_K5, it, cs);       // beta, history, stop test inside
+      mark(8);
+      if (ev) ++d->prof_iters;
     }
   });
 }

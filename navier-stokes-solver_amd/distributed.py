@@ -693,6 +693,55 @@ class DistributedBpcg2:
                 else:                                    # local sum in scal[8 + what] -> global in scal[what]
                     comm.allreduce_sum_into(loop.scal[8 + what:9 + what], loop.scal[what:what + 1])
 
+    PHASE_NAMES = ("K1_BT_preA", "exchange_t1", "K2_A", "K3_B_sum", "allreduce_sKs", "K4_sum", "allreduce_wd", "K5")
+
+    def profile(self, it_begin, iterations):
+        """Per-phase device times (ms, averaged) of `iterations` further iterations.  Native loop: HIP
+        events recorded by the C loop itself (nss_dist_profile_*); Python-driven schedule: torch events
+        around the same segments (includes the host's issue gaps)."""
+        import ctypes as C
+        eng = self.engine
+        if self.native is not None:
+            eng._check(eng.lib.nss_dist_profile_begin(self.native[0], int(iterations)))
+            self.iterate(it_begin, it_begin + iterations)
+            out = (C.c_double * 8)()
+            n = C.c_int32()
+            eng._check(eng.lib.nss_dist_profile_end(self.native[0], out, C.byref(n)))
+            return dict(zip(self.PHASE_NAMES, [float(v) for v in out])), n.value
+        torch = eng.torch
+        loop, comm = self.loop, self.comm
+        acc = [0.0] * 8
+        marks = []
+        for it in range(it_begin, it_begin + iterations):
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(9)]
+            ev[0].record()
+            if not getattr(self, "ghost_p_mode", False):
+                self.halo["s1"][0].exchange(self.halo["s1"][1])
+            loop.phases("K1", "K1", it)
+            ev[1].record()
+            self.halo["t1"][0].exchange(self.halo["t1"][1])
+            ev[2].record()
+            loop.phases("K2", "K2", it)
+            ev[3].record()
+            if not self.ghost_mode:
+                self.halo["t4"][0].exchange(self.halo["t4"][1])
+            loop.phases("K3", "SUM1", it)
+            ev[4].record()
+            comm.allreduce_sum_into(loop.scal[9:10], loop.scal[1:2])
+            ev[5].record()
+            loop.phases("ALPHA", "SUM2", it)
+            ev[6].record()
+            comm.allreduce_sum_into(loop.scal[10:11], loop.scal[2:3])
+            ev[7].record()
+            loop.phases("BETA", "K5", it)
+            ev[8].record()
+            marks.append(ev)
+        torch.cuda.synchronize()
+        for ev in marks:
+            for k in range(8):
+                acc[k] += ev[k].elapsed_time(ev[k + 1]) / len(marks)
+        return dict(zip(self.PHASE_NAMES, acc)), len(marks)
+
     def poll(self):
         return self.loop.poll()
 

@@ -61,6 +61,8 @@ def _signatures():
         "nss_csr_row_blocks": (C.c_int, [vp, vp, i64]),
         "nss_dist_create": (C.c_int, [vp, i32, i32, C.POINTER(vp)]),
         "nss_dist_destroy": (C.c_int, [vp]),
+        "nss_dist_profile_begin": (C.c_int, [vp, i32]),
+        "nss_dist_profile_end": (C.c_int, [vp, c_double_p, c_i32_p]),
         "nss_bpcg2_iterate_dist": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, vp]),
         "nss_diag_apply_f64": (C.c_int, [i64, vp, dbl, vp, dbl, vp, vp]),
         "nss_bjac_create": (C.c_int, [vp, i32, i32, vp, C.POINTER(vp)]),

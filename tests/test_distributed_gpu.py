@@ -153,6 +153,44 @@ def test_native_partitioned_loop_split_and_streams_single_rank(hip_engine, tmp_p
         dist.destroy_process_group()
 
 
+def test_native_loop_profile_and_frozen_scalars_single_rank(hip_engine, tmp_path):
+    """(i) nss_dist_profile_*: the native partitioned loop reports the average device time of its eight
+    phases (two of them the all-reduces, one the halo exchange) -- what tells which collective costs what
+    on a real node.  (ii) Once the stop flag is set, further enqueued iterations leave the poll-visible
+    scalars untouched: the local sums stay in their own slots and the all-reduce is out of place."""
+    import torch
+    import torch.distributed as dist
+    from distributed import DistributedBpcg2
+    from rccl_comm import RcclComm
+    s = mac_stokes(3, 12, 0.01)
+    f, g = s.rhs(0)
+    dist.init_process_group("gloo", init_method="file://" + str(tmp_path / "rdv"), rank=0, world_size=1)
+    try:
+        comm = RcclComm(dist, hip_engine)
+        for native in (True, False):
+            run = DistributedBpcg2(s, f, g, s.line_blocks(3), dist, hip_engine, comm=comm, native=native)
+            assert (run.native is not None) == native
+            run.start(tol=0.0, maxsteps=64)
+            run.iterate(0, 8)
+            phases, n = run.profile(8, 12)
+            assert n == 12 and set(phases) == set(run.PHASE_NAMES)
+            assert all(v >= 0.0 for v in phases.values()) and phases["K2_A"] > 0.0 and phases["K4_sum"] > 0.0
+            assert sum(phases.values()) < 50.0                                 # ms per iteration: sane
+        run = DistributedBpcg2(s, f, g, s.line_blocks(3), dist, hip_engine, comm=comm)
+        it, conv = run.solve(tol=1e-6, maxsteps=4000, poll_every=16)
+        assert conv
+        before = hip_engine.to_host(run.loop.scal).copy()
+        hist_before = run.history(it).copy()
+        run.iterate(it + 1, it + 20)                                           # all no-ops on the device
+        done, it_final, _ = run.poll()
+        assert done and it_final == it
+        np.testing.assert_array_equal(hip_engine.to_host(run.loop.scal), before)
+        np.testing.assert_array_equal(run.history(it), hist_before)
+        comm.close()
+    finally:
+        dist.destroy_process_group()
+
+
 def test_interior_row_blocks_of_a_partitioned_matrix(hip_engine):
     """Row blocks flagged interior must not reference ghost columns; boundary blocks sit at the
     slab ends (checked on rank 1 of 3 without any communication)."""
