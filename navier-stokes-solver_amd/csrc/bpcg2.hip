@@ -247,14 +247,36 @@ struct K4Args {
 // 5.5 TB/s for <= 2048 striding workgroups).
 constexpr int kK4PerBlock = 2 * kBlock;
 
-template <bool VEC2>
+template <bool VEC2, bool FOLD>
 __global__ __launch_bounds__(kBlock) void bpcg2_k4_kernel(K4Args a) {
   __shared__ double lds[kRedDoubles];
   if (a.ctrl[C_DONE] != 0) return;
+  // the lane's operands are requested before the sum of the partials: both latencies overlap
+  const int wg0 = blockIdx.x;
+  const int e0 = ((wg0 < a.gu ? wg0 : wg0 - a.gu) * kBlock + int(threadIdx.x)) * 2;
+  double2 q0{}, q1{}, q2{}, q3{}, q4{}, q5{};
+  const bool vec_u = VEC2 && wg0 < a.gu && e0 + 1 < a.n_u;
+  const bool vec_p = VEC2 && wg0 >= a.gu && wg0 < a.gu + a.gp && e0 + 1 < a.n_p;
+  if (vec_u) {
+    q0 = ld2(a.t0 + e0);
+    q1 = ld2(a.t1 + e0);
+    q2 = ld2(a.t2 + e0);
+    q3 = ld2(a.d0 + e0);
+    q4 = ld2(a.w0 + e0);
+  } else if (vec_p) {
+    q0 = ld2(a.s1 + e0);
+    q1 = ld2(a.t3 + e0);
+    q2 = ld2(a.minv + e0);
+    q3 = ld2(a.u1 + e0);
+    q4 = ld2(a.d1 + e0);
+    q5 = ld2(a.w1 + e0);
+  }
   // alpha = wd / <s, K^ s> (:226), evaluated by every lane from the (all-)reduced sum.
   // <s, K^ s> == 0: the reference raises ZeroDivisionError in Python; freeze the state and report
   // it (ctrl[3]) so that the host can raise the same error.
-  const double as_s = a.fold ? fixed_sum_1024(a.pa, a.na, a.pb, a.nb, lds) : a.scal[S_AS];
+  double as_s;
+  if constexpr (FOLD) as_s = fixed_sum_1024(a.pa, a.na, a.pb, a.nb, lds);
+  else as_s = a.scal[S_AS];
   if (as_s == 0.0) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
       a.ctrl[C_BREAKDOWN] = 1;
@@ -269,16 +291,14 @@ __global__ __launch_bounds__(kBlock) void bpcg2_k4_kernel(K4Args a) {
     a.scal[S_ALPHA] = alpha;          // K1 of the next iteration
     a.ctrl[C_PENDING] = a.it + 1;     // ... which also applies u0 += alpha s0
     a.ctrl[C_COMPUTED] = a.it + 1;
-    if (a.fold) a.scal[S_AS] = as_s;  // for the host's eyes only
+    if (FOLD) a.scal[S_AS] = as_s;    // for the host's eyes only
   }
   const int wg = blockIdx.x;
   double acc = 0.0;
   if (wg < a.gu) {
     const int i0 = (wg * kBlock + int(threadIdx.x)) * 2;
-    if (VEC2 && i0 + 1 < a.n_u) {
-      const double2 t0v = *reinterpret_cast<const double2*>(a.t0 + i0), t1v = *reinterpret_cast<const double2*>(a.t1 + i0);
-      const double2 t2v = *reinterpret_cast<const double2*>(a.t2 + i0);
-      const double2 d = *reinterpret_cast<const double2*>(a.d0 + i0), w = *reinterpret_cast<const double2*>(a.w0 + i0);
+    if (vec_u) {
+      const double2 t0v = q0, t1v = q1, t2v = q2, d = q3, w = q4;
       double2 dn, wn;
       dn.x = fma(-alpha, t2v.x - t0v.x, d.x);
       dn.y = fma(-alpha, t2v.y - t0v.y, d.y);
@@ -299,11 +319,9 @@ __global__ __launch_bounds__(kBlock) void bpcg2_k4_kernel(K4Args a) {
     }
   } else if (wg < a.gu + a.gp) {
     const int i0 = ((wg - a.gu) * kBlock + int(threadIdx.x)) * 2;
-    if (VEC2 && i0 + 1 < a.n_p) {
-      const double2 sv = *reinterpret_cast<const double2*>(a.s1 + i0), t3v = *reinterpret_cast<const double2*>(a.t3 + i0);
-      const double2 mv = *reinterpret_cast<const double2*>(a.minv + i0);
-      double2 u = *reinterpret_cast<const double2*>(a.u1 + i0);
-      const double2 d = *reinterpret_cast<const double2*>(a.d1 + i0), w = *reinterpret_cast<const double2*>(a.w1 + i0);
+    if (vec_p) {
+      const double2 sv = q0, t3v = q1, mv = q2, d = q4, w = q5;
+      double2 u = q3;
       u.x = fma(alpha, sv.x, u.x);
       u.y = fma(alpha, sv.y, u.y);
       double2 dn, wn;
@@ -399,9 +417,12 @@ struct CloseArgs {
 // The books of iteration it - 1, evaluated by every workgroup of C1(it) from the same inputs (what K5
 // did with one lane): wdn, beta = wdn / wd (:236), history entry (:243), stop test (:246), wd of the next
 // iteration.  Workgroup 0 records them.  Returns false when the loop stops at iteration it - 1.
+template <bool FOLD>
 __device__ __forceinline__ bool close_iteration(const CloseArgs& a, int it, double* lds, double* beta_out) {
   const int prev = it - 1;
-  const double wdn = a.fold ? fixed_sum_1024(a.partials_c, a.nc, a.partials_c, 0, lds) : a.scal[S_WDN];
+  double wdn;
+  if constexpr (FOLD) wdn = fixed_sum_1024(a.partials_c, a.nc, a.partials_c, 0, lds);
+  else wdn = a.scal[S_WDN];
   const double wd = a.scal[wd_slot(prev)];
   const double beta = wdn / wd;
   const double err = sqrt(fabs(wd));
@@ -410,7 +431,7 @@ __device__ __forceinline__ bool close_iteration(const CloseArgs& a, int it, doub
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     a.scal[S_BETA] = beta;
     a.scal[wd_slot(it)] = wdn;
-    if (a.fold) a.scal[S_WDN] = wdn;
+    if (FOLD) a.scal[S_WDN] = wdn;
     a.hist[prev] = err;
     a.ctrl[C_LAST_IT] = prev;
     a.ctrl[C_CLOSED] = it;
@@ -430,10 +451,14 @@ __global__ __launch_bounds__(kBlock) void bpcg2_close_kernel(CloseArgs a) {
   const int computed = a.ctrl[C_COMPUTED];
   if (a.ctrl[C_CLOSED] >= computed) return;
   double beta;
-  close_iteration(a, computed, lds, &beta);
+  if (a.fold) close_iteration<true>(a, computed, lds, &beta);
+  else close_iteration<false>(a, computed, lds, &beta);
 }
 
-// C1: K1 with the books of the previous iteration in front and the operand beta * s1 + w1 on the fly
+// C1: K1 with the books of the previous iteration in front and the operand beta * s1 + w1 on the fly.
+// FOLD (short sums) is a template parameter: the registers of the in-kernel sum must not cost the
+// bandwidth-bound large systems their occupancy.
+template <bool FOLD>
 struct EpiK1c {
   CloseArgs cl;
   double* __restrict__ u0;
@@ -456,7 +481,7 @@ struct EpiK1c {
     if (it == 0) return true;
     alpha = cl.scal[S_ALPHA];
     pending = cl.ctrl[C_PENDING] == it;
-    return close_iteration(cl, it, lds, &beta);
+    return close_iteration<FOLD>(cl, it, lds, &beta);
   }
   struct X {
     const double* __restrict__ s1;
@@ -466,15 +491,22 @@ struct EpiK1c {
     __device__ double operator()(int c) const { return first ? s1[c] : fma(beta, s1[c], w1[c]); }   // :240-241
   };
   __device__ X xop(const double*) const { return X{s1, w1, beta, it == 0}; }
-  __device__ void row(int r, double bts) const {
-    double qv = q[r];
+  // the row's six read-only operands are requested before the matrix stream (and before alpha / beta
+  // are known: the prologue runs later)
+  struct Pre { double q = 0.0, z0 = 0.0, t2 = 0.0, s0 = 0.0, w0 = 0.0, u0 = 0.0; };
+  __device__ Pre fetch(int r) const {
+    if (it == 0) return Pre{q[r], 0.0, 0.0, 0.0, 0.0, 0.0};
+    return Pre{q[r], z0[r], t2[r], s0[r], w0[r], u0[r]};
+  }
+  __device__ void row(int r, double bts, const Pre& p) const {
+    double qv = p.q;
     if (it != 0) {
-      const double zo = z0[r], t2v = t2[r], so = s0[r];
-      if (pending) NSS_ST(u0[r], fma(alpha, so, u0[r]));   // deferred u += alpha s of iteration it - 1
+      const double zo = p.z0, t2v = p.t2, so = p.s0;
+      if (pending) NSS_ST(u0[r], fma(alpha, so, p.u0));    // deferred u += alpha s of iteration it - 1
       qv = fma(-alpha, t2v, fma(beta, qv, zo));
       NSS_ST(z0[r], fma(-alpha, t2v, zo));
       NSS_ST(q[r], qv);
-      NSS_ST3(s0[r], fma(beta, so, w0[r]));
+      NSS_ST3(s0[r], fma(beta, so, p.w0));
     }
     const double t = qv + bts;
     NSS_ST3(t0[r], t);
@@ -577,8 +609,10 @@ static void launch_k4(const nss_bpcg2_t& s, int it, bool fold, hipStream_t st) {
                         (const void*)s.s1, (const void*)s.t0, (const void*)s.t1, (const void*)s.t2, (const void*)s.t3,
                         (const void*)s.minv})
     vec = vec && aligned16(p);
-  if (vec) hipLaunchKernelGGL(bpcg2_k4_kernel<true>, dim3(grid), dim3(kBlock), 0, st, a);
-  else hipLaunchKernelGGL(bpcg2_k4_kernel<false>, dim3(grid), dim3(kBlock), 0, st, a);
+  if (vec && fold) hipLaunchKernelGGL((bpcg2_k4_kernel<true, true>), dim3(grid), dim3(kBlock), 0, st, a);
+  else if (vec) hipLaunchKernelGGL((bpcg2_k4_kernel<true, false>), dim3(grid), dim3(kBlock), 0, st, a);
+  else if (fold) hipLaunchKernelGGL((bpcg2_k4_kernel<false, true>), dim3(grid), dim3(kBlock), 0, st, a);
+  else hipLaunchKernelGGL((bpcg2_k4_kernel<false, false>), dim3(grid), dim3(kBlock), 0, st, a);
   NSS_CHECK_LAUNCH();
 }
 
@@ -725,9 +759,13 @@ void bpcg2_cphase(const nss_bpcg2_t& s, int which, int it, hipStream_t st) {
   const bool fold = fold_sums(s);
   switch (which) {
     case NSS_BPCG2C_C1: {
-      EpiK1c e{close_args(s, fold), s.u0, s.q, s.z0, s.t2, s.s0, s.w0, s.t0, s.t1,
-               (s.pre_amg || s.cond_HT) ? nullptr : s.pre_diag, s.k, it, s.s1, s.w1};
-      launch_csr_stream(*s.BT, s.s1, e, st);
+      const double* dinv = (s.pre_amg || s.cond_HT) ? nullptr : s.pre_diag;
+      if (fold)
+        launch_csr_stream(*s.BT, s.s1, EpiK1c<true>{close_args(s, true), s.u0, s.q, s.z0, s.t2, s.s0, s.w0, s.t0, s.t1,
+                                                    dinv, s.k, it, s.s1, s.w1}, st);
+      else
+        launch_csr_stream(*s.BT, s.s1, EpiK1c<false>{close_args(s, false), s.u0, s.q, s.z0, s.t2, s.s0, s.w0, s.t0, s.t1,
+                                                     dinv, s.k, it, s.s1, s.w1}, st);
       bpcg2_k1_finish(s, st);
       break;
     }

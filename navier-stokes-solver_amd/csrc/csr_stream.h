@@ -179,9 +179,13 @@ struct EpiPrologue<E, std::void_t<decltype(std::declval<E&>().prologue(static_ca
 constexpr int kRedDoubles = 32;   // per-workgroup reduction scratch (block_sum: 4, fixed_sum_1024: 32)
 
 // One workgroup = one row block: `wg` is the workgroup's index inside this launch's grid part.
-template <int RG, class Epi, bool C16, int CH, bool GRP, class X>
-__device__ __forceinline__ void csr_stream_body(const CsrView& a, const X& xop, Epi& epi, int wg, double* prod,
-                                                double* red, int32_t* window) {
+// The epilogue's optional prologue (sum of the previous kernel's dot partials -> alpha / beta) runs AFTER the
+// row block's col / val loads have been issued and before the operand gather, which is the first thing that
+// may need its result: the partials arrive while the matrix stream is in flight instead of in front of it
+// (small, launch-bound systems: ~2 us per kernel).  A prologue that returns false ends the workgroup.
+template <int RG, class Epi, bool C16, int CH, bool GRP>
+__device__ __forceinline__ void csr_stream_body(const CsrView& a, const double* __restrict__ x, Epi& epi, int wg,
+                                                double* prod, double* red, int32_t* window) {
   const int tid = threadIdx.x;
   // XCD-aware map: workgroups with equal (index & 7) share an XCD; XCD i owns the i-th
   // contiguous eighth of the row blocks.  One row block per workgroup: a striding
@@ -239,6 +243,8 @@ __device__ __forceinline__ void csr_stream_body(const CsrView& a, const X& xop, 
         v[k] = live ? a.val[p0 + i] : 0.0;
 #endif
       }
+      if (!EpiPrologue<Epi>::run(epi, red)) return;        // uniform over the workgroup
+      const auto xop = EpiX<Epi>::get(epi, x);
       if (C16) {
         __syncthreads();                                   // window bases in LDS
 #pragma unroll
@@ -283,6 +289,8 @@ __device__ __forceinline__ void csr_stream_body(const CsrView& a, const X& xop, 
 #endif
     } else {
       // ---- one row longer than the LDS chunk: the whole workgroup reduces it ----------
+      if (!EpiPrologue<Epi>::run(epi, red)) return;
+      const auto xop = EpiX<Epi>::get(epi, x);
       double acc = 0.0;
       for (int i = tid; i < cnt; i += kBlock) acc = fma(a.val[p0 + i], xop(a.col[p0 + i]), acc);
       const double sum = block_sum(acc, red);
@@ -298,8 +306,7 @@ __global__ __launch_bounds__(kBlock) void csr_stream_kernel(CsrView a, const dou
   __shared__ double red[kRedDoubles];
   __shared__ int32_t window[kWindows];
   if (epi.skip()) return;
-  if (!EpiPrologue<Epi>::run(epi, red)) return;
-  csr_stream_body<RG, Epi, C16, CH, GRP>(a, EpiX<Epi>::get(epi, x), epi, int(blockIdx.x), prod, red, window);
+  csr_stream_body<RG, Epi, C16, CH, GRP>(a, x, epi, int(blockIdx.x), prod, red, window);
 }
 
 // Two matrices with the same launch-plan parameters in ONE launch: workgroups [0, grid_a) stream the
@@ -314,12 +321,10 @@ __global__ __launch_bounds__(kBlock) void csr_stream_dual_kernel(CsrView a, CsrV
   __shared__ int32_t window[kWindows];
   if (int(blockIdx.x) < grid_a) {
     if (ea.skip()) return;
-    if (!EpiPrologue<EpiA>::run(ea, red)) return;
-    csr_stream_body<RG, EpiA, C16, CH, GRP>(a, EpiX<EpiA>::get(ea, xa), ea, int(blockIdx.x), prod, red, window);
+    csr_stream_body<RG, EpiA, C16, CH, GRP>(a, xa, ea, int(blockIdx.x), prod, red, window);
   } else {
     if (eb.skip()) return;
-    if (!EpiPrologue<EpiB>::run(eb, red)) return;
-    csr_stream_body<RG, EpiB, C16, CH, GRP>(b, EpiX<EpiB>::get(eb, xb), eb, int(blockIdx.x) - grid_a, prod, red, window);
+    csr_stream_body<RG, EpiB, C16, CH, GRP>(b, xb, eb, int(blockIdx.x) - grid_a, prod, red, window);
   }
 }
 

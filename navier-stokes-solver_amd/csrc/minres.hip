@@ -30,7 +30,12 @@ namespace nss {
 
 enum {
   M_DELTA = 0, M_GAMMA = 1, M_G2 = 2, M_ETA_OLD = 3, M_C_OLD = 4, M_C = 5, M_S_OLD = 6, M_S = 7,
-  M_RES_OLD = 8, M_ERR0 = 9, M_TOL = 10, M_A1 = 11, M_A2 = 12, M_A3 = 13, M_UCOEF = 14, M_INVG = 15
+  M_RES_OLD = 8, M_ERR0 = 9, M_TOL = 10, M_A1 = 11, M_A2 = 12, M_A3 = 13, M_UCOEF = 14, M_INVG = 15,
+  // z, v and v_old are kept UN-normalised: the reference's `z_new *= 1/gamma_new; v_new *= 1/gamma_new`
+  // (:104-105) would cost four vector passes per iteration; instead every consumer multiplies the raw
+  // entry by the vector's factor -- fl(raw * factor) is exactly the double the in-place scaling would have
+  // stored, so the history is unchanged.  Factors of the current z, the current v and v_old:
+  M_SZ = 16, M_SV = 17, M_SVO = 18
 };
 enum { MC_STOP = 0, MC_KSTOP = 1, MC_REASON = 2, MC_LASTK = 3 };
 
@@ -38,30 +43,53 @@ __device__ __forceinline__ bool minres_skip(const int32_t* ctrl, int k) {
   return ctrl[MC_STOP] != 0 && k > ctrl[MC_KSTOP];
 }
 
-struct EpiMStore {  // y = A x
+// operand of the three SpMVs: the current z, stored un-normalised (see M_SZ)
+struct XScaledZ {
+  const double* __restrict__ z;
+  double scale;
+  __device__ double operator()(int c) const { return z[c] * scale; }
+};
+
+struct EpiMStore {  // y = A (scale * x)
   const int32_t* __restrict__ ctrl;
   int k;
   double* __restrict__ y;
+  const double* __restrict__ set;    // scalars of iteration k
+  double sz = 1.0;
   __device__ bool skip() const { return minres_skip(ctrl, k); }
+  __device__ bool prologue(double*) {
+    sz = set[M_SZ];
+    return true;
+  }
+  using X = XScaledZ;
+  __device__ X xop(const double* x) const { return X{x, sz}; }
   __device__ void row(int r, double ax) const { y[r] = ax; }
   __device__ void finish(int, double*) const {}
 };
 
-struct EpiMAccDot {  // y (+)= A x ; partial <y, z>
+struct EpiMAccDot {  // y (+)= A (scale * x) ; partial <y, scale * z>
   const int32_t* __restrict__ ctrl;
   int k;
   int accumulate;
   double* __restrict__ y;
   const double* __restrict__ z;
   double* __restrict__ partials;
+  const double* __restrict__ set;    // scalars of iteration k
   double acc = 0.0;
+  double sz = 1.0;
   __device__ bool skip() const { return minres_skip(ctrl, k); }
+  __device__ bool prologue(double*) {
+    sz = set[M_SZ];
+    return true;
+  }
+  using X = XScaledZ;
+  __device__ X xop(const double* x) const { return X{x, sz}; }
   struct Pre { double y = 0.0, z = 0.0; };
-  __device__ Pre fetch(int r) const { return Pre{accumulate ? y[r] : 0.0, z[r]}; }
+  __device__ Pre fetch(int r) const { return Pre{accumulate ? y[r] : 0.0, z[r]}; }   // (before the prologue)
   __device__ void row(int r, double ax, const Pre& p) {
     const double t = accumulate ? p.y + ax : ax;
     y[r] = t;
-    acc = fma(t, p.z, acc);
+    acc = fma(t, p.z * sz, acc);
   }
   __device__ void finish(int b, double* lds) {
     const double s = block_sum(acc, lds);
@@ -117,95 +145,100 @@ template <int BS>
 __global__ __launch_bounds__(kBlock) void minres_m3_kernel(MK4Args a) {
   __shared__ double lds[kRedDoubles];
   if (minres_skip(a.ctrl, a.k)) return;
-  const double delta = m3_delta(a, lds), gamma = a.scal[M_GAMMA];
+  constexpr int B = BS > 0 ? BS : 1;
   const int wg = blockIdx.x;
-  double acc = 0.0;
-  if (wg < a.gu) {
-    if constexpr (BS == 0) {
-      const int i0 = (wg * kBlock + int(threadIdx.x)) * 2;
-      if (a.vec && i0 + 1 < a.n_u) {
-        const double2 kz = ld2(a.kz0 + i0), v = ld2(a.v0 + i0), vo = ld2(a.vo0 + i0);
-        double2 vn;
-        vn.x = fma(-gamma, vo.x, fma(-delta, v.x, kz.x));
-        vn.y = fma(-gamma, vo.y, fma(-delta, v.y, kz.y));
-        st2(a.vn0 + i0, vn);
-        if (a.dinv) {
-          const double2 dv = ld2(a.dinv + i0);
-          double2 zn;
-          zn.x = dv.x * vn.x;
-          zn.y = dv.y * vn.y;
-          st2(a.zn0 + i0, zn);
-          acc = fma(zn.x, vn.x, acc);
-          acc = fma(zn.y, vn.y, acc);
-        }
-      } else {
-        for (int i = i0; i < i0 + 2 && i < a.n_u; ++i) {
-          const double vn = fma(-gamma, a.vo0[i], fma(-delta, a.v0[i], a.kz0[i]));
-          a.vn0[i] = vn;
-          if (a.dinv) {
-            const double zn = a.dinv[i] * vn;
-            a.zn0[i] = zn;
-            acc = fma(zn, vn, acc);
-          }
-        }
-      }
-    } else {
-      constexpr int B = BS;
-      const int b = wg * kBlock + int(threadIdx.x);
-      if (b < a.nblocks) {
-        const int32_t w = a.run[b], first = w >> 5, len = w & 31;
-        double xv[B], sv[B];
+  const bool velocity = wg < a.gu;
+  // ---- stage 1: this lane's operands are requested before the sum of the partials (delta), so that
+  //      both latencies overlap (launch-bound small systems) -----------------------------------------
+  const int i0 = ((velocity ? wg : wg - a.gu) * kBlock + int(threadIdx.x)) * 2;
+  const int n_part = velocity ? a.n_u : a.n_p;
+  const bool fast = (BS == 0 || !velocity) && a.vec && i0 + 1 < n_part;
+  double2 qkz{}, qv{}, qvo{}, qd{};
+  if (fast) {
+    qkz = ld2((velocity ? a.kz0 : a.kz1) + i0);
+    qv = ld2((velocity ? a.v0 : a.v1) + i0);
+    qvo = ld2((velocity ? a.vo0 : a.vo1) + i0);
+    if (!velocity) qd = ld2(a.minv + i0);
+    else if (a.dinv) qd = ld2(a.dinv + i0);
+  }
+  const int blk = wg * kBlock + int(threadIdx.x);        // BS > 0: one lane per block
+  const bool live = BS > 0 && velocity && blk < a.nblocks;
+  int32_t first = 0, len = 0;
+  double bkz[B], bv[B], bvo[B];
+  if (live) {
+    const int32_t w = a.run[blk];
+    first = w >> 5;
+    len = w & 31;
 #pragma unroll
-        for (int c = 0; c < B; ++c) {
-          double vn = 0.0;
-          if (c < len) {
-            const int i = first + c;
-            vn = fma(-gamma, a.vo0[i], fma(-delta, a.v0[i], a.kz0[i]));
-            a.vn0[i] = vn;
-          }
-          xv[c] = vn;
-          sv[c] = 0.0;
-        }
-        int t = 0;
-#pragma unroll
-        for (int r = 0; r < B; ++r) {
-#pragma unroll
-          for (int c = r; c < B; ++c, ++t) {
-            const double m = a.packed[size_t(t) * a.nblocks + b];
-            sv[r] = fma(m, xv[c], sv[r]);
-            if (c > r) sv[c] = fma(m, xv[r], sv[c]);
-          }
-        }
-#pragma unroll
-        for (int r = 0; r < B; ++r) {
-          if (r < len) {
-            const double zn = sv[r];
-            a.zn0[first + r] = zn;
-            acc = fma(zn, xv[r], acc);
-          }
-        }
-      }
+    for (int c = 0; c < B; ++c) {
+      const bool in = c < len;
+      bkz[c] = in ? a.kz0[first + c] : 0.0;
+      bv[c] = in ? a.v0[first + c] : 0.0;
+      bvo[c] = in ? a.vo0[first + c] : 0.0;
     }
-  } else {
-    const int i0 = ((wg - a.gu) * kBlock + int(threadIdx.x)) * 2;
-    if (a.vec && i0 + 1 < a.n_p) {
-      const double2 kz = ld2(a.kz1 + i0), v = ld2(a.v1 + i0), vo = ld2(a.vo1 + i0), mv = ld2(a.minv + i0);
-      double2 vn, zn;
-      vn.x = fma(-gamma, vo.x, fma(-delta, v.x, kz.x));
-      vn.y = fma(-gamma, vo.y, fma(-delta, v.y, kz.y));
-      zn.x = mv.x * vn.x;
-      zn.y = mv.y * vn.y;
-      st2(a.vn1 + i0, vn);
-      st2(a.zn1 + i0, zn);
+  }
+  // ---- stage 2: the scalars ------------------------------------------------------------------------
+  const double delta = m3_delta(a, lds), gamma = a.scal[M_GAMMA];
+  const double scv = a.scal[M_SV], scvo = a.scal[M_SVO];     // v and v_old are stored un-normalised
+  // ---- stage 3 -------------------------------------------------------------------------------------
+  double acc = 0.0;
+  if (fast) {
+    double2 vn;
+    vn.x = fma(-gamma, qvo.x * scvo, fma(-delta, qv.x * scv, qkz.x));
+    vn.y = fma(-gamma, qvo.y * scvo, fma(-delta, qv.y * scv, qkz.y));
+    st2((velocity ? a.vn0 : a.vn1) + i0, vn);
+    if (!velocity || a.dinv) {
+      double2 zn;
+      zn.x = qd.x * vn.x;
+      zn.y = qd.y * vn.y;
+      st2((velocity ? a.zn0 : a.zn1) + i0, zn);
       acc = fma(zn.x, vn.x, acc);
       acc = fma(zn.y, vn.y, acc);
-    } else {
-      for (int i = i0; i < i0 + 2 && i < a.n_p; ++i) {
-        const double vn = fma(-gamma, a.vo1[i], fma(-delta, a.v1[i], a.kz1[i]));
-        const double zn = a.minv[i] * vn;
-        a.vn1[i] = vn;
-        a.zn1[i] = zn;
+    }
+  } else if (BS == 0 || !velocity) {
+    const double* kz = velocity ? a.kz0 : a.kz1;
+    const double* v = velocity ? a.v0 : a.v1;
+    const double* vo = velocity ? a.vo0 : a.vo1;
+    const double* dd = velocity ? a.dinv : a.minv;
+    double* vnp = velocity ? a.vn0 : a.vn1;
+    double* znp = velocity ? a.zn0 : a.zn1;
+    for (int i = i0; i < i0 + 2 && i < n_part; ++i) {
+      const double vn = fma(-gamma, vo[i] * scvo, fma(-delta, v[i] * scv, kz[i]));
+      vnp[i] = vn;
+      if (dd) {
+        const double zn = dd[i] * vn;
+        znp[i] = zn;
         acc = fma(zn, vn, acc);
+      }
+    }
+  } else if (live) {
+    double xv[B], sv[B];
+#pragma unroll
+    for (int c = 0; c < B; ++c) {
+      double vn = 0.0;
+      if (c < len) {
+        vn = fma(-gamma, bvo[c] * scvo, fma(-delta, bv[c] * scv, bkz[c]));
+        a.vn0[first + c] = vn;
+      }
+      xv[c] = vn;
+      sv[c] = 0.0;
+    }
+    int t = 0;
+#pragma unroll
+    for (int r = 0; r < B; ++r) {
+#pragma unroll
+      for (int c = r; c < B; ++c, ++t) {
+        const double m = a.packed[size_t(t) * a.nblocks + blk];
+        sv[r] = fma(m, xv[c], sv[r]);
+        if (c > r) sv[c] = fma(m, xv[r], sv[c]);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < B; ++r) {
+      if (r < len) {
+        const double zn = sv[r];
+        a.zn0[first + r] = zn;
+        acc = fma(zn, xv[r], acc);
       }
     }
   }
@@ -240,34 +273,10 @@ struct MK5Args {
   int32_t vec;
 };
 
-// the same update for two consecutive entries with 16-byte accesses
-__device__ __forceinline__ void minres_k5_body2(int i, double invg, double a1inv, double a2, double a3, double uc,
-                                                 double* zn, double* vn, double* wn, double* u, const double* z,
-                                                 const double* wo, const double* w) {
-  double2 znv = ld2(zn + i), vnv = ld2(vn + i);
-  const double2 wv = ld2(w + i), wov = ld2(wo + i), zv = ld2(z + i);
-  double2 uv = ld2(u + i);
-  znv.x *= invg;
-  znv.y *= invg;
-  vnv.x *= invg;
-  vnv.y *= invg;
-  double2 t;
-  t.x = fma(-a2, wv.x, fma(-a3, wov.x, zv.x)) * a1inv;
-  t.y = fma(-a2, wv.y, fma(-a3, wov.y, zv.y)) * a1inv;
-  uv.x = fma(uc, t.x, uv.x);
-  uv.y = fma(uc, t.y, uv.y);
-  st2(zn + i, znv);
-  store2_nt(vn + i, vnv);
-  store2_nt(wn + i, t);
-  store2_nt(u + i, uv);
-}
-
-__device__ __forceinline__ void minres_k5_body(int i, double invg, double a1inv, double a2, double a3, double uc,
-                                                double* zn, double* vn, double* wn, double* u, const double* z,
-                                                const double* wo, const double* w) {
-  zn[i] *= invg;
-  NSS_ST(vn[i], vn[i] * invg);
-  double t = fma(-a2, w[i], fma(-a3, wo[i], z[i]));   // :115
+__device__ __forceinline__ void minres_k5_body(int i, double sz, double a1inv, double a2, double a3, double uc,
+                                                double* wn, double* u, const double* z, const double* wo,
+                                                const double* w) {
+  double t = fma(-a2, w[i], fma(-a3, wo[i], z[i] * sz));   // :115 (z un-normalised: see M_SZ)
   t *= a1inv;                                         // :116
   NSS_ST(wn[i], t);                                   // next read one iteration later
   NSS_ST(u[i], fma(uc, t, u[i]));                     // :118
@@ -278,6 +287,18 @@ __global__ __launch_bounds__(kBlock) void minres_m4_kernel(MK5Args a) {
   if (minres_skip(a.ctrl, a.k)) return;
   const double* s = a.scal + m_set(a.k);        // this iteration's scalars (read by every workgroup)
   double* o = a.scal + m_set(a.k + 1);          // next iteration's (written by workgroup 0 only)
+  // this lane's operands first, then the sum of the partials: the two latencies overlap
+  const int wg = blockIdx.x;
+  const bool velocity = wg < a.gu;
+  const int i0 = ((velocity ? wg : wg - a.gu) * kBlock + int(threadIdx.x)) * 2;
+  const bool fast = a.vec && i0 + 1 < (velocity ? a.n_u : a.n_p);
+  double2 qw{}, qwo{}, qz{}, qu{};
+  if (fast) {
+    qw = ld2((velocity ? a.w0 : a.w1) + i0);
+    qwo = ld2((velocity ? a.wo0 : a.wo1) + i0);
+    qz = ld2((velocity ? a.z0 : a.z1) + i0);
+    qu = ld2((velocity ? a.u0 : a.u1) + i0);
+  }
   const double g2 = a.fold ? fixed_sum_1024(a.pa, a.na, a.pb, a.nb, lds) : s[M_G2];
   const double delta = s[M_DELTA], gamma = s[M_GAMMA];
   const double gamma_new = sqrt(g2);                                   // :103
@@ -305,6 +326,9 @@ __global__ __launch_bounds__(kBlock) void minres_m4_kernel(MK5Args a) {
     o[M_RES_OLD] = res;
     o[M_ERR0] = s[M_ERR0];
     o[M_TOL] = s[M_TOL];
+    o[M_SZ] = invg;               // z_new and v_new stay un-normalised (:104-105 applied by their readers)
+    o[M_SV] = invg;
+    o[M_SVO] = s[M_SV];
     if (res < s[M_TOL] * s[M_ERR0]) {                                  // relative break (:126)
       a.ctrl[MC_KSTOP] = a.k;
       a.ctrl[MC_REASON] = 1;
@@ -315,24 +339,21 @@ __global__ __launch_bounds__(kBlock) void minres_m4_kernel(MK5Args a) {
       a.ctrl[MC_STOP] = 1;
     }
   }
-  const double a1inv = 1.0 / alpha1;
-  const int wg = blockIdx.x;
-  if (wg < a.gu) {
-    const int i0 = (wg * kBlock + int(threadIdx.x)) * 2;
-    if (a.vec && i0 + 1 < a.n_u) {
-      minres_k5_body2(i0, invg, a1inv, alpha2, alpha3, uc, a.zn0, a.vn0, a.wn0, a.u0, a.z0, a.wo0, a.w0);
-    } else {
-      for (int i = i0; i < i0 + 2 && i < a.n_u; ++i)
-        minres_k5_body(i, invg, a1inv, alpha2, alpha3, uc, a.zn0, a.vn0, a.wn0, a.u0, a.z0, a.wo0, a.w0);
-    }
+  const double a1inv = 1.0 / alpha1, sz = s[M_SZ];
+  if (fast) {
+    double2 t;
+    t.x = fma(-alpha2, qw.x, fma(-alpha3, qwo.x, qz.x * sz)) * a1inv;      // :115-116
+    t.y = fma(-alpha2, qw.y, fma(-alpha3, qwo.y, qz.y * sz)) * a1inv;
+    qu.x = fma(uc, t.x, qu.x);                                              // :118
+    qu.y = fma(uc, t.y, qu.y);
+    store2_nt((velocity ? a.wn0 : a.wn1) + i0, t);
+    store2_nt((velocity ? a.u0 : a.u1) + i0, qu);
+  } else if (velocity) {
+    for (int i = i0; i < i0 + 2 && i < a.n_u; ++i)
+      minres_k5_body(i, sz, a1inv, alpha2, alpha3, uc, a.wn0, a.u0, a.z0, a.wo0, a.w0);
   } else {
-    const int i0 = ((wg - a.gu) * kBlock + int(threadIdx.x)) * 2;
-    if (a.vec && i0 + 1 < a.n_p) {
-      minres_k5_body2(i0, invg, a1inv, alpha2, alpha3, uc, a.zn1, a.vn1, a.wn1, a.u1, a.z1, a.wo1, a.w1);
-    } else {
-      for (int i = i0; i < i0 + 2 && i < a.n_p; ++i)
-        minres_k5_body(i, invg, a1inv, alpha2, alpha3, uc, a.zn1, a.vn1, a.wn1, a.u1, a.z1, a.wo1, a.w1);
-    }
+    for (int i = i0; i < i0 + 2 && i < a.n_p; ++i)
+      minres_k5_body(i, sz, a1inv, alpha2, alpha3, uc, a.wn1, a.u1, a.z1, a.wo1, a.w1);
   }
 }
 
@@ -401,13 +422,13 @@ static void minres_iteration(const nss_minres_t& s, int k, hipStream_t st) {
   const bool fold = m_fold(s);
   double* set = s.scal + m_set(k);
   // M1: kz0 = B^T z1 and kz1 = B z0 with <kz1, z1>;  M2: kz0 += A z0 with <kz0, z0>
-  EpiMStore e_bt{s.ctrl, k, s.kz[0]};
-  EpiMAccDot e_b{s.ctrl, k, 0, s.kz[1], s.z[zc][1], s.partials_b};
+  EpiMStore e_bt{s.ctrl, k, s.kz[0], set};
+  EpiMAccDot e_b{s.ctrl, k, 0, s.kz[1], s.z[zc][1], s.partials_b, set};
   if (!launch_csr_stream_dual(*s.BT, s.z[zc][1], e_bt, *s.B, s.z[zc][0], e_b, st)) {
     launch_csr_stream(*s.BT, s.z[zc][1], e_bt, st);
     launch_csr_stream(*s.B, s.z[zc][0], e_b, st);
   }
-  launch_csr_stream(*s.A, s.z[zc][0], EpiMAccDot{s.ctrl, k, 1, s.kz[0], s.z[zc][0], s.partials_a}, st);
+  launch_csr_stream(*s.A, s.z[zc][0], EpiMAccDot{s.ctrl, k, 1, s.kz[0], s.z[zc][0], s.partials_a, set}, st);
   if (!fold) {
     hipLaunchKernelGGL(minres_sum_kernel, dim3(1), dim3(kSumLanes), 0, st, s.ctrl, k, s.A->nblk, s.partials_a,
                        s.B->nblk, s.partials_b, set, int(M_DELTA));

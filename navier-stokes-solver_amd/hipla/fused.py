@@ -386,6 +386,7 @@ class MinresLoop:
         scal = np.zeros(64)                 # iteration k = 1 reads the first set
         scal[M_GAMMA], scal[M_ETA_OLD], scal[M_C_OLD], scal[M_C] = gamma, gamma, 1.0, 1.0
         scal[M_RES_OLD], scal[M_ERR0], scal[M_TOL] = gamma, gamma, tol
+        scal[16:19] = 1.0                   # factors of the (here: normalised) z, v, v_old -- see csrc/minres.hip
         eng.upload(scal, self.scal)
         self.ctrl.zero_()
         stop, k_stop, reason, last = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
