@@ -42,11 +42,12 @@ def golden_path(name):
 
 
 def iteration_tolerance(d):
-    """Allowed |iterations - golden|.  SURVEY.md section 8c proposed +-max(2, 1 %); measured here,
-    the CPU oracle itself moves by up to ~2 % when only the summation order of its inner
-    products changes (296 -> 302 on stokes2d_n12_jacobi_bpcg1: the error functional is not
-    monotone near the tolerance).  Every fixture records that spread
-    (``iterations_perturbed``); the band used is max(3, 3 %, twice the recorded spread)."""
+    """Allowed |iterations - golden|: the survey's contract +-max(2, 1 %) (SURVEY.md section 8c ii), widened
+    only where the fixture itself documents that the contract cannot hold: every fixture records by how
+    much the CPU oracle's own count moves when nothing but the summation order of its inner products
+    changes (``iterations_perturbed``; up to ~2 % -- 296 -> 302 on stokes2d_n12_jacobi_bpcg1 -- because the
+    error functional is not monotone near the tolerance), and a count cannot be pinned more tightly than
+    that spread."""
     ref = int(d["iterations"])
     spread = abs(ref - int(d["iterations_perturbed"])) if "iterations_perturbed" in d else 0
-    return max(3, int(0.03 * ref + 0.999), 2 * spread)
+    return max(2, int(0.01 * ref + 0.999), spread)

@@ -1005,14 +1005,22 @@ def test_fused_loops_on_unstructured_saddle_systems(hip_engine, seed):
     assert np.linalg.norm(b - K @ sol.numpy()) < 1e-6 * np.linalg.norm(b)
 
     # BPCG v1 and MINRES: converge to the same solution as the oracle, same iteration counts
-    with contextlib.redirect_stdout(io.StringIO()):
+    out1 = io.StringIO()
+    with contextlib.redirect_stdout(out1):
         x1, errs1 = bramble_pasciak_cg(Ad, Bd, None, preA, preS, hipla.Vector.from_numpy(f), hipla.Vector.from_numpy(g),
                                        tolerance=tol, max_steps=maxsteps, print_rates=False)
+    with contextlib.redirect_stdout(io.StringIO()):
         um, errsm = MinRes(mat=hipla.BlockMatrix([[Ad, Bd.T], [Bd, None]]),
                            pre=hipla.BlockMatrix([[preA, None], [None, preS]]),
                            rhs=hipla.BlockVector([hipla.Vector.from_numpy(f), hipla.Vector.from_numpy(g)]),
                            maxsteps=maxsteps, tol=tol, printrates=False)
-    assert errs1[-1] < tol and len(errs1) < maxsteps       # (v1 estimates its own scale factor: no oracle history)
+    assert errs1[-1] < tol and len(errs1) < maxsteps
+    # v1 estimates its own scale factor (tol 1e-10 Lanczos, :70-71) and prints it: the oracle takes that k
+    k1 = float(re.search(r"scale factor:\s+(\S+)", out1.getvalue()).group(1))
+    errs1_o = kr.bpcg_v1(A, B, pa, ps, f, g, k1, tolerance=tol, max_steps=maxsteps)[2]
+    w1 = min(25, len(errs1), len(errs1_o))
+    np.testing.assert_allclose(np.array(errs1)[:w1], np.array(errs1_o)[:w1], rtol=1e-8)
+    assert abs(len(errs1) - len(errs1_o)) <= max(3, int(0.03 * len(errs1_o)))
     for x in (x1.numpy(), um.numpy()):
         assert np.linalg.norm(b - K @ x) < 1e-6 * np.linalg.norm(b)
         assert np.linalg.norm(x - sol.numpy()) < 1e-5 * np.linalg.norm(sol.numpy())
