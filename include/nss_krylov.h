@@ -431,6 +431,12 @@ typedef struct nss_minres_s {
   double* hist;
   double *partials_a, *partials_b, *partials_c; /* sizes: nss_minres_workspace() */
   int32_t n_u, n_p;
+  /* row-partitioned runs: A, B, BT are the slab's local blocks (ghost columns behind the owned ones; B's
+   * columns numbered in the layout of A's operand), the z ring vectors are the owned views of
+   * halo-extended buffers, and the two sums of an iteration stay local in scal slots 19 / 20 of the
+   * iteration's set until the caller (or nss_minres_iterate_dist) all-reduces them out of place into
+   * slots 0 (delta) / 2 (gamma_new^2). */
+  int32_t local_sums;
 } nss_minres_t;
 
 NSS_API int nss_minres_workspace(const nss_minres_t* s, int64_t* partials_a, int64_t* partials_b,
@@ -439,6 +445,15 @@ NSS_API int nss_minres_workspace(const nss_minres_t* s, int64_t* partials_a, int
 NSS_API int nss_minres_iterate(const nss_minres_t* s, int32_t k_begin, int32_t k_end, nss_stream_t stream);
 NSS_API int nss_minres_poll(const nss_minres_t* s, int32_t* stop, int32_t* k_stop, int32_t* reason,
                             int32_t* last_k, nss_stream_t stream);
+/* phases first..last of iteration k: 1 the three SpMVs (M1 + M2), 2 local sum of delta, 3 M3 (+ a
+ * preconditioner apply that is not fused, and its dot), 4 local sum of gamma_new^2, 5 M4 -- the stretches
+ * between the collectives of a row-partitioned schedule driven by the host */
+NSS_API int nss_minres_phases(const nss_minres_t* s, int32_t first, int32_t last, int32_t k, nss_stream_t stream);
+/* row-partitioned MINRES iterations issued natively (as nss_bpcg2_iterate_dist): per iteration ONE grouped
+ * halo exchange (z0 for A and B, z1 for B^T: halo_z0 / halo_z1 describe ring slot 0, slot 1 has the same
+ * layout) and two all-reduces of one double.  minres.py:96-144; the reference is single-process. */
+NSS_API int nss_minres_iterate_dist(const nss_minres_t* s, nss_dist_t d, const nss_halo_t* halo_z0,
+                                    const nss_halo_t* halo_z1, int32_t k_begin, int32_t k_end, nss_stream_t stream);
 /* process-wide override of where the two dot-product sums of an iteration are evaluated (tests,
  * measurements): -1 automatic (inside the consuming kernels up to 4096 partials), 0 always by the
  * stand-alone sum kernel, 1 always inside the consumers.  Same bits either way. */

@@ -13,29 +13,9 @@
 //   C: SUM1 . allreduce(as_s) . K4 . SUM2 . allreduce(wdn) . K5
 // Interior row blocks touch no ghost column, so they overlap the exchange; xGMI is
 // point-to-point and only slab neighbours talk.  With overlap == 0 everything runs on C.
-#include "bpcg2.h"
+#include "dist.h"
 
 #include <dlfcn.h>
-
-#include <vector>
-
-struct nss_dist_s {
-  void* comm = nullptr;
-  int nranks = 1, rank = 0;
-  hipStream_t xstream = nullptr;
-  hipEvent_t ev_ready[3] = {nullptr, nullptr, nullptr};  // operand produced on C
-  hipEvent_t ev_halo[3] = {nullptr, nullptr, nullptr};   // ghost tail filled on X
-  void* lib = nullptr;
-  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
-  int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
-  int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
-  int (*GroupStart)() = nullptr;
-  int (*GroupEnd)() = nullptr;
-  const char* (*GetErrorString)(int) = nullptr;
-  // per-phase profile of the native loop (nss_dist_profile_begin / _end): kProfMarks events per iteration
-  std::vector<hipEvent_t> prof_ev;
-  int prof_cap = 0, prof_iters = 0;
-};
 
 namespace nss {
 
@@ -45,11 +25,9 @@ namespace nss {
 //   4 all-reduce <s, K s>      5 K4 (+ ghost rows of B) + local sum      6 all-reduce <w, d>      7 K5
 constexpr int kProfMarks = 9;
 
-constexpr int kNcclFloat64 = 8;
-constexpr int kNcclSum = 0;
 enum { S_AS_SLOT = 1, S_WDN_SLOT = 2, S_LOCAL_OFFSET = 8 };   // local sums: slots 9 / 10 (bpcg2.hip)
 
-static void nccl_check(const nss_dist_s& d, int rc, const char* what) {
+void nccl_check(const nss_dist_s& d, int rc, const char* what) {
   if (rc != 0) throw Error(std::string(what) + ": " + (d.GetErrorString ? d.GetErrorString(rc) : "RCCL error"));
 }
 
@@ -59,7 +37,7 @@ static void resolve(void* lib, const char* name, F& out) {
   if (!out) throw Error(std::string("librccl does not export ") + name);
 }
 
-static void check_halo(const nss_halo_t* h, const nss_csr_s& mat, const char* name) {
+void check_halo(const nss_halo_t* h, const nss_csr_s& mat, const char* name) {
   NSS_REQUIRE(h != nullptr, std::string(name) + ": NULL halo");
   NSS_REQUIRE(h->ext != nullptr, std::string(name) + ": NULL operand buffer");
   NSS_REQUIRE(h->n_pack >= 0 && h->n_send >= 0 && h->n_recv >= 0, std::string(name) + ": negative count");
@@ -87,19 +65,38 @@ static void check_halo(const nss_halo_t* h, const nss_csr_s& mat, const char* na
                 std::string(name) + ": receive segment outside the operand");
 }
 
-// pack + grouped send/recv of one operand on stream `st`
-static void exchange(const nss_dist_s& d, const nss_halo_t& h, hipStream_t st) {
-  if (h.n_send == 0 && h.n_recv == 0) return;
-  const double* src = h.direct ? h.ext : h.sendbuf;
-  if (!h.direct) gather_launch(h.n_pack, h.send_idx, h.ext, h.sendbuf, st);
+// pack + grouped send/recv of up to two operands on stream `st` (one RCCL group: one exchange phase)
+void exchange(const nss_dist_s& d, const nss_halo_t& h, hipStream_t st, const nss_halo_t* second) {
+  const nss_halo_t* hs[2] = {&h, second};
+  bool any = false;
+  for (const nss_halo_t* p : hs)
+    if (p && (p->n_send > 0 || p->n_recv > 0)) {
+      any = true;
+      if (!p->direct) gather_launch(p->n_pack, p->send_idx, p->ext, p->sendbuf, st);
+    }
+  if (!any || d.nranks <= 1) return;
   nccl_check(d, d.GroupStart(), "ncclGroupStart");
-  for (int i = 0; i < h.n_send; ++i)
-    nccl_check(d, d.Send(src + h.h_send_off[i], size_t(h.h_send_cnt[i]), kNcclFloat64, h.h_send_peer[i], d.comm, st),
-               "ncclSend");
-  for (int i = 0; i < h.n_recv; ++i)
-    nccl_check(d, d.Recv(h.ext + h.h_recv_off[i], size_t(h.h_recv_cnt[i]), kNcclFloat64, h.h_recv_peer[i], d.comm, st),
-               "ncclRecv");
+  for (const nss_halo_t* p : hs) {
+    if (!p) continue;
+    const double* src = p->direct ? p->ext : p->sendbuf;
+    for (int i = 0; i < p->n_send; ++i)
+      nccl_check(d, d.Send(src + p->h_send_off[i], size_t(p->h_send_cnt[i]), kNcclFloat64, p->h_send_peer[i], d.comm, st),
+                 "ncclSend");
+    for (int i = 0; i < p->n_recv; ++i)
+      nccl_check(d, d.Recv(p->ext + p->h_recv_off[i], size_t(p->h_recv_cnt[i]), kNcclFloat64, p->h_recv_peer[i], d.comm, st),
+                 "ncclRecv");
+  }
   nccl_check(d, d.GroupEnd(), "ncclGroupEnd");
+}
+
+// dst[0 .. n) = sum over the ranks of src[0 .. n) (device pointers; out of place or in place)
+void allreduce_sum(const nss_dist_s& d, const double* src, double* dst, size_t n, hipStream_t st) {
+  if (d.comm == nullptr) {
+    if (d.nranks > 1) throw Error("dist: no communicator");
+    if (src != dst) NSS_HIP(hipMemcpyAsync(dst, src, sizeof(double) * n, hipMemcpyDeviceToDevice, st));
+    return;
+  }
+  nccl_check(d, d.AllReduce(src, dst, n, kNcclFloat64, kNcclSum, d.comm, st), "ncclAllReduce");
 }
 
 // one SpMV phase with its operand exchange, optionally overlapped.  `mark` (profiling, non-overlapped

@@ -22,7 +22,7 @@
 // Stop handling: M4 of iteration k records {stop, k_stop}; kernels of iteration k' return at
 // once when stop is set and k' > k_stop, so M4 of the stopping iteration still applies the
 // update of u (the reference tests *after* :118) and nothing later touches the state.
-#include "bpcg2.h"
+#include "dist.h"
 
 #include <algorithm>
 
@@ -35,7 +35,10 @@ enum {
   // (:104-105) would cost four vector passes per iteration; instead every consumer multiplies the raw
   // entry by the vector's factor -- fl(raw * factor) is exactly the double the in-place scaling would have
   // stored, so the history is unchanged.  Factors of the current z, the current v and v_old:
-  M_SZ = 16, M_SV = 17, M_SVO = 18
+  M_SZ = 16, M_SV = 17, M_SVO = 18,
+  // row-partitioned runs (nss_minres_t.local_sums): the local sums of delta / gamma_new^2; the all-reduce
+  // writes M_DELTA / M_G2 out of place, so the scalars stay frozen after the stop
+  M_DELTA_LOC = 19, M_G2_LOC = 20
 };
 enum { MC_STOP = 0, MC_KSTOP = 1, MC_REASON = 2, MC_LASTK = 3 };
 
@@ -381,6 +384,7 @@ static bool m_small(const nss_minres_t& s) {       // launch-bound regime: every
   return s.A->nblk + s.B->nblk <= kMFoldMax && m3 <= kMFoldMax && dotg <= kMFoldMax;
 }
 static bool m_fold(const nss_minres_t& s) {
+  if (s.local_sums) return false;          // row-partitioned: the sums are all-reduced between the kernels
   if (g_minres_fold_mode >= 0) return g_minres_fold_mode != 0;
   return m_small(s);
 }
@@ -397,7 +401,10 @@ static void minres_check(const nss_minres_t* s) {
   NSS_REQUIRE(s != nullptr, "minres: NULL state");
   NSS_REQUIRE(s->A && s->B && s->BT, "minres: NULL matrix handle");
   NSS_REQUIRE(s->A->m == s->n_u && s->BT->m == s->n_u && s->B->m == s->n_p, "minres: matrix rows do not match n_u/n_p");
-  NSS_REQUIRE(s->A->n == s->n_u && s->B->n == s->n_u && s->BT->n == s->n_p, "minres: matrix columns do not match n_u/n_p");
+  if (s->local_sums)      // row-partitioned: the operands carry ghost entries behind the owned ones
+    NSS_REQUIRE(s->A->n >= s->n_u && s->B->n >= s->n_u && s->BT->n >= s->n_p, "minres: local matrix narrower than the slab");
+  else
+    NSS_REQUIRE(s->A->n == s->n_u && s->B->n == s->n_u && s->BT->n == s->n_p, "minres: matrix columns do not match n_u/n_p");
   NSS_REQUIRE(!(s->pre_diag && s->pre_bjac), "minres: pre_diag and pre_bjac are exclusive");
   NSS_REQUIRE(s->pre_diag || s->pre_bjac || s->pre_amg, "minres: no preconditioner for the velocity block");
   NSS_REQUIRE(!s->pre_amg || s->pre_amg->levels[0].n == s->n_u, "minres: AMG size mismatch");
@@ -416,11 +423,29 @@ static void launch_m3(const MK4Args& a, int grid, hipStream_t st) {
   hipLaunchKernelGGL((minres_m3_kernel<BS>), dim3(grid), dim3(kBlock), 0, st, a);
 }
 
-static void minres_iteration(const nss_minres_t& s, int k, hipStream_t st) {
+// phases of one iteration (nss_minres_phases; the row-partitioned schedules all-reduce between them):
+//   1 M1 + M2 (the three SpMVs)   2 local sum of delta   3 M3 (+ unfused preA and its dot)
+//   4 local sum of gamma_new^2    5 M4
+struct MinresDist {
+  const nss_dist_s* d;
+  const nss_halo_t* hz0;     // z0 in the layout of A's operand (B's local columns are numbered in it too)
+  const nss_halo_t* hz1;     // z1 in the layout of B^T's operand
+};
+
+static void minres_iteration(const nss_minres_t& s, int k, hipStream_t st, int first = 1, int last = 5,
+                             const MinresDist* dist = nullptr) {
   const int io = (k + 2) % 3, ic = k % 3, in = (k + 1) % 3;   // old, current, new
   const int zc = k % 2, zn = (k + 1) % 2;
   const bool fold = m_fold(s);
   double* set = s.scal + m_set(k);
+  auto on = [&](int ph) { return first <= ph && ph <= last; };
+  if (on(1)) {
+  if (dist) {       // both operands in one grouped send/recv phase; z of this iteration sits in ring slot zc
+    nss_halo_t h0 = *dist->hz0, h1 = *dist->hz1;
+    h0.ext = s.z[zc][0];
+    h1.ext = s.z[zc][1];
+    exchange(*dist->d, h0, st, &h1);
+  }
   // M1: kz0 = B^T z1 and kz1 = B z0 with <kz1, z1>;  M2: kz0 += A z0 with <kz0, z0>
   EpiMStore e_bt{s.ctrl, k, s.kz[0], set};
   EpiMAccDot e_b{s.ctrl, k, 0, s.kz[1], s.z[zc][1], s.partials_b, set};
@@ -429,11 +454,13 @@ static void minres_iteration(const nss_minres_t& s, int k, hipStream_t st) {
     launch_csr_stream(*s.B, s.z[zc][0], e_b, st);
   }
   launch_csr_stream(*s.A, s.z[zc][0], EpiMAccDot{s.ctrl, k, 1, s.kz[0], s.z[zc][0], s.partials_a, set}, st);
-  if (!fold) {
+  }
+  if (on(2) && !fold) {
     hipLaunchKernelGGL(minres_sum_kernel, dim3(1), dim3(kSumLanes), 0, st, s.ctrl, k, s.A->nblk, s.partials_a,
-                       s.B->nblk, s.partials_b, set, int(M_DELTA));
+                       s.B->nblk, s.partials_b, set, int(s.local_sums ? M_DELTA_LOC : M_DELTA));
     NSS_CHECK_LAUNCH();
   }
+  if (dist && on(2)) allreduce_sum(*dist->d, set + M_DELTA_LOC, set + M_DELTA, 1, st);
   // M3
   const bool fused = m_fused_bjac(s);
   bool vec = aligned16(s.minv) && (!s.pre_diag || aligned16(s.pre_diag));
@@ -447,6 +474,8 @@ static void minres_iteration(const nss_minres_t& s, int k, hipStream_t st) {
              fused ? s.pre_bjac->nblocks : 0, fused ? s.pre_bjac->run : nullptr, fused ? s.pre_bjac->inv_sym : nullptr,
              vec ? 1 : 0};
   const int g3 = a4.gu + a4.gp;
+  int nb2 = 0;
+  if (on(3)) {
   if (!fused) {
     launch_m3<0>(a4, g3, st);
   } else {
@@ -459,10 +488,15 @@ static void minres_iteration(const nss_minres_t& s, int k, hipStream_t st) {
     }
   }
   NSS_CHECK_LAUNCH();
-  int nb2 = 0;
+  }
   if (!fused && (s.pre_bjac || s.pre_amg)) {
+    const bool dot_in_apply = !s.pre_amg && !s.pre_bjac->gs_mat;
+    if (!on(3)) {                   // phases 4 / 5 issued on their own: the partial count of phase 3
+      nb2 = dot_in_apply ? bjac_dot_grid(*s.pre_bjac) : m_dot_grid(s);
+    } else
     // z_new[0] = preA v_new[0] outside the element-wise kernel; after the stop these launches only
     // touch ring slots nobody reads any more
+    {
     if (s.pre_amg) {
       amg_apply(*s.pre_amg, 1.0, s.v[in][0], s.z[zn][0], st);
       if (s.pre_bjac) bjac_apply(*s.pre_bjac, 1.0, s.v[in][0], 1.0, s.z[zn][0], nullptr, st);
@@ -478,12 +512,15 @@ static void minres_iteration(const nss_minres_t& s, int k, hipStream_t st) {
                          s.partials_a);
       NSS_CHECK_LAUNCH();
     }
+    }
   }
-  if (!fold) {
+  if (on(4) && !fold) {
     hipLaunchKernelGGL(minres_sum_kernel, dim3(1), dim3(kSumLanes), 0, st, s.ctrl, k, nb2, s.partials_a, g3,
-                       s.partials_c, set, int(M_G2));
+                       s.partials_c, set, int(s.local_sums ? M_G2_LOC : M_G2));
     NSS_CHECK_LAUNCH();
   }
+  if (dist && on(4)) allreduce_sum(*dist->d, set + M_G2_LOC, set + M_G2, 1, st);
+  if (!on(5)) return;
   // M4
   MK5Args a5{s.ctrl, s.scal, s.hist, s.n_u, s.n_p, k, s.z[zn][0], s.z[zn][1], s.v[in][0], s.v[in][1], s.w[in][0],
              s.w[in][1], s.u[0], s.u[1], s.z[zc][0], s.z[zc][1], s.w[io][0], s.w[io][1], s.w[ic][0], s.w[ic][1],
@@ -516,6 +553,33 @@ int nss_minres_iterate(const nss_minres_t* s, int32_t k_begin, int32_t k_end, ns
     minres_check(s);
     NSS_REQUIRE(k_begin >= 1, "minres_iterate: iterations are counted from 1");
     for (int k = k_begin; k < k_end; ++k) minres_iteration(*s, k, as_stream(stream));
+  });
+}
+
+int nss_minres_phases(const nss_minres_t* s, int32_t first, int32_t last, int32_t k, nss_stream_t stream) {
+  return guarded([&] {
+    minres_check(s);
+    NSS_REQUIRE(k >= 1 && first >= 1 && last <= 5 && first <= last, "minres_phases: bad phase range / iteration");
+    minres_iteration(*s, k, as_stream(stream), first, last);
+  });
+}
+
+int nss_minres_iterate_dist(const nss_minres_t* s, nss_dist_t d, const nss_halo_t* halo_z0, const nss_halo_t* halo_z1,
+                            int32_t k_begin, int32_t k_end, nss_stream_t stream) {
+  return guarded([&] {
+    minres_check(s);
+    NSS_REQUIRE(d != nullptr && s->local_sums, "minres_iterate_dist: needs a dist handle and a row-partitioned state");
+    NSS_REQUIRE(k_begin >= 1, "minres_iterate_dist: iterations are counted from 1");
+    NSS_REQUIRE(d->nranks == 1 || d->comm != nullptr, "minres_iterate_dist: multi-rank run without a communicator");
+    // the halo descriptors are checked against ring slot 0; slot 1 has the same layout
+    nss_halo_t h0 = *halo_z0, h1 = *halo_z1;
+    h0.ext = s->z[0][0];
+    h1.ext = s->z[0][1];
+    check_halo(&h0, *s->A, "halo_z0");
+    check_halo(&h1, *s->BT, "halo_z1");
+    NSS_REQUIRE(h0.direct && h1.direct, "minres_iterate_dist: contiguous (direct) halo plans only");
+    MinresDist md{d, halo_z0, halo_z1};
+    for (int k = k_begin; k < k_end; ++k) minres_iteration(*s, k, as_stream(stream), 1, 5, &md);
   });
 }
 

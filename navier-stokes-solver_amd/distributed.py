@@ -24,7 +24,7 @@ import os
 import numpy as np
 import scipy.sparse as sp
 
-from hipla import BaseMatrix, BlockJacobi, DiagonalMatrix, InnerProduct, SparseMatrix, Vector
+from hipla import BaseMatrix, BlockJacobi, BlockMatrix, DiagonalMatrix, InnerProduct, SparseMatrix, Vector
 from hipla.engine import get_engine
 
 
@@ -764,3 +764,139 @@ class DistributedBpcg2:
             if done:
                 break
         return (it_final if done else maxsteps - 1), done
+
+
+class DistributedMinres:
+    """Row-partitioned preconditioned MINRES (minres.py:12-149) on this rank, K = [[A, B^T], [B, 0]],
+    C = diag(preA, preM): set-up through the operator protocol with distributed operands, iteration
+    through the fused device kernels (`nss_minres_*`).  Per iteration ONE grouped halo exchange -- z0 in
+    the layout of A's operand, which also serves B (its local columns are renumbered into that layout), and
+    z1 in the layout of B^T's operand -- and two all-reduces of one double (delta, gamma_new^2), issued
+    natively from C over RCCL (`nss_minres_iterate_dist`) or, with any other communicator, between the
+    device phases (`nss_minres_phases`).  The scalars are identical on every rank, so every rank takes the
+    same stop decision."""
+
+    def __init__(self, sysm, f, g, blocks, dist, engine=None, comm=None, native=True, sol=None, initialize=True):
+        import ctypes as C
+        from math import sqrt
+        from hipla import BlockVector
+        from hipla.fused import MinresLoop, native_bjac, native_diag
+        self.engine = eng = engine if engine is not None else get_engine()
+        self.comm = comm if comm is not None else TorchComm(dist, eng)
+        ops = self.ops = DistributedStokes(sysm, blocks, self.comm, eng)
+        n_u, n_p = ops.n_u, ops.n_p
+        # B's slab with its ghost columns numbered in the layout of A's operand (A's ghosts contain B's)
+        gb, ga = ops.B.plan.ghosts, ops.A.plan.ghosts
+        pos = np.searchsorted(ga, gb)
+        if gb.size and (pos.max(initial=0) >= ga.size or not np.array_equal(ga[np.minimum(pos, ga.size - 1)], gb)):
+            raise RuntimeError("ghost columns of B are not among those of A's operand")
+        loc = ops.B.local_scipy
+        cols = loc.indices.astype(np.int64)
+        ghost = cols >= n_u
+        cols[ghost] = n_u + pos[cols[ghost] - n_u]
+        b_on_a = sp.csr_matrix((loc.data, cols.astype(np.int32), loc.indptr), shape=(n_p, n_u + ga.size))
+        b_on_a.sort_indices()
+        self.B_onA = SparseMatrix.from_scipy(b_on_a, engine=eng)
+
+        us, ps = ops.local_slices()
+        fv, gv = ops.vectors(f, g)
+        rhs = BlockVector([fv, gv])
+
+        def plain():
+            return BlockVector([fv.CreateVector(), gv.CreateVector()])
+
+        def extended():            # SpMV operands: owned views of halo-extended buffers
+            z0, z1 = ops.A.operand(), ops.BT.operand()
+            z0.comm = z1.comm = self.comm
+            return BlockVector([z0, z1])
+
+        self.u = u = sol if sol is not None else plain()
+        v_ring, w_ring, z_ring, kz = [plain() for _ in range(3)], [plain() for _ in range(3)], [extended(), extended()], plain()
+        K = BlockMatrix([[ops.A, ops.B.T], [ops.B, None]])
+        Cm = BlockMatrix([[ops.preA, None], [None, ops.preM]])
+        # minres.py:62-75 -- at iteration k = 1 the ring indices are v = v[1], v_old = v[0], z = z[1]
+        v, z = v_ring[1], z_ring[1]
+        if initialize:
+            u[:] = 0.0
+            v.data = rhs
+        else:
+            v.data = rhs - K * u
+        z.data = Cm * v
+        self.gamma = sqrt(InnerProduct(z, v))                # global: the slabs know their communicator
+        z.data = 1.0 / self.gamma * z
+        v.data = 1.0 / self.gamma * v
+        for ring in (v_ring, w_ring):
+            for j in (0, 2) if ring is v_ring else (0, 1, 2):
+                ring[j][:] = 0.0
+        pa_d, pa_b, pm = native_diag(ops.preA), native_bjac(ops.preA), native_diag(ops.preM)
+        if pm is None or (pa_d is None and pa_b is None):
+            raise RuntimeError("DistributedMinres: preA must be a (block) Jacobi, preM diagonal")
+        self.loop = MinresLoop(eng, ops.A.local, self.B_onA, ops.BT.local, pa_d, pa_b, pm, u, v_ring, w_ring, z_ring, kz)
+        self.loop.state.local_sums = 1
+        self.z_ring = z_ring
+        self.native = None
+        comm_handle = getattr(self.comm, "comm", None)        # RcclComm: an ncclComm_t
+        if (native and comm_handle is not None and hasattr(eng.lib, "nss_minres_iterate_dist")
+                and (self.comm.size == 1 or (ops.A.plan.direct and ops.BT.plan.direct))):
+            handle = C.c_void_p()
+            eng._check(eng.lib.nss_dist_create(comm_handle, self.comm.size, self.comm.rank, C.byref(handle)))
+            self.native = (handle, (ops.A.native_halo(z_ring[0][0]), ops.BT.native_halo(z_ring[0][1])))
+
+    def close(self):
+        if getattr(self, "native", None) is not None:
+            self.engine.lib.nss_dist_destroy(self.native[0])
+            self.native = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _iterate(self, k_begin, k_end):
+        import ctypes as C
+        eng, loop, st = self.engine, self.loop, self.loop.state
+        if self.native is not None:
+            handle, (h0, h1) = self.native
+            eng._check(eng.lib.nss_minres_iterate_dist(C.byref(st), handle, C.byref(h0), C.byref(h1), int(k_begin),
+                                                       int(k_end), eng.stream))
+            return
+        ops, comm = self.ops, self.comm
+        for k in range(k_begin, k_end):
+            z = self.z_ring[k % 2]
+            ops.A.exchange(z[0])
+            ops.BT.exchange(z[1])
+            base = ((k - 1) & 1) * 32
+            eng._check(eng.lib.nss_minres_phases(C.byref(st), 1, 2, k, eng.stream))
+            comm.allreduce_sum_into(loop.scal[base + 19:base + 20], loop.scal[base + 0:base + 1])     # delta
+            eng._check(eng.lib.nss_minres_phases(C.byref(st), 3, 4, k, eng.stream))
+            comm.allreduce_sum_into(loop.scal[base + 20:base + 21], loop.scal[base + 2:base + 3])     # gamma_new^2
+            eng._check(eng.lib.nss_minres_phases(C.byref(st), 5, 5, k, eng.stream))
+
+    def solve(self, tol=1e-7, maxsteps=100, poll_every=16):
+        """Returns (u, errors, hit_relative_tol) as `MinRes` does (errors[0] == 1.0)."""
+        import ctypes as C
+        from hipla.fused import (M_C, M_C_OLD, M_ERR0, M_ETA_OLD, M_GAMMA, M_RES_OLD, M_TOL)
+        eng, loop, st = self.engine, self.loop, self.loop.state
+        loop.hist = eng.zeros(maxsteps + 2)
+        st.hist = loop.hist.data_ptr()
+        scal = np.zeros(64)
+        g = self.gamma
+        scal[M_GAMMA], scal[M_ETA_OLD], scal[M_C_OLD], scal[M_C] = g, g, 1.0, 1.0
+        scal[M_RES_OLD], scal[M_ERR0], scal[M_TOL] = g, g, tol
+        scal[16:19] = 1.0
+        eng.upload(scal, loop.scal)
+        loop.ctrl.zero_()
+        stop, k_stop, reason, last = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        k = 1
+        while k < maxsteps + 1:
+            end = min(maxsteps + 1, k + poll_every)
+            self._iterate(k, end)
+            k = end
+            eng._check(eng.lib.nss_minres_poll(C.byref(st), C.byref(stop), C.byref(k_stop), C.byref(reason),
+                                               C.byref(last), eng.stream))
+            if stop.value:
+                break
+        last_k = k_stop.value if stop.value else maxsteps
+        errors = [1.0] + [float(x) for x in eng.to_host(loop.hist)[1: last_k + 1]]
+        return self.u, errors, bool(stop.value and reason.value == 1)

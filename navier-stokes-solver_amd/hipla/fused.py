@@ -292,7 +292,7 @@ class MinresState(C.Structure):
                    ("z", (C.c_void_p * 2) * 2), ("kz", C.c_void_p * 2),
                    ("scal", C.c_void_p), ("ctrl", C.c_void_p), ("hist", C.c_void_p),
                    ("partials_a", C.c_void_p), ("partials_b", C.c_void_p), ("partials_c", C.c_void_p),
-                   ("n_u", C.c_int32), ("n_p", C.c_int32)])
+                   ("n_u", C.c_int32), ("n_p", C.c_int32), ("local_sums", C.c_int32)])
 
 
 (M_DELTA, M_GAMMA, M_G2, M_ETA_OLD, M_C_OLD, M_C, M_S_OLD, M_S, M_RES_OLD, M_ERR0, M_TOL) = range(11)

@@ -95,6 +95,8 @@ def _signatures():
         "nss_minres_workspace": (C.c_int, [vp, c_i64_p, c_i64_p, c_i64_p]),
         "nss_minres_iterate": (C.c_int, [vp, i32, i32, vp]),
         "nss_minres_poll": (C.c_int, [vp, c_i32_p, c_i32_p, c_i32_p, c_i32_p, vp]),
+        "nss_minres_phases": (C.c_int, [vp, i32, i32, i32, vp]),
+        "nss_minres_iterate_dist": (C.c_int, [vp, vp, vp, vp, i32, i32, vp]),
         "nss_minres_fold_mode": (C.c_int, [i32]),
         "nss_minres_fuse_mode": (C.c_int, [i32]),
     }

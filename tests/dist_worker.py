@@ -95,6 +95,12 @@ def run(rank, world, mode, init_file, out_dir, dim, n, pre, tol, maxsteps):
         res["ghost_mode"] = int(bool(run_.ghost_mode)) + int(bool(getattr(run_, "ghost_p_mode", False)))
         res["it"], res["k"], res["err0"] = it, run_.k, run_.err0
         res["u"], res["p"] = run_.sol[0].numpy(), run_.sol[1].numpy()
+        # ---- fused row-partitioned MINRES (device phases + exchanges / all-reduces in between) ----------
+        from distributed import DistributedMinres
+        mr = DistributedMinres(sysm, f, g, blocks, dist, eng, comm=comm)
+        um, errs, rel = mr.solve(tol=tol, maxsteps=maxsteps, poll_every=8)
+        res["minres_errors"], res["minres_rel"] = np.array(errs), int(rel)
+        res["minres_u"], res["minres_p"] = um[0].numpy(), um[1].numpy()
     # ---- distributed AMG (replicated coarse levels) as preA, BPCG v2 through the protocol ------------
     if pre == "bjac":
         from distributed import DistributedAMG

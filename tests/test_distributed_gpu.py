@@ -39,6 +39,20 @@ def single_gpu(dim, n, pre, tol, maxsteps):
     return s, dict(it=it, hist=hist, k=ses.k, err0=ses.err0, u=sol[0].numpy(), p=sol[1].numpy())
 
 
+def single_gpu_minres(s, pre, tol, maxsteps):
+    import hipla
+    from minres import MinRes
+    f, g = s.rhs(0)
+    A, B = hipla.SparseMatrix.from_scipy(s.A), hipla.SparseMatrix.from_scipy(s.B)
+    preA = hipla.BlockJacobi(A, s.line_blocks(3)) if pre == "bjac" else hipla.JacobiPreconditioner(A)
+    K = hipla.BlockMatrix([[A, B.T], [B, None]])
+    Cm = hipla.BlockMatrix([[preA, None], [None, hipla.DiagonalMatrix(1.0 / s.mass)]])
+    with contextlib.redirect_stdout(io.StringIO()):
+        u, errors = MinRes(mat=K, pre=Cm, rhs=hipla.BlockVector([hipla.Vector.from_numpy(f), hipla.Vector.from_numpy(g)]),
+                           maxsteps=maxsteps, tol=tol, printrates=False)
+    return dict(errors=np.array(errors), u=u[0].numpy(), p=u[1].numpy())
+
+
 @pytest.mark.parametrize("world,dim,n,pre", [(2, 3, 10, "bjac"), (3, 2, 24, "jacobi"), (5, 3, 10, "jacobi")])
 def test_fused_distributed_loop_matches_single_gpu(hip_engine, world, dim, n, pre):
     tol, maxsteps = 1e-8, 4000
@@ -58,6 +72,16 @@ def test_fused_distributed_loop_matches_single_gpu(hip_engine, world, dim, n, pr
     assert np.linalg.norm(u - ref["u"]) < 1e-5 * np.linalg.norm(ref["u"])
     p0, pr = p - p.mean(), ref["p"] - ref["p"].mean()
     assert np.linalg.norm(p0 - pr) < 1e-4 * np.linalg.norm(pr)
+    # fused row-partitioned MINRES against the single-GPU fused MINRES
+    mref = single_gpu_minres(s, pre, tol, maxsteps)
+    for d in ranks:
+        np.testing.assert_array_equal(d["minres_errors"], ranks[0]["minres_errors"])
+        w = min(40, len(mref["errors"]), len(d["minres_errors"]))
+        np.testing.assert_allclose(d["minres_errors"][:w], mref["errors"][:w], rtol=1e-8)
+        assert abs(len(d["minres_errors"]) - len(mref["errors"])) <= max(3, int(0.03 * len(mref["errors"])))
+        assert int(d["minres_rel"]) == 1
+    um = np.concatenate([d["minres_u"] for d in ranks])
+    assert np.linalg.norm(um - mref["u"]) < 1e-5 * np.linalg.norm(mref["u"])
     if pre == "bjac":
         # DistributedAMG (finest level on the slabs, coarse levels replicated on every rank) on the
         # product engine: same hierarchy, same V-cycle and same BPCG history as one GPU
@@ -188,6 +212,47 @@ def test_native_loop_profile_and_frozen_scalars_single_rank(hip_engine, tmp_path
         np.testing.assert_array_equal(run.history(it), hist_before)
         comm.close()
     finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("pre", ["bjac", "jacobi"])
+def test_native_partitioned_minres_single_rank(hip_engine, tmp_path, pre):
+    """nss_minres_iterate_dist on a 1-rank RCCL communicator (grouped exchange of both operands, out-of-place
+    all-reduces of delta and gamma_new^2 issued from C) and the host-driven schedule over nss_minres_phases:
+    with the single-GPU loop held to the same launch form (sums in their stand-alone kernels, block Jacobi
+    as its own launch) all three give identical bits; and the scalars stay frozen after the stop."""
+    import torch
+    import torch.distributed as dist
+    from distributed import DistributedMinres
+    from rccl_comm import RcclComm
+    s = mac_stokes(3, 12, 0.01)
+    f, g = s.rhs(0)
+    tol, maxsteps = 1e-8, 4000
+    lib = hip_engine.lib
+    dist.init_process_group("gloo", init_method="file://" + str(tmp_path / "rdv"), rank=0, world_size=1)
+    try:
+        assert lib.nss_minres_fold_mode(0) == 0 and lib.nss_minres_fuse_mode(0) == 0
+        ref = single_gpu_minres(s, pre, tol, maxsteps)
+        comm = RcclComm(dist, hip_engine)
+        for native in (True, False):
+            run = DistributedMinres(s, f, g, s.line_blocks(3) if pre == "bjac" else None, dist, hip_engine, comm=comm,
+                                    native=native)
+            assert (run.native is not None) == native
+            u, errors, rel = run.solve(tol=tol, maxsteps=maxsteps, poll_every=16)
+            assert rel
+            np.testing.assert_array_equal(np.array(errors), ref["errors"])
+            np.testing.assert_array_equal(u[0].numpy(), ref["u"])
+            np.testing.assert_array_equal(u[1].numpy(), ref["p"])
+            before = hip_engine.to_host(run.loop.scal).copy()
+            run._iterate(len(errors), len(errors) + 9)                  # after the stop: no-ops on the device
+            torch.cuda.synchronize()
+            np.testing.assert_array_equal(hip_engine.to_host(run.loop.scal), before)
+            np.testing.assert_array_equal(u[0].numpy(), ref["u"])
+            run.close()
+        comm.close()
+    finally:
+        lib.nss_minres_fold_mode(-1)
+        lib.nss_minres_fuse_mode(-1)
         dist.destroy_process_group()
 
 
