@@ -277,6 +277,9 @@ typedef struct nss_bpcg2_s {
    * once the stop flag is set (the sum kernels then return early and every further all-reduce
    * reproduces the same value).  0: the sums go straight to scal[1] / scal[2] (single GPU). */
   int32_t local_sums;
+  /* row-partitioned runs: V-cycle with replicated coarse levels as (part of) preA, applied natively with its
+   * two halo exchanges and one coarse all-reduce (nss_dist_amg_create); NULL otherwise */
+  struct nss_dist_amg_s* pre_dist_amg;
 } nss_bpcg2_t;
 
 enum {
@@ -369,6 +372,18 @@ NSS_API int nss_dist_destroy(nss_dist_t d);
 NSS_API int nss_bpcg2_iterate_dist(const nss_bpcg2_t* s, nss_dist_t d, const nss_halo_t* halo_s1,
                                    const nss_halo_t* halo_t1, const nss_halo_t* halo_t4, int32_t overlap,
                                    int32_t it_begin, int32_t it_end, nss_stream_t stream);
+/* Smoothed-aggregation V(1,1)-cycle on a row-partitioned operator with replicated coarse levels, applied
+ * natively (the reference has no counterpart: it is single-process; this is what keeps the auxiliary / AMG
+ * term of MypreA, templates/NavierStokesSIMPLE_iterative.py:380,383, inside the native multi-GPU loop):
+ * a_loc = the slab's rows of the finest operator (columns [owned | ghosts]) with the halo plan of the iterate,
+ * r_loc = R[:, owned columns], p_loc = P[owned rows, :], wdinv = omega / diag on the slab, coarse = V-cycle
+ * handle of levels 1.. (nss_amg_create).  y = scale * V(b). */
+typedef struct nss_dist_amg_s* nss_dist_amg_t;
+NSS_API int nss_dist_amg_create(nss_dist_t d, nss_csr_t a_loc, const nss_halo_t* halo_x, nss_csr_t r_loc,
+                                nss_csr_t p_loc, const double* wdinv, nss_amg_t coarse, nss_dist_amg_t* out);
+NSS_API int nss_dist_amg_destroy(nss_dist_amg_t h);
+NSS_API int nss_dist_amg_apply_f64(nss_dist_amg_t h, double scale, const double* b, double* y, nss_stream_t stream);
+
 /* Per-phase device times of the native partitioned loop: between _begin and _end every iteration issued by
  * nss_bpcg2_iterate_dist (up to max_iterations) records 9 HIP events on the compute stream; _end waits for them
  * and returns the average duration (ms) of the 8 segments between them:

@@ -17,36 +17,6 @@
 
 namespace nss {
 
-struct EpiResidual {   // r = b - A x
-  const double* __restrict__ b;
-  double* __restrict__ r;
-  const int32_t* __restrict__ done;
-  __device__ bool skip() const { return done != nullptr && *done != 0; }
-  struct Pre { double b = 0.0; };
-  __device__ Pre fetch(int i) const { return Pre{b[i]}; }
-  __device__ void row(int i, double ax, const Pre& p) const { r[i] = p.b - ax; }
-  __device__ void finish(int, double*) const {}
-};
-
-struct EpiJacobi {     // y (+)= scale * (x + w dinv (b - A x))
-  const double* __restrict__ b;
-  const double* __restrict__ x;
-  const double* __restrict__ dinv;
-  double* __restrict__ y;
-  double w;
-  double scale;
-  const int32_t* __restrict__ done;
-  bool accumulate = false;
-  __device__ bool skip() const { return done != nullptr && *done != 0; }
-  struct Pre { double b = 0.0, x = 0.0, dinv = 0.0, y = 0.0; };
-  __device__ Pre fetch(int i) const { return Pre{b[i], x[i], dinv[i], accumulate ? y[i] : 0.0}; }
-  __device__ void row(int i, double ax, const Pre& p) const {
-    const double t = scale * fma(w * p.dinv, p.b - ax, p.x);
-    y[i] = accumulate ? p.y + t : t;
-  }
-  __device__ void finish(int, double*) const {}
-};
-
 // y = s * d .* x
 __global__ __launch_bounds__(kBlock) void amg_diag_kernel(int32_t n, double s, const double* __restrict__ d,
                                                            const double* __restrict__ x, double* __restrict__ y,

@@ -90,21 +90,26 @@ __global__ __launch_bounds__(kBlock) void lincomb_kernel(int64_t n, LinArgs a, d
   }
 }
 
+// STREAM triad z = x + a y, the roofline denominator.  One-shot launch (one 16-byte access per lane and
+// stream, no grid-stride loop) with non-temporal loads and stores: the fastest of the forms swept in
+// tools/triad_variants.hip (6.2 TB/s; <= 2048 striding workgroups: 5.5 TB/s).
 template <bool VEC2>
 __global__ __launch_bounds__(kBlock) void triad_kernel(int64_t n, double a, const double* __restrict__ x,
                                                         const double* __restrict__ y, double* __restrict__ z) {
-  const int64_t stride = int64_t(gridDim.x) * kBlock;
-  int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+  const int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x;
   if (VEC2) {
     const int64_t n2 = n >> 1;
-    for (; i < n2; i += stride) {
-      const double2 xv = reinterpret_cast<const double2*>(x)[i];
-      const double2 yv = reinterpret_cast<const double2*>(y)[i];
-      reinterpret_cast<double2*>(z)[i] = make_double2(fma(a, yv.x, xv.x), fma(a, yv.y, xv.y));
+    if (i < n2) {
+      const dbl2v xv = __builtin_nontemporal_load(reinterpret_cast<const dbl2v*>(x) + i);
+      const dbl2v yv = __builtin_nontemporal_load(reinterpret_cast<const dbl2v*>(y) + i);
+      dbl2v r;
+      r.x = fma(a, yv.x, xv.x);
+      r.y = fma(a, yv.y, xv.y);
+      __builtin_nontemporal_store(r, reinterpret_cast<dbl2v*>(z) + i);
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) z[n - 1] = fma(a, y[n - 1], x[n - 1]);
   } else {
-    for (; i < n; i += stride) z[i] = fma(a, y[i], x[i]);
+    if (i < n) z[i] = fma(a, y[i], x[i]);
   }
 }
 
@@ -388,11 +393,12 @@ int nss_upwind_flux_f64(int64_t n, const double* adv, const double* avg, const d
 int nss_stream_triad_f64(int64_t n, double a, const double* x, const double* y, double* z, nss_stream_t stream) {
   return guarded([&] {
     if (n <= 0) return;
-    const int grid = stream_grid(n, kBlock * 4);
     if (aligned16(x) && aligned16(y) && aligned16(z))
-      hipLaunchKernelGGL(triad_kernel<true>, dim3(grid), dim3(kBlock), 0, as_stream(stream), n, a, x, y, z);
+      hipLaunchKernelGGL(triad_kernel<true>, dim3(unsigned(((n >> 1) + kBlock) / kBlock)), dim3(kBlock), 0,
+                         as_stream(stream), n, a, x, y, z);
     else
-      hipLaunchKernelGGL(triad_kernel<false>, dim3(grid), dim3(kBlock), 0, as_stream(stream), n, a, x, y, z);
+      hipLaunchKernelGGL(triad_kernel<false>, dim3(unsigned((n + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                         as_stream(stream), n, a, x, y, z);
     NSS_CHECK_LAUNCH();
   });
 }

@@ -40,7 +40,7 @@
 // R1/R2 only form local sums; alpha and beta are evaluated by the consuming kernels, so the
 // row-partitioned multi-GPU loop simply all-reduces scal[as_s] / scal[wdn] in between
 // (SURVEY.md section 8e).
-#include "bpcg2.h"
+#include "dist.h"
 
 namespace nss {
 
@@ -621,7 +621,9 @@ void bpcg2_check_state(const nss_bpcg2_t* s) {
   NSS_REQUIRE(s->A && s->B && s->BT, "bpcg2: NULL matrix handle");
   NSS_REQUIRE(s->A->m == s->n_u && s->BT->m == s->n_u && s->B->m == s->n_p, "bpcg2: matrix row counts do not match n_u/n_p");
   NSS_REQUIRE(!(s->pre_diag && s->pre_bjac), "bpcg2: pre_diag and pre_bjac are exclusive");
-  NSS_REQUIRE(s->pre_diag || s->pre_bjac || s->pre_amg, "bpcg2: no preconditioner for the velocity block");
+  NSS_REQUIRE(s->pre_diag || s->pre_bjac || s->pre_amg || s->pre_dist_amg, "bpcg2: no preconditioner for the velocity block");
+  NSS_REQUIRE(!s->pre_dist_amg || (!s->pre_amg && !s->cond_HT && s->pre_dist_amg->n == s->n_u),
+              "bpcg2: the row-partitioned AMG replaces pre_amg, takes no condensed form, and must match n_u");
   NSS_REQUIRE(!s->pre_amg || s->pre_amg->levels[0].n == s->n_u, "bpcg2: AMG size mismatch");
   // AMG (or auxiliary-space) term + a block-Jacobi handle in Gauss-Seidel mode = the MULTIPLICATIVE MypreA
   // (GS=True, :376-381): sweep, residual, correction, back sweep.  Not with the condensed form.
@@ -685,7 +687,11 @@ void bpcg2_k1_finish(const nss_bpcg2_t& s, hipStream_t st) {
     src = s.cond_f;
   }
   auto diag = [&](double beta) { diag_apply(s.n_u, s.pre_diag, s.k, src, beta, s.t1, s.ctrl, st); };
-  if (s.pre_amg && s.pre_bjac && s.pre_bjac->gs_mat) {
+  if (s.pre_dist_amg) {                              // row-partitioned V-cycle (+ additive Jacobi part)
+    dist_amg_apply(*s.pre_dist_amg, s.k, src, s.t1, st, s.ctrl);
+    if (s.pre_bjac) bjac_apply(*s.pre_bjac, s.k, src, 1.0, s.t1, s.ctrl, st);
+    if (s.pre_diag) diag(1.0);
+  } else if (s.pre_amg && s.pre_bjac && s.pre_bjac->gs_mat) {
     // multiplicative MypreA (GS=True, :376-381) applied to k * t0:
     //   y = 0; J.Smooth(y, x); r = x - A y; y += M r; J.SmoothBack(y, x)        (t2 is free here: the
     //   previous iteration's t2 was consumed by K1 / C1 and the A-SpMV has not written the new one yet)
@@ -759,7 +765,7 @@ void bpcg2_cphase(const nss_bpcg2_t& s, int which, int it, hipStream_t st) {
   const bool fold = fold_sums(s);
   switch (which) {
     case NSS_BPCG2C_C1: {
-      const double* dinv = (s.pre_amg || s.cond_HT) ? nullptr : s.pre_diag;
+      const double* dinv = (s.pre_amg || s.pre_dist_amg || s.cond_HT) ? nullptr : s.pre_diag;
       if (fold)
         launch_csr_stream(*s.BT, s.s1, EpiK1c<true>{close_args(s, true), s.u0, s.q, s.z0, s.t2, s.s0, s.w0, s.t0, s.t1,
                                                     dinv, s.k, it, s.s1, s.w1}, st);

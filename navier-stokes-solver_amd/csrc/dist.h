@@ -24,7 +24,28 @@ struct nss_dist_s {
 };
 
 
+// Smoothed-aggregation V(1,1)-cycle on a row-partitioned operator with REPLICATED coarse levels, applied
+// natively inside the partitioned loops (distributed.DistributedAMG is the host-side twin): the finest level
+// works on the slab (two halo exchanges of the iterate), the slab's share of the restricted residual is
+// all-reduced (one coarse vector) and levels 1.. run redundantly on every rank.
+struct nss_dist_amg_s {
+  const nss_dist_s* d = nullptr;
+  const nss_csr_s* A = nullptr;        // slab rows, columns [owned | ghosts]
+  const nss_csr_s* R = nullptr;        // coarse rows x owned columns
+  const nss_csr_s* P = nullptr;        // owned rows x coarse columns
+  const double* wdinv = nullptr;       // omega / diag(A) on the slab
+  const nss_amg_s* coarse = nullptr;   // levels 1.. (replicated)
+  nss_halo_t halo{};                   // of the iterate x (ext = x's halo-extended buffer)
+  int32_t n = 0, nc = 0;
+  double *res = nullptr, *rc = nullptr, *ec = nullptr;   // work vectors (owned by the handle)
+};
+
 namespace nss {
+
+// y = scale * V(b) on the slab; every kernel returns at once when *done != 0 (the collectives still run on all
+// ranks, on unchanged buffers)
+void dist_amg_apply(const nss_dist_amg_s& a, double scale, const double* b, double* y, hipStream_t st,
+                    const int32_t* done);
 
 constexpr int kNcclFloat64 = 8;
 constexpr int kNcclSum = 0;

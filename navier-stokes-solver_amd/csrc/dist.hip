@@ -158,11 +158,73 @@ static void allreduce_slot(const nss_bpcg2_t& s, const nss_dist_s& d, int slot, 
   nccl_check(d, d.AllReduce(local, s.scal + slot, 1, kNcclFloat64, kNcclSum, d.comm, cs), "ncclAllReduce");
 }
 
+void dist_amg_apply(const nss_dist_amg_s& a, double scale, const double* b, double* y, hipStream_t st,
+                    const int32_t* done) {
+  double* x = a.halo.ext;                                                    // owned entries first
+  diag_apply(a.n, a.wdinv, 1.0, b, 0.0, x, done, st);                        // pre-smoothing from zero
+  exchange(*a.d, a.halo, st);
+  launch_csr_stream(*a.A, x, EpiResidual{b, a.res, done}, st);               // res = b - A x
+  launch_csr_stream(*a.R, a.res, EpiAxpby{1.0, 0.0, a.rc, done}, st);        // this slab's share of R res
+  allreduce_sum(*a.d, a.rc, a.rc, size_t(a.nc), st);
+  amg_apply(*a.coarse, 1.0, a.rc, a.ec, st, done);                           // levels 1.. on every rank
+  launch_csr_stream(*a.P, a.ec, EpiAxpby{1.0, 1.0, x, done}, st);            // x += P e
+  exchange(*a.d, a.halo, st);
+  launch_csr_stream(*a.A, x, EpiJacobi{b, x, a.wdinv, y, 1.0, scale, done}, st);   // y = scale (x + w D^-1 (b - A x))
+}
+
 }  // namespace nss
 
 using namespace nss;
 
 extern "C" {
+
+int nss_dist_amg_create(nss_dist_t d, nss_csr_t a_loc, const nss_halo_t* halo_x, nss_csr_t r_loc, nss_csr_t p_loc,
+                        const double* wdinv, nss_amg_t coarse, nss_dist_amg_t* out) {
+  return guarded([&] {
+    NSS_REQUIRE(d && a_loc && halo_x && r_loc && p_loc && wdinv && coarse && out, "dist_amg_create: NULL argument");
+    NSS_REQUIRE(coarse->T == nullptr && !coarse->levels.empty(), "dist_amg_create: coarse must be a plain V-cycle handle");
+    const int32_t n = a_loc->m, nc = coarse->levels[0].n;
+    NSS_REQUIRE(a_loc->n >= n && r_loc->m == nc && r_loc->n == n && p_loc->m == n && p_loc->n == nc,
+                "dist_amg_create: operator shapes do not chain");
+    check_halo(halo_x, *a_loc, "dist_amg halo");
+    nss_dist_amg_s* h = new nss_dist_amg_s;
+    try {
+      h->d = d;
+      h->A = a_loc;
+      h->R = r_loc;
+      h->P = p_loc;
+      h->wdinv = wdinv;
+      h->coarse = coarse;
+      h->halo = *halo_x;
+      h->n = n;
+      h->nc = nc;
+      NSS_HIP(hipMalloc(&h->res, sizeof(double) * size_t(std::max(1, n))));
+      NSS_HIP(hipMalloc(&h->rc, sizeof(double) * size_t(std::max(1, nc))));
+      NSS_HIP(hipMalloc(&h->ec, sizeof(double) * size_t(std::max(1, nc))));
+    } catch (...) {
+      nss_dist_amg_destroy(h);
+      throw;
+    }
+    *out = h;
+  });
+}
+
+int nss_dist_amg_destroy(nss_dist_amg_t h) {
+  return guarded([&] {
+    if (!h) return;
+    (void)hipFree(h->res);
+    (void)hipFree(h->rc);
+    (void)hipFree(h->ec);
+    delete h;
+  });
+}
+
+int nss_dist_amg_apply_f64(nss_dist_amg_t h, double scale, const double* b, double* y, nss_stream_t stream) {
+  return guarded([&] {
+    NSS_REQUIRE(h && b && y && b != y, "dist_amg_apply: bad argument");
+    dist_amg_apply(*h, scale, b, y, as_stream(stream), nullptr);
+  });
+}
 
 int nss_dist_create(void* nccl_comm, int32_t nranks, int32_t rank, nss_dist_t* out) {
   return guarded([&] {

@@ -577,7 +577,6 @@ int nss_minres_iterate_dist(const nss_minres_t* s, nss_dist_t d, const nss_halo_
     h1.ext = s->z[0][1];
     check_halo(&h0, *s->A, "halo_z0");
     check_halo(&h1, *s->BT, "halo_z1");
-    NSS_REQUIRE(h0.direct && h1.direct, "minres_iterate_dist: contiguous (direct) halo plans only");
     MinresDist md{d, halo_z0, halo_z1};
     for (int k = k_begin; k < k_end; ++k) minres_iteration(*s, k, as_stream(stream), 1, 5, &md);
   });

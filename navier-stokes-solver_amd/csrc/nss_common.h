@@ -43,10 +43,14 @@ namespace nss {
 
 constexpr int kWave = 64;
 constexpr int kBlock = 256;           // 4 waves: one per SIMD of a CU
+// Upper bound of the grid of the element-wise (grid-stride) kernels.  Round 1 capped it at 2048 (8 resident
+// workgroups per CU); measured in round 2 (profiles/r02_triad_variants.txt, r02_ab_grid_cap.txt): launches with
+// far more, shorter workgroups reach a higher HBM rate on this chip (triad 5.5 -> 6.2 TB/s one-shot; block
+// Jacobi + K1 -2 %), so the cap is now high enough that every per-iteration kernel is (nearly) one-shot.
 #ifndef NSS_MAX_STREAM_BLOCKS
-#define NSS_MAX_STREAM_BLOCKS 2048
+#define NSS_MAX_STREAM_BLOCKS 65536
 #endif
-constexpr int kMaxStreamBlocks = NSS_MAX_STREAM_BLOCKS;  // 256 CUs x 8 resident blocks: grid-stride the rest
+constexpr int kMaxStreamBlocks = NSS_MAX_STREAM_BLOCKS;
 
 void set_error(const char* fmt, ...);
 

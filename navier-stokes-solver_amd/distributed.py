@@ -402,6 +402,36 @@ class DistributedAMG(BaseMatrix):
         self.rc, self.ec = Vector(nc, engine=eng), Vector(nc, engine=eng)
         self.x0, self.res = dist_A.CreateRowVector(), dist_A.CreateColVector()
         self.n = r1 - r0
+        self._native = None
+
+    def native_handle(self, dist_handle):
+        """`nss_dist_amg_t` of this cycle for the native partitioned loops (created once): the C loop then
+        issues the cycle's two halo exchanges and its coarse all-reduce itself."""
+        import ctypes as C
+        if self._native is None:
+            eng = self.engine
+            self._x_native = self.A.operand()                      # the iterate, halo-extended
+            halo = self.A.native_halo(self._x_native)
+            out = C.c_void_p()
+            eng._check(eng.lib.nss_dist_amg_create(dist_handle, self.A.local.handle.ptr, C.byref(halo),
+                                                   self.R_loc.handle.ptr, self.P_loc.handle.ptr,
+                                                   self.dinv.d.data_ptr(), self.coarse.ptr, C.byref(out)))
+            self._native = (out, halo, dist_handle)
+        return self._native[0]
+
+    def native_apply(self, scale, b, y):
+        """y = scale * V(b) through the native handle (tests)."""
+        eng = self.engine
+        eng._check(eng.lib.nss_dist_amg_apply_f64(self._native[0], float(scale), b.buf.data_ptr(), y.buf.data_ptr(),
+                                                  eng.stream))
+
+    def __del__(self):
+        try:
+            if self._native is not None:
+                self.engine.lib.nss_dist_amg_destroy(self._native[0])
+                self._native = None
+        except Exception:
+            pass
 
     def Height(self):
         return self.n
@@ -532,9 +562,12 @@ class DistributedBpcg2:
                 ("halo", "t4"), ("phases", ("K3", "SUM1")), ("allreduce", 1), ("phases", ("ALPHA", "SUM2")),
                 ("allreduce", 2), ("phases", ("BETA", "K5")))
 
-    def __init__(self, sysm, f, g, blocks, dist, engine=None, comm=None, quiet=True, native=True):
+    def __init__(self, sysm, f, g, blocks, dist, engine=None, comm=None, quiet=True, native=True, pre=None):
         """`native=False` keeps the Python-driven schedule even when `comm` is an `RcclComm` (its
-        collectives are then single ctypes calls into librccl between the device phases)."""
+        collectives are then single ctypes calls into librccl between the device phases).
+        `pre="amg"`: preA = the V-cycle with replicated coarse levels (`DistributedAMG`), applied inside the
+        native loop (needs the RCCL communicator: the cycle's exchanges and its coarse all-reduce are issued
+        from C); `pre="amg+bjac"` adds the block Jacobi (additive MypreA)."""
         import contextlib
         self.want_native = bool(native)
         import io
@@ -543,6 +576,11 @@ class DistributedBpcg2:
         self.engine = engine if engine is not None else get_engine()
         self.comm = comm if comm is not None else TorchComm(dist, self.engine)
         ops = self.ops = DistributedStokes(sysm, blocks, self.comm, self.engine)
+        self.dist_amg = None
+        if pre in ("amg", "amg+bjac"):
+            self.dist_amg = DistributedAMG(sysm.A, ops.A)
+            self.jacobi_part = ops.preA if pre == "amg+bjac" else None
+            ops.preA = self.dist_amg if self.jacobi_part is None else self.dist_amg + self.jacobi_part
         us, ps = ops.local_slices()
         fv = Vector.from_numpy(np.asarray(f)[us], engine=self.engine)
         gv = Vector.from_numpy(np.asarray(g)[ps], engine=self.engine)
@@ -577,8 +615,21 @@ class DistributedBpcg2:
         from hipla.fused import Bpcg2Loop
         ops = self.ops
         self.vecs = vecs
-        self.loop = Bpcg2Loop.try_create(ops.A.local, ops.B.local, ops.BT.local, ops.preA, self.k, ops.preM, vecs,
-                                         distributed=True)
+        dist_amg = getattr(self, "dist_amg", None)
+        if dist_amg is not None:
+            import ctypes as C
+            comm_handle = getattr(self.comm, "comm", None)
+            if comm_handle is None:
+                raise RuntimeError("pre='amg' inside the fused partitioned loop needs the RCCL communicator "
+                                   "(with torch.distributed use BramblePasciakCG on the distributed operands)")
+            handle = C.c_void_p()
+            self.engine._check(self.engine.lib.nss_dist_create(comm_handle, self.comm.size, self.comm.rank, C.byref(handle)))
+            self._amg_dist_handle = handle
+            self.loop = Bpcg2Loop.try_create(ops.A.local, ops.B.local, ops.BT.local, self.jacobi_part, self.k, ops.preM,
+                                             vecs, distributed=True, dist_amg=dist_amg.native_handle(handle))
+        else:
+            self.loop = Bpcg2Loop.try_create(ops.A.local, ops.B.local, ops.BT.local, ops.preA, self.k, ops.preM, vecs,
+                                             distributed=True)
         if self.loop is None:
             raise RuntimeError("fused distributed BPCG loop needs the HIP engine and native operands")
         self.halo = {"s1": (ops.BT, self.s1), "t1": (ops.A, self.t1), "t4": (ops.B, self.t4)}
@@ -836,8 +887,7 @@ class DistributedMinres:
         self.z_ring = z_ring
         self.native = None
         comm_handle = getattr(self.comm, "comm", None)        # RcclComm: an ncclComm_t
-        if (native and comm_handle is not None and hasattr(eng.lib, "nss_minres_iterate_dist")
-                and (self.comm.size == 1 or (ops.A.plan.direct and ops.BT.plan.direct))):
+        if native and comm_handle is not None and hasattr(eng.lib, "nss_minres_iterate_dist"):
             handle = C.c_void_p()
             eng._check(eng.lib.nss_dist_create(comm_handle, self.comm.size, self.comm.rank, C.byref(handle)))
             self.native = (handle, (ops.A.native_halo(z_ring[0][0]), ops.BT.native_halo(z_ring[0][1])))

@@ -37,7 +37,7 @@ class Bpcg2State(C.Structure):
                    ("ghost_s0", C.c_void_p), ("ghost_w0", C.c_void_p),
                    ("ghost_p_mode", C.c_int32), ("ghost_p_n", C.c_int32), ("ghost_b", C.c_void_p),
                    ("ghost_t3", C.c_void_p), ("ghost_w1", C.c_void_p), ("ghost_minv", C.c_void_p),
-                   ("local_sums", C.c_int32)])
+                   ("local_sums", C.c_int32), ("pre_dist_amg", C.c_void_p)])
 
 
 class HaloStruct(C.Structure):
@@ -142,7 +142,8 @@ class Bpcg2Loop:
     """Device-resident iteration of solvers/bramblepasciak_new.py:200-249."""
 
     @classmethod
-    def try_create(cls, matA, matB, matBT, preA_unscaled, k, preM, vecs, distributed=False, condensed=None):
+    def try_create(cls, matA, matB, matBT, preA_unscaled, k, preM, vecs, distributed=False, condensed=None,
+                   dist_amg=None):
         """`distributed`: the matrices are the local row blocks of a partitioned run -- their
         column spaces carry halo entries behind the owned ones and t1 / t4 / s1 are the owned
         views of halo-extended buffers (same base pointer).  `condensed`: dict(HT, H, inner) of
@@ -160,7 +161,14 @@ class Bpcg2Loop:
         if distributed and (matA.width < n_u or matB.width < n_u or matBT.width < n_p):
             return None
         pm = native_diag(preM)
-        pa = native_velocity_pre(preA_unscaled)
+        if dist_amg is not None:     # row-partitioned V-cycle (native handle) [+ an additive Jacobi part]
+            pa = native_velocity_pre(preA_unscaled) if preA_unscaled is not None else None
+            if pa is None:
+                pa = {"scale": 1.0, "amg": None, "diag": None, "bjac": None, "multiplicative": False}
+            if pa["amg"] is not None or pa["multiplicative"] or not distributed:
+                return None
+        else:
+            pa = native_velocity_pre(preA_unscaled)
         if pm is None or pa is None:
             return None
         if pa["multiplicative"] and (condensed is not None or distributed or pa["bjac"].mat is not matA):
@@ -175,9 +183,9 @@ class Bpcg2Loop:
                 return None
             if not _extension_is_in_place_safe(condensed["H"]):
                 return None
-        return cls(eng, matA, matB, matBT, pa, k, pm, vecs, condensed, distributed)
+        return cls(eng, matA, matB, matBT, pa, k, pm, vecs, condensed, distributed, dist_amg)
 
-    def __init__(self, eng, matA, matB, matBT, pa, k, pm, vecs, condensed=None, distributed=False):
+    def __init__(self, eng, matA, matB, matBT, pa, k, pm, vecs, condensed=None, distributed=False, dist_amg=None):
         torch = eng.torch
         self.eng, self.lib = eng, eng.lib
         self.keep = [matA, matB, matBT, vecs, pa, pm, condensed]       # keep device memory alive
@@ -201,6 +209,8 @@ class Bpcg2Loop:
             setattr(st, name, vecs[name].buf.data_ptr())
         st.n_u, st.n_p = matA.height, matB.height
         st.local_sums = 1 if distributed else 0     # the caller all-reduces scal[9], scal[10] into scal[1], scal[2]
+        st.pre_dist_amg = dist_amg
+        self.keep.append(dist_amg)
         na, nb, nc = C.c_int64(), C.c_int64(), C.c_int64()
         eng._check(self.lib.nss_bpcg2_workspace(C.byref(st), C.byref(na), C.byref(nb), C.byref(nc)))
         self.partials = [eng.zeros(max(1, v.value)) for v in (na, nb, nc)]

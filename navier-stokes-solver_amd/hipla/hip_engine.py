@@ -61,6 +61,9 @@ def _signatures():
         "nss_csr_row_blocks": (C.c_int, [vp, vp, i64]),
         "nss_dist_create": (C.c_int, [vp, i32, i32, C.POINTER(vp)]),
         "nss_dist_destroy": (C.c_int, [vp]),
+        "nss_dist_amg_create": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.POINTER(vp)]),
+        "nss_dist_amg_destroy": (C.c_int, [vp]),
+        "nss_dist_amg_apply_f64": (C.c_int, [vp, dbl, vp, vp, vp]),
         "nss_dist_profile_begin": (C.c_int, [vp, i32]),
         "nss_dist_profile_end": (C.c_int, [vp, c_double_p, c_i32_p]),
         "nss_bpcg2_iterate_dist": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, vp]),

@@ -256,6 +256,57 @@ def test_native_partitioned_minres_single_rank(hip_engine, tmp_path, pre):
         dist.destroy_process_group()
 
 
+def test_native_partitioned_amg_single_rank(hip_engine, tmp_path):
+    """The V-cycle with replicated coarse levels inside the NATIVE partitioned BPCG loop (nss_dist_amg_*: the C
+    loop issues the cycle's two halo exchanges and its coarse all-reduce itself), on a 1-rank RCCL communicator:
+    the native apply equals the host-driven `DistributedAMG.Mult`, and the solve -- preA = AMG and the additive
+    AMG + block Jacobi -- follows the single-GPU fused loop with the same hierarchy."""
+    import re
+    import torch.distributed as dist
+    import hipla
+    from distributed import DistributedBpcg2
+    from rccl_comm import RcclComm
+    from solvers.bramblepasciak_new import BramblePasciakCG
+    s = mac_stokes(3, 12, 0.01)
+    f, g = s.rhs(0)
+    tol, maxsteps = 1e-8, 2000
+
+    class Form:
+        def __init__(self, mat):
+            self.mat, self.condense = mat, False
+
+    dist.init_process_group("gloo", init_method="file://" + str(tmp_path / "rdv"), rank=0, world_size=1)
+    try:
+        comm = RcclComm(dist, hip_engine)
+        A, B = hipla.SparseMatrix.from_scipy(s.A), hipla.SparseMatrix.from_scipy(s.B)
+        V = hipla.SmoothedAggregationAMG(A)
+        for pre, single in (("amg", V), ("amg+bjac", V + hipla.BlockJacobi(A, s.line_blocks(3)))):
+            run = DistributedBpcg2(s, f, g, s.line_blocks(3), dist, hip_engine, comm=comm, pre=pre)
+            assert run.native is not None and run.dist_amg is not None
+            assert run.dist_amg.level_sizes == V.level_sizes
+            x = hipla.Vector.from_numpy(np.random.default_rng(3).standard_normal(s.n_u))
+            y_host, y_native = hipla.Vector(s.n_u), hipla.Vector(s.n_u)
+            y_host.data = run.dist_amg * x
+            run.dist_amg.native_apply(1.0, x, y_native)
+            assert np.linalg.norm(y_native.numpy() - y_host.numpy()) <= 1e-13 * np.linalg.norm(y_host.numpy())
+            it, conv = run.solve(tol=tol, maxsteps=maxsteps, poll_every=16)
+            assert conv
+            sol = hipla.BlockVector([hipla.Vector(s.n_u), hipla.Vector(s.n_p)])
+            out = io.StringIO()
+            with contextlib.redirect_stdout(out):
+                it_s, _ = BramblePasciakCG(Form(A), Form(B), None, hipla.Vector.from_numpy(f), hipla.Vector.from_numpy(g),
+                                           single, hipla.DiagonalMatrix(1.0 / s.mass), sol, tol=tol, maxsteps=maxsteps)
+            hist = np.array([float(m) for m in re.findall(r"it =\s+\d+\s+err =\s+(\S+)", out.getvalue())])
+            w = min(25, len(hist), it + 1)
+            np.testing.assert_allclose(run.history(it)[:w], hist[:w], rtol=1e-8)
+            assert abs(it - it_s) <= max(3, int(0.03 * it_s))
+            assert np.linalg.norm(run.sol[0].numpy() - sol[0].numpy()) < 1e-5 * np.linalg.norm(sol[0].numpy())
+            run.close()
+        comm.close()
+    finally:
+        dist.destroy_process_group()
+
+
 def test_interior_row_blocks_of_a_partitioned_matrix(hip_engine):
     """Row blocks flagged interior must not reference ghost columns; boundary blocks sit at the
     slab ends (checked on rank 1 of 3 without any communication)."""
