@@ -2,6 +2,7 @@
 // bramble_pasciak_cg.py:110-143; 6 SpMV per iteration as the reference).
 //
 //   S0   one lane : hist[it] = err/err0 (:115-118), stop test at the loop top (:119)
+//   (V1a + V1c and V3a + V3b are issued as one launch each: same operand, no mutual dependence)
 //   V1a  rows of A   : t1u = A du                                                     (:125)
 //   V1b  rows of B^T : ku = t1u + B^T dp;  t1u = -ku;  Jacobi: t2u = k dinv ku        (:125-126)
 //   [J]  block-Jacobi: t2u = -k J t1u                                                 (:126)
@@ -216,7 +217,13 @@ static void bpcg1_iteration(const nss_bpcg1_t& s, int it, hipStream_t st) {
   hipLaunchKernelGGL(bpcg1_scalar_kernel, dim3(1), dim3(kWave), 0, st, s.ctrl, s.scal, s.hist, 0, it, 0,
                      s.partials_a, 0, s.partials_b);
   NSS_CHECK_LAUNCH();
-  launch_csr_stream(*s.A, s.d[0], EpiStore1{s.ctrl, s.t1[0]}, st);
+  // V1a and V1c multiply the same operand (du) and do not depend on each other: one launch
+  const EpiStore1 e1a{s.ctrl, s.t1[0]};
+  const EpiV1c e1c{s.ctrl, s.t1[1], s.t2[1]};
+  if (!launch_csr_stream_dual(*s.A, s.d[0], e1a, *s.B, s.d[0], e1c, st)) {
+    launch_csr_stream(*s.A, s.d[0], e1a, st);
+    launch_csr_stream(*s.B, s.d[0], e1c, st);
+  }
   launch_csr_stream(*s.BT, s.d[1], EpiV1b{s.ctrl, s.t1[0], s.t2[0], s.pre_amg ? nullptr : s.pre_diag, s.k}, st);
   if (s.pre_amg) {                                         // t2 = -k (AMG + J) t1 (t1 holds -K u here)
     amg_apply(*s.pre_amg, -s.k, s.t1[0], s.t2[0], st);
@@ -228,9 +235,12 @@ static void bpcg1_iteration(const nss_bpcg1_t& s, int it, hipStream_t st) {
   } else if (s.pre_bjac) {
     bjac_apply(*s.pre_bjac, -s.k, s.t1[0], 0.0, s.t2[0], s.ctrl, st);
   }
-  launch_csr_stream(*s.B, s.d[0], EpiV1c{s.ctrl, s.t1[1], s.t2[1]}, st);
-  launch_csr_stream(*s.A, s.t2[0], EpiV3{s.ctrl, s.t1[0], s.d[0], s.partials_a}, st);
-  launch_csr_stream(*s.B, s.t2[0], EpiV3{s.ctrl, s.t1[1], s.d[1], s.partials_b}, st);
+  // V3a and V3b (operand t2u) likewise
+  const EpiV3 e3a{s.ctrl, s.t1[0], s.d[0], s.partials_a}, e3b{s.ctrl, s.t1[1], s.d[1], s.partials_b};
+  if (!launch_csr_stream_dual(*s.A, s.t2[0], e3a, *s.B, s.t2[0], e3b, st)) {
+    launch_csr_stream(*s.A, s.t2[0], e3a, st);
+    launch_csr_stream(*s.B, s.t2[0], e3b, st);
+  }
   hipLaunchKernelGGL(bpcg1_scalar_kernel, dim3(1), dim3(kPSum), 0, st, s.ctrl, s.scal, s.hist, 1, it, s.A->nblk,
                      s.partials_a, s.B->nblk, s.partials_b);
   NSS_CHECK_LAUNCH();
