@@ -60,7 +60,7 @@ def parse_args():
                          "(12 -> ~84 nnz per row as the reference's order-2 3-D spaces); preA = facet blocks")
     ap.add_argument("--cpu-iters", type=int, default=-1, help="oracle iterations to time (-1: auto, 0: skip)")
     ap.add_argument("--kernel-reps", type=int, default=30)
-    ap.add_argument("--hdg", type=int, default=28,
+    ap.add_argument("--hdg", type=int, default=36,
                     help="grid of the secondary HDG-like measurement (facet blocks of 12 dofs, ~84 non-zeros per "
                          "row: the reference's row regime, SURVEY.md A7); 0 skips it")
     return ap.parse_args()

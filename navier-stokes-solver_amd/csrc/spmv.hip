@@ -143,12 +143,27 @@ __global__ __launch_bounds__(kBlock) void col_group_pack_kernel(int64_t ngroups,
 static void group_columns(nss_csr_s& A, hipStream_t st) {
 #if NSS_COL_GROUPS
   if (!A.col16 || A.nnz < 16) return;
+  // host-side pre-filter on the first rows (a few KB): candidates that already fail there -- every
+  // candidate, for an operator without column runs -- never cost a pass over the matrix
+  const int32_t probe_rows = std::min<int32_t>(A.m, 256);
+  std::vector<int32_t> h_ptr(size_t(probe_rows) + 1);
+  NSS_HIP(hipMemcpy(h_ptr.data(), A.rowptr, sizeof(int32_t) * h_ptr.size(), hipMemcpyDeviceToHost));
+  std::vector<int32_t> h_col(size_t(std::max<int32_t>(1, h_ptr.back())));
+  if (h_ptr.back() > 0)
+    NSS_HIP(hipMemcpy(h_col.data(), A.col, sizeof(int32_t) * size_t(h_ptr.back()), hipMemcpyDeviceToHost));
+  auto plausible = [&](int gb) {
+    for (int32_t r = 0; r <= probe_rows; ++r)
+      if (h_ptr[size_t(r)] % gb != 0) return false;
+    for (int32_t p = 1; p < h_ptr.back(); ++p)
+      if (p % gb != 0 && h_col[size_t(p)] != h_col[size_t(p) - 1] + 1) return false;
+    return true;
+  };
   int32_t* bad = nullptr;
   uint16_t* packed = nullptr;
   try {
     NSS_HIP(hipMalloc(&bad, sizeof(int32_t)));
     for (int gb = 16; gb >= 2; --gb) {
-      if (A.nnz % gb != 0) continue;
+      if (A.nnz % gb != 0 || !plausible(gb)) continue;
       NSS_HIP(hipMemsetAsync(bad, 0, sizeof(int32_t), st));
       hipLaunchKernelGGL(col_group_check_kernel, dim3(stream_grid(A.nnz, kBlock * 4)), dim3(kBlock), 0, st, A.m, A.nnz,
                          A.rowptr, A.col, gb, bad);
