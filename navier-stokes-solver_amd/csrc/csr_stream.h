@@ -38,6 +38,10 @@ namespace nss {
 #define NSS_STREAM_PREFETCH 1   // request row bounds + epilogue operands before the matrix stream
 #endif
 
+#ifndef NSS_PREFETCH_ROWS
+#define NSS_PREFETCH_ROWS 1     // phase-2 rows per lane whose bounds and epilogue operands are requested up front (RG == 1)
+#endif
+
 #ifndef NSS_STREAM_VEC2
 #define NSS_STREAM_VEC2 0   // 1: 16-byte (val) / 8-byte (col) loads, two consecutive entries per lane
 #endif
@@ -199,13 +203,21 @@ __device__ __forceinline__ void csr_stream_body(const CsrView& a, const double* 
     const int p0 = a.rowptr[r0];
     const int cnt = a.rowptr[r1] - p0;
 #if NSS_STREAM_PREFETCH
-    // Row bounds and epilogue operands of this lane's first phase-2 row are requested now, so
-    // their HBM latency overlaps the matrix stream instead of following the barrier.
+    // Row bounds and epilogue operands of this lane's first phase-2 rows (kPF of them: short-row matrices
+    // give a lane several rows) are requested now, so their HBM latency overlaps the matrix stream instead
+    // of following the barrier.
+    constexpr int kPF = RG == 1 ? NSS_PREFETCH_ROWS : 1;
     const int rf = r0 + tid / RG;
-    const bool has_first = rf < r1;
-    const int rf_s = has_first ? a.rowptr[rf] : 0;
-    const int rf_e = has_first ? a.rowptr[rf + 1] : 0;
-    typename EpiPre<Epi>::type pre0 = has_first ? EpiPre<Epi>::fetch(epi, rf) : typename EpiPre<Epi>::type{};
+    int rf_s[kPF], rf_e[kPF];
+    typename EpiPre<Epi>::type pre[kPF];
+#pragma unroll
+    for (int j = 0; j < kPF; ++j) {
+      const int rj = rf + j * (kBlock / RG);
+      const bool has = rj < r1;
+      rf_s[j] = has ? a.rowptr[rj] : 0;
+      rf_e[j] = has ? a.rowptr[rj + 1] : 0;
+      pre[j] = has ? EpiPre<Epi>::fetch(epi, rj) : typename EpiPre<Epi>::type{};
+    }
 #endif
     if (cnt <= CH) {
       // ---- phase 1: coalesced stream of (col, val), gather x, stage products ---------
@@ -262,17 +274,30 @@ __device__ __forceinline__ void csr_stream_body(const CsrView& a, const double* 
       constexpr int kRowsPerPass = kBlock / RG;
       const int sub = tid % RG;
 #if NSS_STREAM_PREFETCH
-      for (int r = rf; r < r1; r += kRowsPerPass) {
-        const bool first = r == rf;
-        const int s = (first ? rf_s : a.rowptr[r]) - p0;
-        const int e = (first ? rf_e : a.rowptr[r + 1]) - p0;
+#pragma unroll
+      for (int q = 0; q < kPF; ++q) {                      // the prefetched rows
+        const int r = rf + q * kRowsPerPass;
+        if (r < r1) {
+          const int s = rf_s[q] - p0, e = rf_e[q] - p0;
+          double sum = 0.0;
+          for (int j = s + sub; j < e; j += RG) sum += prod[j];
+          if (RG > 1) {
+#pragma unroll
+            for (int off = RG / 2; off > 0; off >>= 1) sum += __shfl_xor(sum, off, kWave);
+          }
+          if (sub == 0) EpiPre<Epi>::row(epi, r, sum, pre[q]);
+        }
+      }
+      for (int r = rf + kPF * kRowsPerPass; r < r1; r += kRowsPerPass) {
+        const int s = a.rowptr[r] - p0;
+        const int e = a.rowptr[r + 1] - p0;
         double sum = 0.0;
         for (int j = s + sub; j < e; j += RG) sum += prod[j];
         if (RG > 1) {
 #pragma unroll
           for (int off = RG / 2; off > 0; off >>= 1) sum += __shfl_xor(sum, off, kWave);
         }
-        if (sub == 0) EpiPre<Epi>::row(epi, r, sum, first ? pre0 : EpiPre<Epi>::fetch(epi, r));
+        if (sub == 0) EpiPre<Epi>::row(epi, r, sum, EpiPre<Epi>::fetch(epi, r));
       }
 #else
       for (int r = r0 + tid / RG; r < r1; r += kRowsPerPass) {
