@@ -398,7 +398,11 @@ def main():
         k2_gbs = k2_bytes / (k2_ms * 1e-3) / 1e9
         dist.barrier()
         # which collective costs what: per-phase device times of further iterations of the SAME loop
-        phase_ms, phase_n = run.profile(total_its, prof_its)
+        try:
+            phase_ms, phase_n = run.profile(total_its, prof_its)
+        except Exception as exc:                     # never lose the result line over the diagnostics
+            print("rank %d: per-phase profile failed: %r" % (rank, exc), file=sys.stderr)
+            phase_ms, phase_n = None, 0
         dist.barrier()
         if rank == 0:
             out = {
