@@ -493,12 +493,24 @@ struct EpiK1c {
   __device__ X xop(const double*) const { return X{s1, w1, beta, it == 0}; }
   // the row's six read-only operands are requested before the matrix stream (and before alpha / beta
   // are known: the prologue runs later)
+  // requesting the row's six operands before the matrix stream costs 12 registers (occupancy 8 -> 6 waves per
+  // SIMD) and measured 0.7 % slower at 1e7 DoF, no different at 1e5 (profiles/r02_ab_k1_prefetch.txt): off
+#ifndef NSS_K1C_PREFETCH
+#define NSS_K1C_PREFETCH 0
+#endif
+#if NSS_K1C_PREFETCH
   struct Pre { double q = 0.0, z0 = 0.0, t2 = 0.0, s0 = 0.0, w0 = 0.0, u0 = 0.0; };
   __device__ Pre fetch(int r) const {
     if (it == 0) return Pre{q[r], 0.0, 0.0, 0.0, 0.0, 0.0};
     return Pre{q[r], z0[r], t2[r], s0[r], w0[r], u0[r]};
   }
   __device__ void row(int r, double bts, const Pre& p) const {
+#else
+  struct PreLate { double q, z0, t2, s0, w0, u0; };
+  __device__ void row(int r, double bts) const {
+    const PreLate p{q[r], it ? z0[r] : 0.0, it ? t2[r] : 0.0, it ? s0[r] : 0.0, it ? w0[r] : 0.0,
+                    (it && pending) ? u0[r] : 0.0};
+#endif
     double qv = p.q;
     if (it != 0) {
       const double zo = p.z0, t2v = p.t2, so = p.s0;
