@@ -45,10 +45,11 @@ def iteration_tolerance(d):
     """Allowed |iterations - golden|.  The survey proposed +-max(2, 1 %) (SURVEY.md section 8c ii); measured, a
     count cannot be pinned that tightly: the BPCG error functional is not monotone near the tolerance, and
     changing nothing but the summation order of the inner products moves the count of the CPU oracle itself by
-    up to 2 % (296 -> 302 on stokes2d_n12_jacobi_bpcg1; the GPU statement-by-statement path lands on 301 for
-    stokes2d_n12_jacobi_bpcg2 where the fused loop and the golden have 296).  Every fixture records the spread
-    of one such perturbation (``iterations_perturbed``); the band is max(2, 2 %, twice that spread) -- round 1
-    used max(3, 3 %, twice the spread)."""
+    up to 2 % (296 -> 302 on stokes2d_n12_jacobi_bpcg1).  Tightening the band to max(2, 2 %, 2 x spread) was
+    tried in round 2 and fails on correct runs: the GPU statement-by-statement path needs 301 iterations where
+    the fused loop and the golden need 296, the fused loop 377 where a golden has 386 (2.3 %) -- all with
+    histories equal to 1e-8 over the stable window.  Every fixture records the spread of one such perturbation
+    (``iterations_perturbed``); the band stays max(3, 3 %, twice that spread)."""
     ref = int(d["iterations"])
     spread = abs(ref - int(d["iterations_perturbed"])) if "iterations_perturbed" in d else 0
-    return max(2, int(0.02 * ref + 0.999), 2 * spread)
+    return max(3, int(0.03 * ref + 0.999), 2 * spread)
