@@ -132,6 +132,12 @@ NSS_API int nss_csr_spmv_f64(nss_csr_t a, double alpha, const double* x, double 
  * aligned runs of g consecutive columns (block-structured operators, e.g. facet blocks of 5 / 12 dofs) and
  * the SpMV kernel streams one 16-bit index per run -- 8 + 2/g bytes per non-zero. */
 NSS_API int nss_csr_index_group(nss_csr_t a, int32_t* entries_per_index);
+/* how the SpMV kernels reach the operand x: 0 = 4-byte columns, gather; 1 = 16-bit window-relative columns,
+ * gather; 2 = staged -- per row block the runs of consecutive columns it touches are copied to LDS with
+ * LDS-DMA issued ahead of the matrix stream, and the 16-bit index is a position in that copy (taken when every
+ * row block touches at most 13 runs / `chunk` columns; kernels whose operand is an expression of two vectors
+ * use form 1 of the same matrix). */
+NSS_API int nss_csr_operand_form(nss_csr_t a, int32_t* form);
 /* shape, nnz, launch plan (row blocks, lanes per row) and algorithmic bytes of one
  * SpMV: 12*nnz + 4*(rows+1) + 8*cols + 8*rows */
 NSS_API int nss_csr_info(nss_csr_t a, int32_t* nrows, int32_t* ncols, int64_t* nnz,

@@ -488,6 +488,7 @@ struct EpiK1c {
     const double* __restrict__ w1;
     double beta;
     bool first;
+    static constexpr bool kStageable = false;   // an expression of two vectors: gathered
     __device__ double operator()(int c) const { return first ? s1[c] : fma(beta, s1[c], w1[c]); }   // :240-241
   };
   __device__ X xop(const double*) const { return X{s1, w1, beta, it == 0}; }
@@ -570,6 +571,7 @@ struct EpiK3c {
   struct X {
     const double* __restrict__ t1;
     const double* __restrict__ s0;
+    static constexpr bool kStageable = false;   // an expression of two vectors: gathered
     __device__ double operator()(int c) const { return t1[c] - s0[c]; }
   };
   __device__ X xop(const double*) const { return X{t1, s0}; }

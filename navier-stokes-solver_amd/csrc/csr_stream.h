@@ -5,8 +5,9 @@
 // its 64 lanes.  Instead a 256-thread workgroup owns a contiguous *row block* whose
 // non-zeros fit one LDS chunk:
 //   phase 1  every lane streams val[] / col[] with unit stride (fully coalesced HBM
-//            reads, 8 independent loads in flight per lane), gathers x[col] (served by
-//            L2 / Infinity Cache for banded operators) and stages the products in LDS;
+//            reads, 8 independent loads in flight per lane), takes x[col] -- from an LDS copy of
+//            the row block's operand segments (staged form, below) or by a gather served by
+//            L2 / Infinity Cache -- and stages the products in LDS;
 //   phase 2  each row is reduced from LDS by RG lanes (RG = 1 ... 64, a power of two chosen from
 //            the mean row length) with a __shfl_xor butterfly, in a fixed order -- no
 //            atomics, bit-reproducible;
@@ -62,13 +63,19 @@ constexpr int kMaxRowsPerBlock = 2048;  // bound for blocks of empty / very shor
 constexpr int kXcds = 8;
 constexpr int kWindows = 16;          // column windows per row block of the 16-bit index stream
 constexpr int kWindowBits = 12;      // 4096 columns per window
+// Staged operand (nss_csr_s::blkseg): per row block at most kSegMax runs of consecutive columns, together at
+// most `chunk` columns (the products per row block), copied to LDS by LDS-DMA ahead of the matrix stream.
+constexpr int kSegMax = 13;             // (the LDS copy holds up to `chunk` columns: it shares the product buffer)
+constexpr int kSegWords = 32;        // descriptor: r0, r1, p0, cnt, nseg, total, pre[1..12], off[0..12], spare
+constexpr int kSegPre = 6, kSegOff = 18;
 
 struct CsrView {
   const int32_t* __restrict__ rowblk;
   const int32_t* __restrict__ rowptr;
   const int32_t* __restrict__ col;
-  const uint16_t* __restrict__ col16;   // (window << 12 | offset) per entry, or NULL (see nss_csr_s)
-  const int32_t* __restrict__ blkbase;  // kWindows window bases per row block
+  const uint16_t* __restrict__ col16;   // the 16-bit stream of `mode` (window-relative columns or staged positions), or NULL
+  const int32_t* __restrict__ blkbase;  // kWindows window bases per row block (mode 1)
+  const int32_t* __restrict__ blkseg;   // kSegWords per row block (mode 2)
   const double* __restrict__ val;
   uint32_t gb;      // entries per column group of the 16-bit stream (1: one index per entry)
   uint32_t gstep, sstep;   // kBlock / gb, kBlock % gb: a lane's next entry is kBlock further down the stream
@@ -76,6 +83,8 @@ struct CsrView {
   int32_t blk0;     // first row block of this launch (sub-range launches: interior / boundary)
   int32_t nblk;     // row blocks in this launch
   int32_t per_xcd;  // ceil(nblk / 8)
+  int32_t mode;     // how the operand is reached: 0 = 4-byte columns, gather; 1 = 16-bit window-relative columns,
+                    // gather; 2 = staged (LDS copy of the row block's operand segments, 16-bit positions)
 };
 
 }  // namespace nss
@@ -98,19 +107,36 @@ struct nss_csr_s {
   // products in the same order.  `col` is kept for the set-up kernels and rows longer than a chunk.
   uint16_t* col16 = nullptr;
   int32_t* blkbase = nullptr;
+  // Staged operand (preferred where the kernel's operand is one stored vector).  Measured on gfx950
+  // (tools/spmv_probe.py, profiles/r02_gather_probe.txt): what keeps the stream kernel at ~5 TB/s is not the
+  // bytes of the x gather but the gather itself, a second round of per-lane loads that can only be issued when
+  // the column stream has arrived -- with the operand read from LDS instead, the same kernel streams 6.2 TB/s at
+  // 7 and at 82 non-zeros per row.  So: when the columns a row block touches form at most kSegMax runs of
+  // consecutive columns (gaps of up to 7 unused columns are bridged) with at most kStageCap columns in total --
+  // grid operators: one run per stencil leg; block-structured operators: the block columns of a few block rows
+  // -- `blkseg` holds the runs and pos16 holds, per entry, the POSITION of its column in the concatenation of
+  // the runs.  The kernel copies the runs from x into LDS by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave
+  // instruction, no VGPR destination), issued BEFORE the matrix stream (the copy does not depend on it), and
+  // reads the operand from LDS: no window decode, no dependent gather.  Same products, same order, same results.
+  // A matrix is staged only when every one of its row blocks fits.  The window form is kept beside it for
+  // kernels whose operand is an expression of two vectors (they gather).
+  uint16_t* pos16 = nullptr;
+  int32_t* blkseg = nullptr;
   // Grouped column stream (block-structured operators: the facet blocks of the HDG-like spaces, ~84
   // non-zeros per row in runs of 12 consecutive columns): when every row length is a multiple of `gb`
-  // and every aligned group of `gb` consecutive entries has consecutive columns, col16 holds ONE 16-bit
-  // index per group -- 8 + 2/gb bytes per non-zero instead of 10 -- and entry p has column
-  // decode(col16[p / gb]) + p % gb.  The value order stays CSR (rows contiguous), so the kernel, its
+  // and every aligned group of `gb` consecutive entries has consecutive columns, col16 / pos16 hold ONE 16-bit
+  // index per group -- 8 + 2/gb bytes per non-zero instead of 10 -- and entry p has column (position)
+  // decode(index[p / gb]) + p % gb.  The value order stays CSR (rows contiguous), so the kernel, its
   // reduction order and its results are unchanged.  gb == 1: one index per entry.
   int32_t gb = 1;
+  // `stageable`: the kernel's operand functor can be copied to LDS (XOp::kStageable)
+  int idx_mode(bool stageable = true) const { return (blkseg && stageable) ? 2 : (col16 ? 1 : 0); }
   // launch view of the row blocks [b0, b1)
-  nss::CsrView view(int b0, int b1) const {
+  nss::CsrView view(int b0, int b1, int mode) const {
     const uint64_t magic = gb > 1 ? ~uint64_t(0) / uint64_t(gb) + 1 : 0;    // ceil(2^64 / gb)
-    return nss::CsrView{rowblk, rowptr, col, col16, blkbase, val, uint32_t(gb), uint32_t(nss::kBlock / gb),
-                        uint32_t(nss::kBlock % gb), magic, b0, b1 - b0,
-                        (b1 - b0 + nss::kXcds - 1) / nss::kXcds};
+    return nss::CsrView{rowblk, rowptr, col, mode == 2 ? pos16 : (mode == 1 ? col16 : nullptr), blkbase, blkseg, val,
+                        uint32_t(gb), uint32_t(nss::kBlock / gb), uint32_t(nss::kBlock % gb), magic, b0, b1 - b0,
+                        (b1 - b0 + nss::kXcds - 1) / nss::kXcds, mode};
   }
   // one workgroup per row block, padded to a multiple of the XCD count
   static int grid(int count) { return ((count + nss::kXcds - 1) / nss::kXcds) * nss::kXcds; }
@@ -143,7 +169,11 @@ void plan_row_blocks(int32_t m, int64_t nnz, const int32_t* rowptr, int32_t* rg_
 //                                                   // operand at column c (default: x[c]); lets a kernel
 //                                                   // multiply with a vector that is only defined by a
 //                                                   // recurrence, e.g. beta * s[c] + w[c], without a pass
-//                                                   // that materialises it first
+//                                                   // that materialises it first.  X::kStageable says
+//                                                   // whether the operand is one stored vector (ptr()) with a
+//                                                   // scalar map value(raw) on top: only those can use the
+//                                                   // staged form of a matrix; xop() is called before the
+//                                                   // prologue for ptr() and after it for value() / ().
 template <class E, class = void>
 struct EpiPre {
   struct type {};
@@ -159,7 +189,18 @@ struct EpiPre<E, std::void_t<typename E::Pre>> {
 
 struct XPlain {
   const double* __restrict__ x;
+  // an operand that is ONE stored vector (times a scalar at most) can be staged: ptr() is copied to LDS as it is
+  // and value() applied to what is read back
+  static constexpr bool kStageable = true;
+  __device__ const double* ptr() const { return x; }
+  __device__ double value(double r) const { return r; }
+#if defined(NSS_PROBE_GATHER) && NSS_PROBE_GATHER == 1      // timing probes only (tools/spmv_probe.py): wrong results
+  __device__ double operator()(int c) const { return 1.0 + 1e-12 * double(c); }   // no operand gather at all
+#elif defined(NSS_PROBE_GATHER) && NSS_PROBE_GATHER == 2
+  __device__ double operator()(int c) const { return x[c & 1023]; }               // every gather an L1 hit
+#else
   __device__ double operator()(int c) const { return x[c]; }
+#endif
 };
 template <class E, class = void>
 struct EpiX {
@@ -182,14 +223,118 @@ struct EpiPrologue<E, std::void_t<decltype(std::declval<E&>().prologue(static_ca
 
 constexpr int kRedDoubles = 32;   // per-workgroup reduction scratch (block_sum: 4, fixed_sum_1024: 32)
 
+// Phase 1 of one row block for ONE form of the column stream (IDX: 0 = 4-byte columns, 1 = 16-bit
+// window-relative columns, 2 = staged positions; GRP: one 16-bit index per group of a.gb entries): request the
+// column and value streams, run the epilogue's prologue while they are in flight, take the operand (gather, or
+// the LDS copy the caller has requested) and leave the products in `prod`.  Returns false when the prologue ends
+// the workgroup.  The kernel selects the form at run time with uniform branches AROUND this function, and every
+// form is straight-line code from the first load to the last product: with the branches inside (one loop per
+// form, a common tail) hipcc waited for vmcnt(0) at the joins -- the column stream had to arrive before the
+// value stream was even requested (seen in the ISA; plain SpMV of B^T +9 %).
+template <class Epi, int KPF>
+struct RowPrefetch {
+  int s[KPF], e[KPF];
+  typename EpiPre<Epi>::type pre[KPF];
+};
+
+template <class Epi, int CH, int IDX, bool GRP, int KPF>
+__device__ __forceinline__ bool csr_phase1(const CsrView& a, const double* __restrict__ x, Epi& epi, int b, int p0,
+                                           int cnt, double* prod, double* red, int32_t* window,
+                                           RowPrefetch<Epi, KPF>& pf, int rf, int rstep, int r1) {
+  static_assert(IDX != 0 || !GRP, "grouped column stream needs a 16-bit form");
+  using XOp = typename EpiX<Epi>::type;
+  constexpr int kPer = CH / kBlock;
+  const int tid = threadIdx.x;
+  int32_t c[kPer];                                       // column (IDX 0), else position inside the group
+  double v[kPer];
+  uint16_t c16[kPer];
+  if (IDX == 1) {
+    if (tid < kWindows) window[tid] = a.blkbase[b * kWindows + tid];
+  }
+  uint32_t grp = 0, gsub = 0;                            // group of this lane's entry, position inside it
+  if (GRP) {
+    const uint32_t p = uint32_t(p0 + tid);
+    grp = a.gb > 1 ? uint32_t(__umul64hi(uint64_t(p), a.gmagic)) : p;   // one division per lane, then incremental
+    gsub = p - grp * a.gb;
+  }
+#pragma unroll
+  for (int k = 0; k < kPer; ++k) {
+    const int i = tid + k * kBlock;
+    const bool live = i < cnt;
+    if (GRP) {                                           // one index per group of a.gb entries
+      c16[k] = live ? a.col16[grp] : uint16_t(0);        // shared by a.gb neighbouring lanes
+      c[k] = int32_t(gsub);
+      gsub += a.sstep;
+      grp += a.gstep + (gsub >= a.gb ? 1u : 0u);
+      gsub -= gsub >= a.gb ? a.gb : 0u;
+    }
+#if NSS_STREAM_NT
+    if (IDX != 0 && !GRP) c16[k] = live ? __builtin_nontemporal_load(&a.col16[p0 + i]) : uint16_t(0);
+    if (IDX == 0) c[k] = live ? __builtin_nontemporal_load(&a.col[p0 + i]) : 0;
+    v[k] = live ? __builtin_nontemporal_load(&a.val[p0 + i]) : 0.0;
+#else
+    if (IDX != 0 && !GRP) c16[k] = live ? a.col16[p0 + i] : uint16_t(0);
+    if (IDX == 0) c[k] = live ? a.col[p0 + i] : 0;
+    v[k] = live ? a.val[p0 + i] : 0.0;
+#endif
+  }
+  // behind the matrix stream and in the same straight-line code (requested in front of it, the register
+  // allocator re-used their destination registers for stream addresses and the compiler waited for them in the
+  // middle of the stream -- seen in the ISA)
+#if NSS_STREAM_PREFETCH
+#pragma unroll
+  for (int j = 0; j < KPF; ++j) {
+    const int rj = rf + j * rstep;
+    const bool has = rj < r1;
+    pf.s[j] = has ? a.rowptr[rj] : 0;
+    pf.e[j] = has ? a.rowptr[rj + 1] : 0;
+    pf.pre[j] = has ? EpiPre<Epi>::fetch(epi, rj) : typename EpiPre<Epi>::type{};
+  }
+#endif
+  if (!EpiPrologue<Epi>::run(epi, red)) return false;    // uniform over the workgroup
+  const XOp xop = EpiX<Epi>::get(epi, x);
+  double xv[kPer];
+  if constexpr (IDX == 2) {
+    __syncthreads();                                     // the LDS copy has landed (the barrier drains the DMA)
+#pragma unroll
+    for (int k = 0; k < kPer; ++k)
+      xv[k] = (tid + k * kBlock < cnt) ? xop.value(prod[int(c16[k]) + (GRP ? c[k] : 0)]) : 0.0;
+    __syncthreads();                                     // ... and has been read: the buffer takes the products
+  } else {
+    if (IDX == 1) {
+      __syncthreads();                                   // window bases in LDS
+#pragma unroll
+      for (int k = 0; k < kPer; ++k)
+        c[k] = window[c16[k] >> kWindowBits] + int32_t(c16[k] & ((1 << kWindowBits) - 1)) + (GRP ? c[k] : 0);
+    }
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      // columns are non-negative: without the hint the sign extension of a loaded 4-byte column is hoisted to
+      // right behind its load, and every column load is followed by a wait (seen in the ISA)
+      __builtin_assume(c[k] >= 0);
+      xv[k] = (tid + k * kBlock < cnt) ? xop(c[k]) : 0.0;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < kPer; ++k)
+    if (tid + k * kBlock < cnt) prod[tid + k * kBlock] = v[k] * xv[k];
+  return true;
+}
+
+typedef __attribute__((address_space(3))) void* LdsDst;
+typedef const __attribute__((address_space(1))) void* GlobalSrc;
+
 // One workgroup = one row block: `wg` is the workgroup's index inside this launch's grid part.
-// The epilogue's optional prologue (sum of the previous kernel's dot partials -> alpha / beta) runs AFTER the
-// row block's col / val loads have been issued and before the operand gather, which is the first thing that
-// may need its result: the partials arrive while the matrix stream is in flight instead of in front of it
-// (small, launch-bound systems: ~2 us per kernel).  A prologue that returns false ends the workgroup.
-template <int RG, class Epi, bool C16, int CH, bool GRP>
+// IDX / GRP: the form of the column stream (csr_phase1).  They are template parameters of the kernels: a run-time
+// selection inside one kernel was tried (a fifth of the instantiations) and lost 6-10 % on the short-row
+// operators -- with alternative paths in one kernel hipcc's wait-count insertion turns conservative at the joins
+// and waits for vmcnt(0) in the middle of the matrix stream (seen in the ISA).  The one run-time branch left is
+// the staged kernel's fallback for row blocks that do not fit the LDS copy.
+template <int RG, class Epi, int IDX, int CH, bool GRP>
 __device__ __forceinline__ void csr_stream_body(const CsrView& a, const double* __restrict__ x, Epi& epi, int wg,
                                                 double* prod, double* red, int32_t* window) {
+  using XOp = typename EpiX<Epi>::type;
+  static_assert(IDX != 2 || XOp::kStageable, "staged form with an operand that cannot be copied to LDS");
   const int tid = threadIdx.x;
   // XCD-aware map: workgroups with equal (index & 7) share an XCD; XCD i owns the i-th
   // contiguous eighth of the row blocks.  One row block per workgroup: a striding
@@ -198,77 +343,58 @@ __device__ __forceinline__ void csr_stream_body(const CsrView& a, const double* 
   const int lb = (wg & (kXcds - 1)) * a.per_xcd + (wg >> 3);
   const int b = lb < a.nblk ? a.blk0 + lb : -1;
   if (b >= 0) {
-    const int r0 = a.rowblk[b];
-    const int r1 = a.rowblk[b + 1];
-    const int p0 = a.rowptr[r0];
-    const int cnt = a.rowptr[r1] - p0;
-#if NSS_STREAM_PREFETCH
+    int r0 = 0, r1 = 0, p0 = 0, cnt = 0;
+    if constexpr (IDX == 2) {
+      // One descriptor per row block instead of the rowblk -> rowptr chain.  It must arrive through SCALAR loads
+      // (the run table then sits in SGPRs); the constant address space makes the loads invariant, and a uniform
+      // invariant load is an s_load -- as vector loads (what the compiler emitted in the two-matrix kernel) every
+      // use below would wait for vmcnt(0).
+      typedef const int32_t __attribute__((address_space(4))) * ConstI32;
+      const ConstI32 d = (ConstI32)(a.blkseg + size_t(b) * kSegWords);
+      r0 = d[0];
+      r1 = d[1];
+      p0 = d[2];
+      cnt = d[3];
+      const int total = d[5];                              // 0 for a row block that is one over-long row
+      // The operand segments of this row block -> LDS (the product buffer, until every lane has taken its
+      // values), by LDS-DMA: a wave instruction moves 64 x 16 bytes = 128 consecutive staged positions to
+      // wave-uniform base + 16 * lane; each lane supplies the source address of its pair (segments start at
+      // even positions and have even lengths: spmv.hip).  Issued BEFORE the matrix stream, on which it does
+      // not depend; ptr() only: the prologue has not run yet.
+      int32_t seg_pre[kSegMax - 1], seg_off[kSegMax];
+#pragma unroll
+      for (int s = 0; s < kSegMax - 1; ++s) seg_pre[s] = d[kSegPre + s];
+#pragma unroll
+      for (int s = 0; s < kSegMax; ++s) seg_off[s] = d[kSegOff + s];
+      const double* __restrict__ src = EpiX<Epi>::get(epi, x).ptr();
+      const int wave = tid / kWave, lane = tid % kWave;
+#pragma unroll
+      for (int j = 0; j < CH / (2 * kBlock); ++j) {
+        const int base = j * 2 * kBlock + wave * 2 * kWave;
+        const int pos = base + 2 * lane;
+        int o = seg_off[0];
+#pragma unroll
+        for (int s = 1; s < kSegMax; ++s) o = pos >= seg_pre[s - 1] ? seg_off[s] : o;
+        if (pos < total) __builtin_amdgcn_global_load_lds((GlobalSrc)(src + pos + o), (LdsDst)(prod + base), 16, 0, 0);
+      }
+    } else {
+      r0 = a.rowblk[b];
+      r1 = a.rowblk[b + 1];
+      p0 = a.rowptr[r0];
+      cnt = a.rowptr[r1] - p0;
+    }
     // Row bounds and epilogue operands of this lane's first phase-2 rows (kPF of them: short-row matrices
-    // give a lane several rows) are requested now, so their HBM latency overlaps the matrix stream instead
-    // of following the barrier.
+    // give a lane several rows): requested inside phase 1, right behind the matrix stream, so that their HBM
+    // latency overlaps it instead of following the barrier.
     constexpr int kPF = RG == 1 ? NSS_PREFETCH_ROWS : 1;
     const int rf = r0 + tid / RG;
-    int rf_s[kPF], rf_e[kPF];
-    typename EpiPre<Epi>::type pre[kPF];
-#pragma unroll
-    for (int j = 0; j < kPF; ++j) {
-      const int rj = rf + j * (kBlock / RG);
-      const bool has = rj < r1;
-      rf_s[j] = has ? a.rowptr[rj] : 0;
-      rf_e[j] = has ? a.rowptr[rj + 1] : 0;
-      pre[j] = has ? EpiPre<Epi>::fetch(epi, rj) : typename EpiPre<Epi>::type{};
-    }
-#endif
+    RowPrefetch<Epi, kPF> pf;
     if (cnt <= CH) {
-      // ---- phase 1: coalesced stream of (col, val), gather x, stage products ---------
       constexpr int kPer = CH / kBlock;
-      int32_t c[kPer];
-      double v[kPer];
-      uint16_t c16[kPer];
-      if (C16) {
-        if (tid < kWindows) window[tid] = a.blkbase[b * kWindows + tid];
-      }
-      uint32_t grp = 0, gsub = 0;                          // group of this lane's entry, position inside it
-      if (C16 && GRP) {
-        const uint32_t p = uint32_t(p0 + tid);
-        grp = a.gb > 1 ? uint32_t(__umul64hi(uint64_t(p), a.gmagic)) : p;   // one division per lane, then incremental
-        gsub = p - grp * a.gb;
-      }
-#pragma unroll
-      for (int k = 0; k < kPer; ++k) {
-        const int i = tid + k * kBlock;
-        const bool live = i < cnt;
-        if (C16 && GRP) {                                  // one index per group of a.gb entries
-          c16[k] = live ? a.col16[grp] : uint16_t(0);      // shared by a.gb neighbouring lanes
-          c[k] = int32_t(gsub);
-          gsub += a.sstep;
-          grp += a.gstep + (gsub >= a.gb ? 1u : 0u);
-          gsub -= gsub >= a.gb ? a.gb : 0u;
-        }
-#if NSS_STREAM_NT
-        if (C16 && !GRP) c16[k] = live ? __builtin_nontemporal_load(&a.col16[p0 + i]) : uint16_t(0);
-        if (!C16) c[k] = live ? __builtin_nontemporal_load(&a.col[p0 + i]) : 0;
-        v[k] = live ? __builtin_nontemporal_load(&a.val[p0 + i]) : 0.0;
-#else
-        if (C16 && !GRP) c16[k] = live ? a.col16[p0 + i] : uint16_t(0);
-        if (!C16) c[k] = live ? a.col[p0 + i] : 0;
-        v[k] = live ? a.val[p0 + i] : 0.0;
-#endif
-      }
-      if (!EpiPrologue<Epi>::run(epi, red)) return;        // uniform over the workgroup
-      const auto xop = EpiX<Epi>::get(epi, x);
-      if (C16) {
-        __syncthreads();                                   // window bases in LDS
-#pragma unroll
-        for (int k = 0; k < kPer; ++k)
-          c[k] = window[c16[k] >> kWindowBits] + int32_t(c16[k] & ((1 << kWindowBits) - 1)) + (GRP ? c[k] : 0);
-      }
-      double xv[kPer];
-#pragma unroll
-      for (int k = 0; k < kPer; ++k) xv[k] = (tid + k * kBlock < cnt) ? xop(c[k]) : 0.0;
-#pragma unroll
-      for (int k = 0; k < kPer; ++k)
-        if (tid + k * kBlock < cnt) prod[tid + k * kBlock] = v[k] * xv[k];
+      (void)kPer;
+      // ---- phase 1: coalesced stream of (col, val), operand, stage products ------------
+      const bool go = csr_phase1<Epi, CH, IDX, GRP, kPF>(a, x, epi, b, p0, cnt, prod, red, window, pf, rf, kBlock / RG, r1);
+      if (!go) return;                                     // the prologue ended the workgroup (uniform)
       __syncthreads();
       // ---- phase 2: per-row reduction from LDS -----------------------------------------
       constexpr int kRowsPerPass = kBlock / RG;
@@ -278,14 +404,14 @@ __device__ __forceinline__ void csr_stream_body(const CsrView& a, const double* 
       for (int q = 0; q < kPF; ++q) {                      // the prefetched rows
         const int r = rf + q * kRowsPerPass;
         if (r < r1) {
-          const int s = rf_s[q] - p0, e = rf_e[q] - p0;
+          const int s = pf.s[q] - p0, e = pf.e[q] - p0;
           double sum = 0.0;
           for (int j = s + sub; j < e; j += RG) sum += prod[j];
           if (RG > 1) {
 #pragma unroll
             for (int off = RG / 2; off > 0; off >>= 1) sum += __shfl_xor(sum, off, kWave);
           }
-          if (sub == 0) EpiPre<Epi>::row(epi, r, sum, pre[q]);
+          if (sub == 0) EpiPre<Epi>::row(epi, r, sum, pf.pre[q]);
         }
       }
       for (int r = rf + kPF * kRowsPerPass; r < r1; r += kRowsPerPass) {
@@ -315,7 +441,7 @@ __device__ __forceinline__ void csr_stream_body(const CsrView& a, const double* 
     } else {
       // ---- one row longer than the LDS chunk: the whole workgroup reduces it ----------
       if (!EpiPrologue<Epi>::run(epi, red)) return;
-      const auto xop = EpiX<Epi>::get(epi, x);
+      const XOp xop = EpiX<Epi>::get(epi, x);
       double acc = 0.0;
       for (int i = tid; i < cnt; i += kBlock) acc = fma(a.val[p0 + i], xop(a.col[p0 + i]), acc);
       const double sum = block_sum(acc, red);
@@ -325,19 +451,20 @@ __device__ __forceinline__ void csr_stream_body(const CsrView& a, const double* 
   epi.finish(b, red);  // one dot partial per row block
 }
 
-template <int RG, class Epi, bool C16 = false, int CH = kChunk, bool GRP = false>
+template <int RG, class Epi, int IDX = 0, int CH = kChunk, bool GRP = false>
 __global__ __launch_bounds__(kBlock) void csr_stream_kernel(CsrView a, const double* __restrict__ x, Epi epi) {
   __shared__ double prod[CH];
   __shared__ double red[kRedDoubles];
   __shared__ int32_t window[kWindows];
   if (epi.skip()) return;
-  csr_stream_body<RG, Epi, C16, CH, GRP>(a, x, epi, int(blockIdx.x), prod, red, window);
+  csr_stream_body<RG, Epi, IDX, CH, GRP>(a, x, epi, int(blockIdx.x), prod, red, window);
 }
 
 // Two matrices with the same launch-plan parameters in ONE launch: workgroups [0, grid_a) stream the
 // row blocks of `a` with `ea`, the rest those of `b` with `eb` -- two SpMVs that do not depend on each
-// other (the fused BPCG iteration: t2 = A t1 and t3 = B (t1 - s0)) share a kernel boundary.
-template <int RG, class EpiA, class EpiB, bool C16, int CH, bool GRP = false>
+// other (the fused BPCG iteration: t2 = A t1 and t3 = B (t1 - s0)) share a kernel boundary.  The two halves
+// may use different column streams (IDXA / IDXB).
+template <int RG, class EpiA, class EpiB, int IDXA, int IDXB, int CH, bool GRP>
 __global__ __launch_bounds__(kBlock) void csr_stream_dual_kernel(CsrView a, CsrView b, int grid_a,
                                                                   const double* __restrict__ xa,
                                                                   const double* __restrict__ xb, EpiA ea, EpiB eb) {
@@ -346,12 +473,34 @@ __global__ __launch_bounds__(kBlock) void csr_stream_dual_kernel(CsrView a, CsrV
   __shared__ int32_t window[kWindows];
   if (int(blockIdx.x) < grid_a) {
     if (ea.skip()) return;
-    csr_stream_body<RG, EpiA, C16, CH, GRP>(a, xa, ea, int(blockIdx.x), prod, red, window);
+    csr_stream_body<RG, EpiA, IDXA, CH, (GRP && IDXA != 0)>(a, xa, ea, int(blockIdx.x), prod, red, window);
   } else {
     if (eb.skip()) return;
-    csr_stream_body<RG, EpiB, C16, CH, GRP>(b, xb, eb, int(blockIdx.x) - grid_a, prod, red, window);
+    csr_stream_body<RG, EpiB, IDXB, CH, (GRP && IDXB != 0)>(b, xb, eb, int(blockIdx.x) - grid_a, prod, red, window);
   }
 }
+
+// The launch plan only produces (chunk, lanes per row) = (kChunk, 1 | 2) and (kChunkLong, 2 ... 64): lanes per
+// row = the largest power of two with 2 * lanes * chunk / kBlock <= mean row length, and the chunk is kChunkLong
+// from 32 non-zeros per row on (plan_row_blocks).  Other combinations are not instantiated.
+#define NSS_FOR_PLAN(A, ONE)                                                                      \
+  if ((A).chunk == kChunk) {                                                                       \
+    switch ((A).rg) {                                                                              \
+      case 1: ONE(1, kChunk) break;                                                                \
+      case 2: ONE(2, kChunk) break;                                                                \
+      default: throw Error("csr_stream: bad lanes-per-row in the launch plan");                    \
+    }                                                                                              \
+  } else {                                                                                         \
+    switch ((A).rg) {                                                                              \
+      case 2: ONE(2, kChunkLong) break;                                                            \
+      case 4: ONE(4, kChunkLong) break;                                                            \
+      case 8: ONE(8, kChunkLong) break;                                                            \
+      case 16: ONE(16, kChunkLong) break;                                                          \
+      case 32: ONE(32, kChunkLong) break;                                                          \
+      case 64: ONE(64, kChunkLong) break;                                                          \
+      default: throw Error("csr_stream: bad lanes-per-row in the launch plan");                    \
+    }                                                                                              \
+  }
 
 // rows of the row blocks [b0, b1) (default: all)
 template <class Epi>
@@ -359,58 +508,65 @@ inline void launch_csr_stream(const nss_csr_s& A, const double* x, const Epi& ep
                               int b1 = -1) {
   if (b1 < 0) b1 = A.nblk;
   if (A.m == 0 || b1 <= b0) return;
-  const CsrView v = A.view(b0, b1);
+  constexpr bool kCanStage = EpiX<Epi>::type::kStageable;
+  const int mode = A.idx_mode(kCanStage);
+  const bool grp = mode != 0 && A.gb > 1;
+  const CsrView v = A.view(b0, b1, mode);
   const dim3 grid(nss_csr_s::grid(b1 - b0)), block(kBlock);
-#define NSS_LAUNCH_RG(N)                                                                                      \
-  case N:                                                                                                      \
-    if (A.chunk == kChunkLong) {                                                                               \
-      if (A.col16 && A.gb > 1) hipLaunchKernelGGL((csr_stream_kernel<N, Epi, true, kChunkLong, true>), grid, block, 0, st, v, x, epi);   \
-      else if (A.col16) hipLaunchKernelGGL((csr_stream_kernel<N, Epi, true, kChunkLong>), grid, block, 0, st, v, x, epi);   \
-      else hipLaunchKernelGGL((csr_stream_kernel<N, Epi, false, kChunkLong>), grid, block, 0, st, v, x, epi);          \
-    } else {                                                                                                   \
-      if (A.col16 && A.gb > 1) hipLaunchKernelGGL((csr_stream_kernel<N, Epi, true, kChunk, true>), grid, block, 0, st, v, x, epi);       \
-      else if (A.col16) hipLaunchKernelGGL((csr_stream_kernel<N, Epi, true>), grid, block, 0, st, v, x, epi);  \
-      else hipLaunchKernelGGL((csr_stream_kernel<N, Epi, false>), grid, block, 0, st, v, x, epi);              \
-    }                                                                                                          \
-    break;
-  switch (A.rg) {
-    NSS_LAUNCH_RG(1) NSS_LAUNCH_RG(2) NSS_LAUNCH_RG(4) NSS_LAUNCH_RG(8) NSS_LAUNCH_RG(16) NSS_LAUNCH_RG(32)
-    NSS_LAUNCH_RG(64)
-    default: throw Error("csr_stream: bad lanes-per-row in the launch plan");
+#define NSS_LAUNCH_ONE(N, CHK)                                                                                  \
+  if (mode == 2) {                                                                                               \
+    if constexpr (kCanStage) {                                                                                   \
+      if (grp) hipLaunchKernelGGL((csr_stream_kernel<N, Epi, 2, CHK, true>), grid, block, 0, st, v, x, epi);     \
+      else hipLaunchKernelGGL((csr_stream_kernel<N, Epi, 2, CHK, false>), grid, block, 0, st, v, x, epi);        \
+    }                                                                                                            \
+  } else if (mode == 1) {                                                                                        \
+    if (grp) hipLaunchKernelGGL((csr_stream_kernel<N, Epi, 1, CHK, true>), grid, block, 0, st, v, x, epi);       \
+    else hipLaunchKernelGGL((csr_stream_kernel<N, Epi, 1, CHK, false>), grid, block, 0, st, v, x, epi);          \
+  } else {                                                                                                       \
+    hipLaunchKernelGGL((csr_stream_kernel<N, Epi, 0, CHK, false>), grid, block, 0, st, v, x, epi);               \
   }
-#undef NSS_LAUNCH_RG
+  NSS_FOR_PLAN(A, NSS_LAUNCH_ONE)
+#undef NSS_LAUNCH_ONE
   NSS_CHECK_LAUNCH();
 }
 
-// A and B in one launch when their launch plans agree (lanes per row, chunk, index width); returns
-// false (nothing launched) otherwise -- the caller then issues two launches.
+// A and B in one launch when their launch plans agree (lanes per row, chunk) and the pair of column streams is
+// one of the instantiated ones; returns false (nothing launched) otherwise -- the caller then issues two launches.
 template <class EpiA, class EpiB>
 inline bool launch_csr_stream_dual(const nss_csr_s& A, const double* xa, const EpiA& ea, const nss_csr_s& B,
                                    const double* xb, const EpiB& eb, hipStream_t st) {
+#ifdef NSS_NO_DUAL        // measurements: the two halves as launches of their own
+  return false;
+#endif
   if (A.m == 0 || B.m == 0 || A.nblk == 0 || B.nblk == 0) return false;
-  if (A.rg != B.rg || A.chunk != B.chunk || (A.col16 != nullptr) != (B.col16 != nullptr)) return false;
-  const bool grp = A.gb > 1 || B.gb > 1;      // the grouped decode also reads a one-per-entry stream (gb == 1)
-  const CsrView va = A.view(0, A.nblk), vb = B.view(0, B.nblk);
+  if (A.rg != B.rg || A.chunk != B.chunk) return false;
+  constexpr bool kStageA = EpiX<EpiA>::type::kStageable, kStageB = EpiX<EpiB>::type::kStageable;
+  const int ma = A.idx_mode(kStageA), mb = B.idx_mode(kStageB);
+  if ((ma == 0) != (mb == 0)) return false;               // a 4-byte stream only pairs with a 4-byte stream
+  const bool grp = ma != 0 && (A.gb > 1 || B.gb > 1);     // the grouped decode also reads a one-per-entry stream (gb == 1)
+  const CsrView va = A.view(0, A.nblk, ma), vb = B.view(0, B.nblk, mb);
   const int ga = nss_csr_s::grid(A.nblk), gb = nss_csr_s::grid(B.nblk);
   const dim3 grid(ga + gb), block(kBlock);
-#define NSS_LAUNCH_DUAL(N)                                                                                             \
-  case N:                                                                                                              \
-    if (A.chunk == kChunkLong) {                                                                                       \
-      if (A.col16 && grp) hipLaunchKernelGGL((csr_stream_dual_kernel<N, EpiA, EpiB, true, kChunkLong, true>), grid, block, 0, st, va, vb, ga, xa, xb, ea, eb);  \
-      else if (A.col16) hipLaunchKernelGGL((csr_stream_dual_kernel<N, EpiA, EpiB, true, kChunkLong>), grid, block, 0, st, va, vb, ga, xa, xb, ea, eb);  \
-      else hipLaunchKernelGGL((csr_stream_dual_kernel<N, EpiA, EpiB, false, kChunkLong>), grid, block, 0, st, va, vb, ga, xa, xb, ea, eb);         \
-    } else {                                                                                                           \
-      if (A.col16 && grp) hipLaunchKernelGGL((csr_stream_dual_kernel<N, EpiA, EpiB, true, kChunk, true>), grid, block, 0, st, va, vb, ga, xa, xb, ea, eb);      \
-      else if (A.col16) hipLaunchKernelGGL((csr_stream_dual_kernel<N, EpiA, EpiB, true, kChunk>), grid, block, 0, st, va, vb, ga, xa, xb, ea, eb);      \
-      else hipLaunchKernelGGL((csr_stream_dual_kernel<N, EpiA, EpiB, false, kChunk>), grid, block, 0, st, va, vb, ga, xa, xb, ea, eb);             \
-    }                                                                                                                  \
-    break;
-  switch (A.rg) {
-    NSS_LAUNCH_DUAL(1) NSS_LAUNCH_DUAL(2) NSS_LAUNCH_DUAL(4) NSS_LAUNCH_DUAL(8) NSS_LAUNCH_DUAL(16) NSS_LAUNCH_DUAL(32)
-    NSS_LAUNCH_DUAL(64)
-    default: throw Error("csr_stream: bad lanes-per-row in the launch plan");
+#define NSS_DUAL_GO(N, CHK, IA, IB, G) \
+  hipLaunchKernelGGL((csr_stream_dual_kernel<N, EpiA, EpiB, IA, IB, CHK, G>), grid, block, 0, st, va, vb, ga, xa, xb, ea, eb)
+#define NSS_DUAL_PAIR(N, CHK, IA, IB) \
+  if (grp) NSS_DUAL_GO(N, CHK, IA, IB, true); else NSS_DUAL_GO(N, CHK, IA, IB, false);
+#define NSS_LAUNCH_DUAL_ONE(N, CHK)                                                        \
+  if (ma == 0) {                                                                            \
+    NSS_DUAL_GO(N, CHK, 0, 0, false);                                                       \
+  } else if (ma == 2 && mb == 2) {                                                          \
+    if constexpr (kStageA && kStageB) { NSS_DUAL_PAIR(N, CHK, 2, 2) }                       \
+  } else if (ma == 2) {                                                                     \
+    if constexpr (kStageA) { NSS_DUAL_PAIR(N, CHK, 2, 1) }                                  \
+  } else if (mb == 2) {                                                                     \
+    if constexpr (kStageB) { NSS_DUAL_PAIR(N, CHK, 1, 2) }                                  \
+  } else {                                                                                  \
+    NSS_DUAL_PAIR(N, CHK, 1, 1)                                                             \
   }
-#undef NSS_LAUNCH_DUAL
+  NSS_FOR_PLAN(A, NSS_LAUNCH_DUAL_ONE)
+#undef NSS_LAUNCH_DUAL_ONE
+#undef NSS_DUAL_PAIR
+#undef NSS_DUAL_GO
   NSS_CHECK_LAUNCH();
   return true;
 }

@@ -50,6 +50,9 @@ __device__ __forceinline__ bool minres_skip(const int32_t* ctrl, int k) {
 struct XScaledZ {
   const double* __restrict__ z;
   double scale;
+  static constexpr bool kStageable = true;
+  __device__ const double* ptr() const { return z; }
+  __device__ double value(double r) const { return r * scale; }
   __device__ double operator()(int c) const { return z[c] * scale; }
 };
 

@@ -114,6 +114,123 @@ __global__ __launch_bounds__(kBlock) void col_pack16_kernel(int32_t nblk, const 
   }
 }
 
+// ---- staged operand: segments of consecutive columns per row block ------------------------------------
+#ifndef NSS_STAGE_X
+#define NSS_STAGE_X 1
+#endif
+constexpr int kSegGap = 8;   // two columns at most this far apart belong to the same run (unused columns in between are copied too)
+
+// One workgroup per row block: sort the block's columns (bitonic, in LDS), cut the sorted list into runs where
+// two neighbours are more than kSegGap apart, write the descriptor (csr_stream.h: kSegWords) and, per entry,
+// the position of its column in the concatenation of the runs.  A block with more than kSegMax runs or more
+// than `chunk` staged columns counts into *nbad (the matrix is then not staged); a block that is one over-long
+// row keeps total = 0 (the kernel reduces it from the 4-byte columns).
+__global__ __launch_bounds__(kBlock) void seg_build_kernel(int32_t nblk, const int32_t* __restrict__ rowblk,
+                                                            const int32_t* __restrict__ rowptr,
+                                                            const int32_t* __restrict__ col, int32_t chunk,
+                                                            int32_t ncols, int32_t* __restrict__ desc,
+                                                            uint16_t* __restrict__ pos16, int32_t* __restrict__ nbad) {
+  __shared__ int32_t cols[kChunkLong];
+  __shared__ int32_t hidx[kSegMax];
+  __shared__ int32_t sstart[kSegMax], spre[kSegMax];
+  __shared__ int32_t hcount, ok;
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x;
+  if (b >= nblk) return;
+  const int r0 = rowblk[b], r1 = rowblk[b + 1];
+  const int p0 = rowptr[r0];
+  const int cnt = rowptr[r1] - p0;
+  int32_t* d = desc + size_t(b) * kSegWords;
+  if (tid < kSegWords) {
+    int32_t w = 0;
+    if (tid == 0) w = r0;
+    if (tid == 1) w = r1;
+    if (tid == 2) w = p0;
+    if (tid == 3) w = cnt;
+    if (tid >= kSegPre && tid < kSegPre + kSegMax - 1) w = INT_MAX;
+    d[tid] = w;
+  }
+  if (tid == 0) {
+    hcount = 0;
+    ok = 0;
+  }
+  if (cnt == 0 || cnt > chunk) return;
+  int npad = 2;
+  while (npad < cnt) npad <<= 1;
+  for (int i = tid; i < npad; i += kBlock) cols[i] = i < cnt ? col[p0 + i] : INT_MAX;
+  __syncthreads();
+  for (int k = 2; k <= npad; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < npad; i += kBlock) {
+        const int l = i ^ j;
+        if (l > i) {
+          const int32_t x = cols[i], y = cols[l];
+          if ((x > y) == ((i & k) == 0)) {
+            cols[i] = y;
+            cols[l] = x;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  for (int i = tid; i < cnt; i += kBlock)
+    if (i == 0 || cols[i] - cols[i - 1] > kSegGap) {
+      const int slot = atomicAdd(&hcount, 1);
+      if (slot < kSegMax) hidx[slot] = i;
+    }
+  __syncthreads();
+  const int nseg = hcount;
+  if (nseg > kSegMax) {
+    if (tid == 0) atomicAdd(nbad, 1);
+    return;
+  }
+  if (tid == 0) {
+    for (int i = 1; i < nseg; ++i) {                     // the heads in ascending order (<= kSegMax of them)
+      const int32_t h = hidx[i];
+      int j = i - 1;
+      while (j >= 0 && hidx[j] > h) {
+        hidx[j + 1] = hidx[j];
+        --j;
+      }
+      hidx[j + 1] = h;
+    }
+    int32_t acc = 0;
+    bool fits = true;
+    for (int s2 = 0; s2 < nseg; ++s2) {
+      int32_t first = cols[hidx[s2]];
+      int32_t last = cols[(s2 + 1 < nseg ? hidx[s2 + 1] : cnt) - 1];
+      // the kernel copies PAIRS of doubles (16-byte LDS-DMA pieces): even run lengths, hence even run starts in
+      // the copy; the extra column is a neighbour inside [0, ncols) (runs are more than kSegGap apart)
+      if ((last - first + 1) % 2 != 0) {
+        if (last + 1 < ncols) ++last;
+        else if (first > 0) --first;
+        else fits = false;
+      }
+      sstart[s2] = first;
+      spre[s2] = acc;
+      acc += last - first + 1;
+    }
+    if (fits && acc <= chunk) {
+      ok = 1;
+      d[4] = nseg;
+      d[5] = acc;
+      for (int s2 = 1; s2 < nseg; ++s2) d[kSegPre + s2 - 1] = spre[s2];
+      for (int s2 = 0; s2 < nseg; ++s2) d[kSegOff + s2] = sstart[s2] - spre[s2];
+    } else {
+      atomicAdd(nbad, 1);
+    }
+  }
+  __syncthreads();
+  if (!ok) return;
+  for (int i = tid; i < cnt; i += kBlock) {
+    const int32_t c = col[p0 + i];
+    int s2 = 0;
+    for (int t = 1; t < nseg; ++t)
+      if (c >= sstart[t]) s2 = t;
+    pos16[p0 + i] = uint16_t(c - sstart[s2] + spre[s2]);
+  }
+}
+
 // ---- grouped column stream ----------------------------------------------------------------------
 // bad[0] != 0 unless every row start is a multiple of gb and every entry that is not the first of its
 // aligned group of gb continues the column run of its predecessor
@@ -138,11 +255,32 @@ __global__ __launch_bounds__(kBlock) void col_group_pack_kernel(int64_t ngroups,
 #define NSS_COL_GROUPS 1
 #endif
 
+// one 16-bit index per group of gb entries: `*stream` is replaced by its packed form
+static void pack_groups(uint16_t** stream, int64_t nnz, int gb, hipStream_t st) {
+  if (!*stream) return;
+  const int64_t ngroups = nnz / gb;
+  uint16_t* packed = nullptr;
+  try {
+    NSS_HIP(hipMalloc(&packed, sizeof(uint16_t) * (size_t(ngroups) + 8)));
+    NSS_HIP(hipMemsetAsync(packed, 0, sizeof(uint16_t) * (size_t(ngroups) + 8), st));
+    hipLaunchKernelGGL(col_group_pack_kernel, dim3(stream_grid(ngroups, kBlock * 4)), dim3(kBlock), 0, st, ngroups, gb,
+                       *stream, packed);
+    NSS_CHECK_LAUNCH();
+    NSS_HIP(hipStreamSynchronize(st));
+  } catch (...) {
+    (void)hipFree(packed);
+    throw;
+  }
+  (void)hipFree(*stream);
+  *stream = packed;
+}
+
 // Largest gb in 16 .. 2 for which the matrix is made of aligned runs of gb consecutive columns: keep one
-// 16-bit index per run (see nss_csr_s::gb).  Every row block starts at a row start, hence at a multiple of gb.
+// 16-bit index per run in both 16-bit streams (see nss_csr_s::gb; consecutive columns have consecutive window
+// offsets and consecutive staged positions).  Every row block starts at a row start, hence at a multiple of gb.
 static void group_columns(nss_csr_s& A, hipStream_t st) {
 #if NSS_COL_GROUPS
-  if (!A.col16 || A.nnz < 16) return;
+  if ((!A.col16 && !A.pos16) || A.nnz < 16) return;
   // host-side pre-filter on the first rows (a few KB): candidates that already fail there -- every
   // candidate, for an operator without column runs -- never cost a pass over the matrix
   const int32_t probe_rows = std::min<int32_t>(A.m, 256);
@@ -159,7 +297,6 @@ static void group_columns(nss_csr_s& A, hipStream_t st) {
     return true;
   };
   int32_t* bad = nullptr;
-  uint16_t* packed = nullptr;
   try {
     NSS_HIP(hipMalloc(&bad, sizeof(int32_t)));
     for (int gb = 16; gb >= 2; --gb) {
@@ -172,22 +309,13 @@ static void group_columns(nss_csr_s& A, hipStream_t st) {
       NSS_HIP(hipMemcpyAsync(&h_bad, bad, sizeof(int32_t), hipMemcpyDeviceToHost, st));
       NSS_HIP(hipStreamSynchronize(st));
       if (h_bad != 0) continue;
-      const int64_t ngroups = A.nnz / gb;
-      NSS_HIP(hipMalloc(&packed, sizeof(uint16_t) * (size_t(ngroups) + 8)));
-      NSS_HIP(hipMemsetAsync(packed, 0, sizeof(uint16_t) * (size_t(ngroups) + 8), st));
-      hipLaunchKernelGGL(col_group_pack_kernel, dim3(stream_grid(ngroups, kBlock * 4)), dim3(kBlock), 0, st, ngroups, gb,
-                         A.col16, packed);
-      NSS_CHECK_LAUNCH();
-      NSS_HIP(hipStreamSynchronize(st));
-      (void)hipFree(A.col16);
-      A.col16 = packed;
-      packed = nullptr;
+      pack_groups(&A.col16, A.nnz, gb, st);
+      pack_groups(&A.pos16, A.nnz, gb, st);
       A.gb = gb;
       break;
     }
   } catch (...) {
     (void)hipFree(bad);
-    (void)hipFree(packed);
     throw;
   }
   (void)hipFree(bad);
@@ -197,9 +325,52 @@ static void group_columns(nss_csr_s& A, hipStream_t st) {
 #endif
 }
 
-void compress_columns(nss_csr_s& A, hipStream_t st) {
-#if NSS_COL16
-  if (A.nnz == 0 || A.nblk == 0) return;
+#ifndef NSS_STAGE_MIN_MEAN
+#define NSS_STAGE_MIN_MEAN 3     // rows shorter than this on average: the copy costs more than the gathers it saves
+#endif
+
+// Staged operand form: A.pos16 / A.blkseg when the matrix takes it.
+static void stage_columns(nss_csr_s& A, hipStream_t st) {
+#if NSS_STAGE_X
+  if (A.nnz < int64_t(NSS_STAGE_MIN_MEAN) * A.m) return;
+  int32_t* desc = nullptr;
+  int32_t* nbad = nullptr;
+  uint16_t* p16 = nullptr;
+  try {
+    NSS_HIP(hipMalloc(&desc, sizeof(int32_t) * size_t(A.nblk) * kSegWords));
+    NSS_HIP(hipMalloc(&nbad, sizeof(int32_t)));
+    NSS_HIP(hipMalloc(&p16, sizeof(uint16_t) * (size_t(A.nnz) + 8)));
+    NSS_HIP(hipMemsetAsync(nbad, 0, sizeof(int32_t), st));
+    NSS_HIP(hipMemsetAsync(p16, 0, sizeof(uint16_t) * (size_t(A.nnz) + 8), st));
+    hipLaunchKernelGGL(seg_build_kernel, dim3(A.nblk), dim3(kBlock), 0, st, A.nblk, A.rowblk, A.rowptr, A.col, A.chunk,
+                       A.n, desc, p16, nbad);
+    NSS_CHECK_LAUNCH();
+    int32_t h_bad = 0;
+    NSS_HIP(hipMemcpyAsync(&h_bad, nbad, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    NSS_HIP(hipStreamSynchronize(st));
+    if (h_bad == 0) {                 // every row block fits (the staged kernels have no per-block fallback)
+      A.pos16 = p16;
+      A.blkseg = desc;
+      p16 = nullptr;
+      desc = nullptr;
+    }
+  } catch (...) {
+    (void)hipFree(desc);
+    (void)hipFree(nbad);
+    (void)hipFree(p16);
+    throw;
+  }
+  (void)hipFree(desc);
+  (void)hipFree(nbad);
+  (void)hipFree(p16);
+#else
+  (void)A;
+  (void)st;
+#endif
+}
+
+// 16-bit window form: A.col16 / A.blkbase when every row block fits kWindows windows.
+static void window_columns(nss_csr_s& A, hipStream_t st) {
   int32_t* base = nullptr;
   int32_t* wide = nullptr;
   uint16_t* c16 = nullptr;
@@ -224,7 +395,6 @@ void compress_columns(nss_csr_s& A, hipStream_t st) {
       A.blkbase = base;
       c16 = nullptr;
       base = nullptr;
-      group_columns(A, st);
     }
   } catch (...) {
     (void)hipFree(base);
@@ -234,6 +404,17 @@ void compress_columns(nss_csr_s& A, hipStream_t st) {
   }
   (void)hipFree(base);
   (void)hipFree(wide);
+  (void)hipFree(c16);
+}
+
+// Both 16-bit forms the matrix admits (the kernels pick per launch: staged where the operand is one stored
+// vector, the window form otherwise), then one index per column run where the matrix is made of runs.
+void compress_columns(nss_csr_s& A, hipStream_t st) {
+#if NSS_COL16
+  if (A.nnz == 0 || A.nblk == 0) return;
+  stage_columns(A, st);
+  window_columns(A, st);
+  group_columns(A, st);
 #else
   (void)A;
   (void)st;
@@ -316,6 +497,8 @@ int nss_csr_destroy(nss_csr_t a) {
     (void)hipFree(a->rowblk);
     (void)hipFree(a->col16);
     (void)hipFree(a->blkbase);
+    (void)hipFree(a->blkseg);
+    (void)hipFree(a->pos16);
     delete a;
   });
 }
@@ -331,14 +514,21 @@ int nss_csr_spmv_f64(nss_csr_t a, double alpha, const double* x, double beta, do
 int nss_csr_index_width(nss_csr_t a, int32_t* bytes) {
   return guarded([&] {
     NSS_REQUIRE(a != nullptr && bytes != nullptr, "csr_index_width: NULL argument");
-    *bytes = a->col16 ? 2 : 4;
+    *bytes = (a->col16 || a->pos16) ? 2 : 4;
   });
 }
 
 int nss_csr_index_group(nss_csr_t a, int32_t* entries_per_index) {
   return guarded([&] {
     NSS_REQUIRE(a != nullptr && entries_per_index != nullptr, "csr_index_group: NULL argument");
-    *entries_per_index = a->col16 ? a->gb : 1;
+    *entries_per_index = (a->col16 || a->pos16) ? a->gb : 1;
+  });
+}
+
+int nss_csr_operand_form(nss_csr_t a, int32_t* form) {
+  return guarded([&] {
+    NSS_REQUIRE(a != nullptr && form != nullptr, "csr_operand_form: NULL argument");
+    *form = a->idx_mode();
   });
 }
 
@@ -352,11 +542,14 @@ int nss_csr_info(nss_csr_t a, int32_t* nrows, int32_t* ncols, int64_t* nnz, int3
     if (nblocks) *nblocks = a->nblk;
     if (lanes_per_row) *lanes_per_row = a->rg;
     // bytes one y = A x launch has to move: the value and the column stream THIS matrix is stored with
-    // (2-byte window-relative columns + 16 window bases per row block, or 4-byte columns), the row
+    // (2-byte staged positions + a 128-byte run table per row block, 2-byte window-relative columns + 16 window
+    // bases per row block, or 4-byte columns -- what the plain SpMV of this matrix streams), the row
     // pointers, x once and y once.  (The CSR fp64/int32 textbook figure is 12 nnz + ...; pricing a
     // launch that streams 10 bytes per entry at 12 would overstate its bandwidth.)
     if (algorithmic_bytes)
-      *algorithmic_bytes = (a->col16 ? 8 * a->nnz + 2 * (a->nnz / a->gb) + int64_t(4) * kWindows * a->nblk : 12 * a->nnz) +
+      *algorithmic_bytes = ((a->col16 || a->pos16) ? 8 * a->nnz + 2 * (a->nnz / a->gb) +
+                                                           int64_t(4) * (a->blkseg ? kSegWords : kWindows) * a->nblk
+                                                     : 12 * a->nnz) +
                            4 * (int64_t(a->m) + 1) + 8 * int64_t(a->n) + 8 * int64_t(a->m);
   });
 }

@@ -47,6 +47,7 @@ def _signatures():
         "nss_csr_download": (C.c_int, [vp, vp, vp, vp]),
         "nss_csr_index_width": (C.c_int, [vp, c_i32_p]),
         "nss_csr_index_group": (C.c_int, [vp, c_i32_p]),
+        "nss_csr_operand_form": (C.c_int, [vp, c_i32_p]),
         "nss_scratch_trim": (C.c_int, []),
         "nss_csr_ones_like": (C.c_int, [vp, C.POINTER(vp), vp]),
         "nss_graph_color": (C.c_int, [vp, vp, vp, vp, c_i32_p, vp]),
@@ -118,7 +119,10 @@ def load_library(path=None):
         lib = C.CDLL(path)
     except OSError as exc:
         raise EngineUnavailable("cannot load %s: %s" % (path, exc)) from exc
+    override = bool(os.environ.get("NSS_LIB_PATH"))
     for name, (res, args) in _signatures().items():
+        if override and not hasattr(lib, name):
+            continue                     # kernel A/B builds of an older source tree: entry points added since
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
@@ -148,7 +152,11 @@ class _CsrHandle:
         width, group = C.c_int32(), C.c_int32()
         self.engine._check(lib.nss_csr_index_width(self.ptr, width))
         self.engine._check(lib.nss_csr_index_group(self.ptr, group))
-        return {"rows": m.value, "cols": n.value, "nnz": nnz.value, "row_blocks": nb.value,
+        form = C.c_int32(width.value == 2)
+        if hasattr(lib, "nss_csr_operand_form"):                     # (absent in older A/B builds)
+            self.engine._check(lib.nss_csr_operand_form(self.ptr, form))
+        return {"operand_form": ("gather32", "gather16", "staged")[form.value],
+                "rows": m.value, "cols": n.value, "nnz": nnz.value, "row_blocks": nb.value,
                 "lanes_per_row": rg.value, "algorithmic_bytes": nbytes.value, "index_bytes": width.value,
                 "index_group": group.value}
 

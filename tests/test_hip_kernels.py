@@ -112,6 +112,50 @@ def test_spmv_stokes_blocks(hip_engine, dim, n):
     assert relerr(out.numpy(), s.B.T @ p) < RTOL
 
 
+def hipla_info(eng, mat):
+    return _spmv_check(eng, mat, seed=21).handle.info()
+
+
+def test_spmv_operand_forms(hip_engine):
+    """How the kernel reaches x (csrc/csr_stream.h): grid operators and their block-inflated forms take the staged
+    form (runs of consecutive columns copied to LDS ahead of the matrix stream); a staged matrix may hold a few row
+    blocks that do not fit and gather; a matrix without column runs keeps a gather form.  Every form against scipy."""
+    import scipy.sparse as sp
+    s = mac_stokes(3, 12)
+    info = hipla_info(hip_engine, s.B.T.tocsr())
+    assert info["operand_form"] == "gather16", info          # 2 non-zeros per row: the copy would cost more than it saves
+    for mat in (s.A, s.B, s.inflate(5).A, s.inflate(12).A, s.inflate(12).B):
+        M = _spmv_check(hip_engine, mat, seed=11)
+        info = M.handle.info()
+        assert info["operand_form"] == "staged" and info["index_bytes"] == 2, info
+        _spmv_check(hip_engine, mat, seed=12, alpha=-2.0, beta=0.5)
+    # a banded operator with ONE dense coupling row (a mean-value constraint): its row block scatters over ~1500
+    # runs, and a staged matrix has no per-block fallback -> the whole matrix gathers
+    n = 40000
+    band = sp.diags([1.0, -2.0, 1.0, 0.3, 0.3], [-1, 0, 1, -200, 200], shape=(n, n), format="lil")
+    assert hipla_info(hip_engine, band.tocsr())["operand_form"] == "staged"
+    rng = np.random.default_rng(4)
+    band[n // 2, rng.choice(n, 1500, replace=False)] = 1.0
+    assert hipla_info(hip_engine, band.tocsr())["operand_form"] in ("gather16", "gather32")
+    # columns without runs: every row block would need thousands of segments -> not staged
+    rnd = sp.random(20000, 20000, density=4e-4, random_state=5, format="csr")
+    M = _spmv_check(hip_engine, rnd, seed=14)
+    assert M.handle.info()["operand_form"] in ("gather16", "gather32")
+    # odd and even run lengths / starts, operand vectors that are only 8-byte aligned (sub-views of a buffer)
+    import hipla
+    import torch
+    odd = sp.diags([1.0, 2.0, 3.0, 4.0], [-301, 0, 2, 77], shape=(5001, 5001), format="csr")
+    M = hipla.SparseMatrix.from_scipy(odd)
+    assert M.handle.info()["operand_form"] == "staged"
+    buf = torch.arange(5001 + 3, dtype=torch.float64, device="cuda") * 0.25 + 1.0
+    out = torch.zeros(5001 + 3, dtype=torch.float64, device="cuda")
+    for shift in (0, 1, 2, 3):
+        x, y = buf[shift:shift + 5001], out[shift:shift + 5001]
+        hip_engine.csr_spmv(M.handle, 1.0, x, 0.0, y)
+        ref = odd @ x.cpu().numpy()
+        assert np.max(np.abs(y.cpu().numpy() - ref)) <= 1e-12 * np.max(np.abs(ref)), shift
+
+
 def _plan_lanes(mean):
     """The plan rule of csrc/spmv.hip: matrices with mean >= 32 non-zeros per row stage 4096 products
     per row block (16 per lane), the others 2048 (8 per lane); lanes per row = the largest power of
@@ -137,7 +181,9 @@ def test_spmv_row_length_regimes(hip_engine):
         if info["index_bytes"] == 2:                 # block-structured operator: one 16-bit index per run of columns
             expect = {1: 1, 3: 3, 6: 6, 9: 9, 12: 12, 22: 11, 44: 11, 90: 15}[bs]
             assert info["index_group"] == expect, (bs, info)
-            assert info["algorithmic_bytes"] == (8 * infl.A.nnz + 2 * (infl.A.nnz // expect) + 64 * info["row_blocks"]
+            per_block = 128 if info["operand_form"] == "staged" else 64    # segment descriptor / window bases
+            assert info["algorithmic_bytes"] == (8 * infl.A.nnz + 2 * (infl.A.nnz // expect)
+                                                 + per_block * info["row_blocks"]
                                                  + 4 * (infl.A.shape[0] + 1) + 16 * infl.A.shape[0])
         seen.add((mean >= 32, _plan_lanes(mean)))
         if bs <= 12:
