@@ -489,9 +489,13 @@ NSS_API int nss_minres_fuse_mode(int32_t mode);
  * C = None, pre_a Jacobi / block-Jacobi / AMG / AMG + Jacobi, pre_schur diagonal.  Block vectors per component
  * ([0] velocity n_u, [1] pressure n_p): x = solution, r = residuum, d =
  * full_preconditioned_residuum, a = a_preconditioned_residuum, t1 / t2 = temp_1 / temp_2.
- * scal: double[8] = { rho, <d,t1>, rho_new, alpha, beta, err0, tolerance, - };
+ * scal: double[16] = { rho, <d,t1>, rho_new, alpha, beta, err0, tolerance, -, local <d,t1>, local rho_new, .. };
  * ctrl: int32[4] = { stop, it_stop, last_it, - };  hist[it] = err_it / err_0 (:118), written
- * before the stop test of iteration `it` (:119). */
+ * before the stop test of iteration `it` (:119).
+ * local_sums != 0: row-partitioned run (this rank's slab of the rows; the SpMV operands d[0], t2[0], a[0]
+ * are buffers [owned | ghosts] in the layout of A's operand -- B's local columns are numbered in it too --
+ * and d[1] in the layout of B^T's operand): the sum kernels leave their LOCAL totals in scal[8] / scal[9] and
+ * the caller all-reduces them into scal[1] / scal[2] before the phase that consumes them. */
 typedef struct nss_bpcg1_s {
   nss_csr_t A, B, BT;
   const double* pre_diag;
@@ -505,6 +509,7 @@ typedef struct nss_bpcg1_s {
   double *partials_a, *partials_b, *partials_c;
   double k;
   int32_t n_u, n_p;
+  int32_t local_sums;
 } nss_bpcg1_t;
 
 NSS_API int nss_bpcg1_workspace(const nss_bpcg1_t* s, int64_t* partials_a, int64_t* partials_b,
@@ -512,6 +517,20 @@ NSS_API int nss_bpcg1_workspace(const nss_bpcg1_t* s, int64_t* partials_a, int64
 NSS_API int nss_bpcg1_iterate(const nss_bpcg1_t* s, int32_t it_begin, int32_t it_end, nss_stream_t stream);
 NSS_API int nss_bpcg1_poll(const nss_bpcg1_t* s, int32_t* stop, int32_t* it_stop, int32_t* last_it,
                            nss_stream_t stream);
+/* The device phases first .. last of iteration `it` (row-partitioned schedules with a host-side
+ * communicator exchange / all-reduce between them):
+ *   1  loop top (:115-119); t1 = -K d, t2 = A~ t1 (:125-126)     -- needs the ghosts of d[0], d[1]
+ *   2  t1 += [A; B] t2u (:127), local <d, t1>                    -- needs the ghosts of t2[0]
+ *   3  alpha (:129) from scal[1]; x, r, a updates (:131-133), local <a_u, r_u>
+ *   4  t1p = minv (B a_u - a_p) (:135), local <t1p, r_p>         -- needs the ghosts of a[0]
+ *   5  rho_new, beta (:137-138) from scal[2]; d = beta d + ... (:140-141) */
+NSS_API int nss_bpcg1_phases(const nss_bpcg1_t* s, int32_t first, int32_t last, int32_t it, nss_stream_t stream);
+/* iterations [it_begin, it_end) of the row-partitioned loop with RCCL issued natively: per iteration the
+ * grouped exchange of d[0] and d[1], the exchanges of t2[0] and a[0], and two all-reduces of one double.
+ * halo_u describes the velocity operands (its `ext` is replaced by d[0] / t2[0] / a[0]), halo_p the operand of
+ * B^T (d[1]).  bramble_pasciak_cg.py:110-143; the reference is single-process. */
+NSS_API int nss_bpcg1_iterate_dist(const nss_bpcg1_t* s, nss_dist_t d, const nss_halo_t* halo_u,
+                                   const nss_halo_t* halo_p, int32_t it_begin, int32_t it_end, nss_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -125,6 +125,10 @@ def bramble_pasciak_cg(a_matrix, b_matrix, c_matrix, pre_a, pre_schur_complement
 
     fused_loop = Bpcg1Loop.try_create(a_matrix, b_matrix, c_matrix, pre_a, pre_schur_complement, k,
                                       dict(x=solution, r=r, d=d, a=ar, t1=t1, t2=t2))
+    if fused_loop is None and hasattr(a_matrix, "plan"):      # row-partitioned operands (distributed.py)
+        from distributed import Bpcg1DistLoop
+        fused_loop = Bpcg1DistLoop.try_create(a_matrix, b_matrix, c_matrix, pre_a, pre_schur_complement, k,
+                                              dict(x=solution, r=r, d=d, a=ar, t1=t1, t2=t2))
     if fused_loop is not None:
         errors, converged = fused_loop.run(rho, err0, tolerance, max_steps)
         if print_rates:

@@ -14,13 +14,15 @@
 //   V5   rows of B   : t1p = minv (B a_res_u - a_res_p), partial <t1p, r_p>           (:135,137)
 //   R2   rho_new, beta = rho_new / rho                                                (:137-138)
 //   V6   element-wise: du = b du + a_res_u, dp = b dp + t1p                           (:140-141)
-#include "bpcg2.h"
+#include "dist.h"
 
 #include <algorithm>
 
 namespace nss {
 
-enum { P_RHO = 0, P_DSUM = 1, P_RHON = 2, P_ALPHA = 3, P_BETA = 4, P_ERR0 = 5, P_TOL = 6 };
+enum { P_RHO = 0, P_DSUM = 1, P_RHON = 2, P_ALPHA = 3, P_BETA = 4, P_ERR0 = 5, P_TOL = 6,
+       // row-partitioned runs: local totals; the all-reduce writes P_DSUM / P_RHON out of place (frozen after the stop)
+       P_DSUM_LOC = 8, P_RHON_LOC = 9 };
 enum { PC_STOP = 0, PC_ITSTOP = 1, PC_LAST = 2 };
 
 struct EpiStore1 {
@@ -103,14 +105,28 @@ struct EpiV5 {
 };
 
 constexpr int kPSum = 1024;
-// which = 0: loop-top bookkeeping; 1: alpha from sum(pa)+sum(pb); 2: rho_new, beta
+// which = 0: loop-top bookkeeping; 1: alpha from sum(pa)+sum(pb); 2: rho_new, beta;
+// row-partitioned (local != 0): 1 / 2 only store the local total, 3 / 4 derive alpha / rho_new, beta from the
+// all-reduced totals (one lane)
 __global__ __launch_bounds__(kPSum) void bpcg1_scalar_kernel(int32_t* __restrict__ ctrl, double* __restrict__ s,
                                                               double* __restrict__ hist, int which, int it, int na,
                                                               const double* __restrict__ pa, int nb,
-                                                              const double* __restrict__ pb) {
+                                                              const double* __restrict__ pb, int local) {
   __shared__ double lds[2 * kPSum / kWave];
   if (ctrl[PC_STOP] != 0) return;
   const int tid = threadIdx.x;
+  if (which == 3 || which == 4) {
+    if (tid == 0) {
+      if (which == 3) {
+        s[P_ALPHA] = s[P_RHO] / s[P_DSUM];
+      } else {
+        const double total = s[P_RHON];
+        s[P_BETA] = total / s[P_RHO];
+        s[P_RHO] = total;
+      }
+    }
+    return;
+  }
   if (which == 0) {
     if (tid == 0) {
       const double err = sqrt(fabs(s[P_RHO]));
@@ -140,7 +156,9 @@ __global__ __launch_bounds__(kPSum) void bpcg1_scalar_kernel(int32_t* __restrict
       tb += lds[kPSum / kWave + w];
     }
     const double total = ta + tb;
-    if (which == 1) {
+    if (local) {
+      s[which == 1 ? P_DSUM_LOC : P_RHON_LOC] = total;
+    } else if (which == 1) {
       s[P_DSUM] = total;
       s[P_ALPHA] = s[P_RHO] / total;
     } else {
@@ -201,7 +219,11 @@ static void bpcg1_check(const nss_bpcg1_t* s) {
   NSS_REQUIRE(s != nullptr, "bpcg1: NULL state");
   NSS_REQUIRE(s->A && s->B && s->BT, "bpcg1: NULL matrix handle");
   NSS_REQUIRE(s->A->m == s->n_u && s->BT->m == s->n_u && s->B->m == s->n_p, "bpcg1: matrix rows do not match n_u/n_p");
-  NSS_REQUIRE(s->A->n == s->n_u && s->B->n == s->n_u && s->BT->n == s->n_p, "bpcg1: matrix columns do not match");
+  if (s->local_sums)      // row-partitioned: the operands carry ghost entries behind the owned ones
+    NSS_REQUIRE(s->A->n >= s->n_u && s->B->n == s->A->n && s->BT->n >= s->n_p, "bpcg1: local matrix columns do not match the slab");
+  else
+    NSS_REQUIRE(s->A->n == s->n_u && s->B->n == s->n_u && s->BT->n == s->n_p, "bpcg1: matrix columns do not match");
+  NSS_REQUIRE(!(s->local_sums && s->pre_amg), "bpcg1: the row-partitioned loop takes a (block) Jacobi preconditioner");
   NSS_REQUIRE(!(s->pre_diag && s->pre_bjac), "bpcg1: pre_diag and pre_bjac are exclusive");
   NSS_REQUIRE(s->pre_diag || s->pre_bjac || s->pre_amg, "bpcg1: no preconditioner for the velocity block");
   NSS_REQUIRE(!s->pre_amg || s->pre_amg->levels[0].n == s->n_u, "bpcg1: AMG size mismatch");
@@ -213,48 +235,83 @@ static void bpcg1_check(const nss_bpcg1_t* s) {
     NSS_REQUIRE(s->x[c] && s->r[c] && s->d[c] && s->a[c] && s->t1[c] && s->t2[c], "bpcg1: NULL vector");
 }
 
-static void bpcg1_iteration(const nss_bpcg1_t& s, int it, hipStream_t st) {
-  hipLaunchKernelGGL(bpcg1_scalar_kernel, dim3(1), dim3(kWave), 0, st, s.ctrl, s.scal, s.hist, 0, it, 0,
-                     s.partials_a, 0, s.partials_b);
+struct Bpcg1Dist {
+  const nss_dist_s* d;
+  const nss_halo_t* hu;      // velocity operands (d[0], t2[0], a[0]): layout of A's operand
+  const nss_halo_t* hp;      // d[1]: layout of B^T's operand
+};
+
+static void scalar_step(const nss_bpcg1_t& s, int which, int it, int lanes, int na, const double* pa, int nb,
+                        const double* pb, hipStream_t st) {
+  hipLaunchKernelGGL(bpcg1_scalar_kernel, dim3(1), dim3(lanes), 0, st, s.ctrl, s.scal, s.hist, which, it, na, pa, nb, pb,
+                     int(s.local_sums));
   NSS_CHECK_LAUNCH();
-  // V1a and V1c multiply the same operand (du) and do not depend on each other: one launch
-  const EpiStore1 e1a{s.ctrl, s.t1[0]};
-  const EpiV1c e1c{s.ctrl, s.t1[1], s.t2[1]};
-  if (!launch_csr_stream_dual(*s.A, s.d[0], e1a, *s.B, s.d[0], e1c, st)) {
-    launch_csr_stream(*s.A, s.d[0], e1a, st);
-    launch_csr_stream(*s.B, s.d[0], e1c, st);
-  }
-  launch_csr_stream(*s.BT, s.d[1], EpiV1b{s.ctrl, s.t1[0], s.t2[0], s.pre_amg ? nullptr : s.pre_diag, s.k}, st);
-  if (s.pre_amg) {                                         // t2 = -k (AMG + J) t1 (t1 holds -K u here)
-    amg_apply(*s.pre_amg, -s.k, s.t1[0], s.t2[0], st);
-    if (s.pre_bjac) bjac_apply(*s.pre_bjac, -s.k, s.t1[0], 1.0, s.t2[0], s.ctrl, st);
-    if (s.pre_diag) {
-      const int rc = nss_diag_apply_f64(s.n_u, s.pre_diag, -s.k, s.t1[0], 1.0, s.t2[0], st);
-      if (rc != 0) throw Error(nss_last_error());
+}
+
+// phases first .. last of one iteration (nss_bpcg1_phases); `dist`: exchanges and all-reduces issued from here
+static void bpcg1_iteration(const nss_bpcg1_t& s, int it, hipStream_t st, int first = 1, int last = 5,
+                            const Bpcg1Dist* dist = nullptr) {
+  auto on = [&](int ph) { return first <= ph && ph <= last; };
+  auto halo_of = [&](const nss_halo_t* h, double* ext) {
+    nss_halo_t c = *h;
+    c.ext = ext;
+    return c;
+  };
+  if (on(1)) {
+    scalar_step(s, 0, it, kWave, 0, s.partials_a, 0, s.partials_b, st);
+    if (dist) {
+      const nss_halo_t h0 = halo_of(dist->hu, s.d[0]), h1 = halo_of(dist->hp, s.d[1]);
+      exchange(*dist->d, h0, st, &h1);
     }
-  } else if (s.pre_bjac) {
-    bjac_apply(*s.pre_bjac, -s.k, s.t1[0], 0.0, s.t2[0], s.ctrl, st);
+    // V1a and V1c multiply the same operand (du) and do not depend on each other: one launch
+    const EpiStore1 e1a{s.ctrl, s.t1[0]};
+    const EpiV1c e1c{s.ctrl, s.t1[1], s.t2[1]};
+    if (!launch_csr_stream_dual(*s.A, s.d[0], e1a, *s.B, s.d[0], e1c, st)) {
+      launch_csr_stream(*s.A, s.d[0], e1a, st);
+      launch_csr_stream(*s.B, s.d[0], e1c, st);
+    }
+    launch_csr_stream(*s.BT, s.d[1], EpiV1b{s.ctrl, s.t1[0], s.t2[0], s.pre_amg ? nullptr : s.pre_diag, s.k}, st);
+    if (s.pre_amg) {                                         // t2 = -k (AMG + J) t1 (t1 holds -K u here)
+      amg_apply(*s.pre_amg, -s.k, s.t1[0], s.t2[0], st);
+      if (s.pre_bjac) bjac_apply(*s.pre_bjac, -s.k, s.t1[0], 1.0, s.t2[0], s.ctrl, st);
+      if (s.pre_diag) {
+        const int rc = nss_diag_apply_f64(s.n_u, s.pre_diag, -s.k, s.t1[0], 1.0, s.t2[0], st);
+        if (rc != 0) throw Error(nss_last_error());
+      }
+    } else if (s.pre_bjac) {
+      bjac_apply(*s.pre_bjac, -s.k, s.t1[0], 0.0, s.t2[0], s.ctrl, st);
+    }
   }
-  // V3a and V3b (operand t2u) likewise
-  const EpiV3 e3a{s.ctrl, s.t1[0], s.d[0], s.partials_a}, e3b{s.ctrl, s.t1[1], s.d[1], s.partials_b};
-  if (!launch_csr_stream_dual(*s.A, s.t2[0], e3a, *s.B, s.t2[0], e3b, st)) {
-    launch_csr_stream(*s.A, s.t2[0], e3a, st);
-    launch_csr_stream(*s.B, s.t2[0], e3b, st);
+  if (on(2)) {
+    if (dist) exchange(*dist->d, halo_of(dist->hu, s.t2[0]), st);
+    // V3a and V3b (operand t2u) likewise
+    const EpiV3 e3a{s.ctrl, s.t1[0], s.d[0], s.partials_a}, e3b{s.ctrl, s.t1[1], s.d[1], s.partials_b};
+    if (!launch_csr_stream_dual(*s.A, s.t2[0], e3a, *s.B, s.t2[0], e3b, st)) {
+      launch_csr_stream(*s.A, s.t2[0], e3a, st);
+      launch_csr_stream(*s.B, s.t2[0], e3b, st);
+    }
+    scalar_step(s, 1, it, kPSum, s.A->nblk, s.partials_a, s.B->nblk, s.partials_b, st);
+    if (dist) allreduce_sum(*dist->d, s.scal + P_DSUM_LOC, s.scal + P_DSUM, 1, st);
   }
-  hipLaunchKernelGGL(bpcg1_scalar_kernel, dim3(1), dim3(kPSum), 0, st, s.ctrl, s.scal, s.hist, 1, it, s.A->nblk,
-                     s.partials_a, s.B->nblk, s.partials_b);
-  NSS_CHECK_LAUNCH();
-  V4Args a4{s.ctrl, s.scal, s.n_u, s.n_p, s.x[0], s.x[1], s.r[0], s.r[1], s.a[0], s.a[1],
-            s.d[0], s.d[1], s.t1[0], s.t1[1], s.t2[0], s.t2[1], s.partials_c};
-  hipLaunchKernelGGL(bpcg1_v4_kernel, dim3(p_grid(s)), dim3(kBlock), 0, st, a4);
-  NSS_CHECK_LAUNCH();
-  launch_csr_stream(*s.B, s.a[0], EpiV5{s.ctrl, s.a[1], s.minv, s.r[1], s.t1[1], s.partials_b}, st);
-  hipLaunchKernelGGL(bpcg1_scalar_kernel, dim3(1), dim3(kPSum), 0, st, s.ctrl, s.scal, s.hist, 2, it, p_grid(s),
-                     s.partials_c, s.B->nblk, s.partials_b);
-  NSS_CHECK_LAUNCH();
-  hipLaunchKernelGGL(bpcg1_v6_kernel, dim3(p_grid(s)), dim3(kBlock), 0, st, s.ctrl, s.scal, s.n_u, s.n_p, s.d[0],
-                     s.d[1], s.a[0], s.t1[1]);
-  NSS_CHECK_LAUNCH();
+  if (on(3)) {
+    if (s.local_sums) scalar_step(s, 3, it, kWave, 0, s.partials_a, 0, s.partials_b, st);
+    V4Args a4{s.ctrl, s.scal, s.n_u, s.n_p, s.x[0], s.x[1], s.r[0], s.r[1], s.a[0], s.a[1],
+              s.d[0], s.d[1], s.t1[0], s.t1[1], s.t2[0], s.t2[1], s.partials_c};
+    hipLaunchKernelGGL(bpcg1_v4_kernel, dim3(p_grid(s)), dim3(kBlock), 0, st, a4);
+    NSS_CHECK_LAUNCH();
+  }
+  if (on(4)) {
+    if (dist) exchange(*dist->d, halo_of(dist->hu, s.a[0]), st);
+    launch_csr_stream(*s.B, s.a[0], EpiV5{s.ctrl, s.a[1], s.minv, s.r[1], s.t1[1], s.partials_b}, st);
+    scalar_step(s, 2, it, kPSum, p_grid(s), s.partials_c, s.B->nblk, s.partials_b, st);
+    if (dist) allreduce_sum(*dist->d, s.scal + P_RHON_LOC, s.scal + P_RHON, 1, st);
+  }
+  if (on(5)) {
+    if (s.local_sums) scalar_step(s, 4, it, kWave, 0, s.partials_a, 0, s.partials_b, st);
+    hipLaunchKernelGGL(bpcg1_v6_kernel, dim3(p_grid(s)), dim3(kBlock), 0, st, s.ctrl, s.scal, s.n_u, s.n_p, s.d[0],
+                       s.d[1], s.a[0], s.t1[1]);
+    NSS_CHECK_LAUNCH();
+  }
 }
 
 }  // namespace nss
@@ -276,6 +333,31 @@ int nss_bpcg1_iterate(const nss_bpcg1_t* s, int32_t it_begin, int32_t it_end, ns
   return guarded([&] {
     bpcg1_check(s);
     for (int it = it_begin; it < it_end; ++it) bpcg1_iteration(*s, it, as_stream(stream));
+  });
+}
+
+int nss_bpcg1_phases(const nss_bpcg1_t* s, int32_t first, int32_t last, int32_t it, nss_stream_t stream) {
+  return guarded([&] {
+    bpcg1_check(s);
+    NSS_REQUIRE(1 <= first && first <= last && last <= 5, "bpcg1_phases: phases are 1 .. 5");
+    bpcg1_iteration(*s, it, as_stream(stream), first, last);
+  });
+}
+
+int nss_bpcg1_iterate_dist(const nss_bpcg1_t* s, nss_dist_t d, const nss_halo_t* halo_u, const nss_halo_t* halo_p,
+                           int32_t it_begin, int32_t it_end, nss_stream_t stream) {
+  return guarded([&] {
+    bpcg1_check(s);
+    NSS_REQUIRE(d != nullptr && s->local_sums, "bpcg1_iterate_dist: needs a dist handle and a row-partitioned state");
+    NSS_REQUIRE(halo_u && halo_p, "bpcg1_iterate_dist: NULL halo");
+    NSS_REQUIRE(d->nranks == 1 || d->comm != nullptr, "bpcg1_iterate_dist: multi-rank run without a communicator");
+    nss_halo_t h0 = *halo_u, h1 = *halo_p;
+    h0.ext = s->d[0];
+    h1.ext = s->d[1];
+    check_halo(&h0, *s->A, "halo_u");
+    check_halo(&h1, *s->BT, "halo_p");
+    Bpcg1Dist bd{d, halo_u, halo_p};
+    for (int it = it_begin; it < it_end; ++it) bpcg1_iteration(*s, it, as_stream(stream), 1, 5, &bd);
   });
 }
 

@@ -817,6 +817,113 @@ class DistributedBpcg2:
         return (it_final if done else maxsteps - 1), done
 
 
+def b_in_layout_of_a(A, B, engine):
+    """B's slab with its ghost columns numbered in the layout of A's operand (A's ghosts contain B's): the SpMVs
+    with A and with B then multiply the SAME halo-extended buffer."""
+    n_u, n_p = A.n_cols_owned, B.n_rows
+    gb, ga = B.plan.ghosts, A.plan.ghosts
+    pos = np.searchsorted(ga, gb)
+    if gb.size and (pos.max(initial=0) >= ga.size or not np.array_equal(ga[np.minimum(pos, ga.size - 1)], gb)):
+        raise RuntimeError("ghost columns of B are not among those of A's operand")
+    loc = B.local_scipy
+    cols = loc.indices.astype(np.int64)
+    ghost = cols >= n_u
+    cols[ghost] = n_u + pos[cols[ghost] - n_u]
+    b_on_a = sp.csr_matrix((loc.data, cols.astype(np.int32), loc.indptr), shape=(n_p, n_u + ga.size))
+    b_on_a.sort_indices()
+    return SparseMatrix.from_scipy(b_on_a, engine=engine)
+
+
+class Bpcg1DistLoop:
+    """Row-partitioned device loop of the textbook Bramble-Pasciak CG (bramble_pasciak_cg.py:110-143) behind
+    `bramble_pasciak_cg(...)` called with distributed operands: the fused kernels of `nss_bpcg1_*` on this rank's
+    slab; per iteration the exchange of d (both components in one grouped phase), of t2_u and of a_u, and two
+    all-reduces of one double -- issued natively from C over RCCL (`nss_bpcg1_iterate_dist`) or, with any other
+    communicator, between the device phases (`nss_bpcg1_phases`).  The scalars are identical on every rank, so
+    every rank takes the same stop decision."""
+
+    NATIVE = True        # False: keep the host-driven schedule even over an RCCL communicator (tests)
+
+    @classmethod
+    def try_create(cls, a_matrix, b_matrix, c_matrix, pre_a, pre_s, k, vecs, native=None):
+        from hipla import fused
+        native = cls.NATIVE if native is None else native
+        if c_matrix is not None or not (isinstance(a_matrix, DistSparseMatrix) and isinstance(b_matrix, DistSparseMatrix)):
+            return None
+        eng = a_matrix.engine
+        if not fused.ENABLED or not hasattr(getattr(eng, "lib", None), "nss_bpcg1_phases"):
+            return None
+        bt = b_matrix.T
+        if not isinstance(bt, DistSparseMatrix):
+            return None
+        pa_d, pa_b, ps = fused.native_diag(pre_a), fused.native_bjac(pre_a), fused.native_diag(pre_s)
+        if ps is None or (pa_d is None and pa_b is None):
+            return None
+        return cls(eng, a_matrix, b_matrix, bt, pa_d, pa_b, ps, k, vecs, native)
+
+    def __init__(self, eng, A, B, BT, pa_d, pa_b, ps, k, vecs, native):
+        import ctypes as C
+        from hipla.fused import Bpcg1Loop
+        self.engine, self.comm, self.A, self.BT = eng, A.comm, A, BT
+        self.B_onA = b_in_layout_of_a(A, B, eng)
+        # the SpMV operands of the loop in halo-extended buffers (d_u, t2_u, a_u: layout of A's operand; d_p: B^T's)
+        self.d0, self.t20, self.a0, self.d1 = A.operand(), A.operand(), A.operand(), BT.operand()
+        self.d0.data = vecs["d"][0]
+        self.d1.data = vecs["d"][1]
+        self.a0.data = vecs["a"][0]
+        local = dict(vecs)
+        local["d"], local["a"], local["t2"] = [self.d0, self.d1], [self.a0, vecs["a"][1]], [self.t20, vecs["t2"][1]]
+        self.loop = Bpcg1Loop(eng, A.local, self.B_onA, pa_d, pa_b, ps, k, local, BT=BT.local)
+        self.loop.state.local_sums = 1
+        self.loop.enqueue = self.enqueue
+        self.native = None
+        comm_handle = getattr(self.comm, "comm", None)        # RcclComm: an ncclComm_t
+        if native and comm_handle is not None and hasattr(eng.lib, "nss_bpcg1_iterate_dist"):
+            handle = C.c_void_p()
+            eng._check(eng.lib.nss_dist_create(comm_handle, self.comm.size, self.comm.rank, C.byref(handle)))
+            self.native = (handle, (A.native_halo(self.d0), BT.native_halo(self.d1)))
+
+    def close(self):
+        if getattr(self, "native", None) is not None:
+            self.engine.lib.nss_dist_destroy(self.native[0])
+            self.native = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def enqueue(self, it_begin, it_end):
+        import ctypes as C
+        eng, loop, st = self.engine, self.loop, self.loop.state
+        if self.native is not None:
+            handle, (hu, hp) = self.native
+            eng._check(eng.lib.nss_bpcg1_iterate_dist(C.byref(st), handle, C.byref(hu), C.byref(hp), int(it_begin),
+                                                      int(it_end), eng.stream))
+            return
+        A, BT, comm, scal = self.A, self.BT, self.comm, loop.scal
+
+        def phases(first, last, it):
+            eng._check(eng.lib.nss_bpcg1_phases(C.byref(st), first, last, it, eng.stream))
+
+        for it in range(it_begin, it_end):
+            A.exchange(self.d0)
+            BT.exchange(self.d1)
+            phases(1, 1, it)
+            A.exchange(self.t20)
+            phases(2, 2, it)
+            comm.allreduce_sum_into(scal[8:9], scal[1:2])            # <d, t1>
+            phases(3, 3, it)
+            A.exchange(self.a0)
+            phases(4, 4, it)
+            comm.allreduce_sum_into(scal[9:10], scal[2:3])           # rho_new
+            phases(5, 5, it)
+
+    def run(self, rho, err0, tolerance, max_steps, poll_every=None):
+        return self.loop.run(rho, err0, tolerance, max_steps, poll_every)
+
+
 class DistributedMinres:
     """Row-partitioned preconditioned MINRES (minres.py:12-149) on this rank, K = [[A, B^T], [B, 0]],
     C = diag(preA, preM): set-up through the operator protocol with distributed operands, iteration
@@ -836,18 +943,7 @@ class DistributedMinres:
         self.comm = comm if comm is not None else TorchComm(dist, eng)
         ops = self.ops = DistributedStokes(sysm, blocks, self.comm, eng)
         n_u, n_p = ops.n_u, ops.n_p
-        # B's slab with its ghost columns numbered in the layout of A's operand (A's ghosts contain B's)
-        gb, ga = ops.B.plan.ghosts, ops.A.plan.ghosts
-        pos = np.searchsorted(ga, gb)
-        if gb.size and (pos.max(initial=0) >= ga.size or not np.array_equal(ga[np.minimum(pos, ga.size - 1)], gb)):
-            raise RuntimeError("ghost columns of B are not among those of A's operand")
-        loc = ops.B.local_scipy
-        cols = loc.indices.astype(np.int64)
-        ghost = cols >= n_u
-        cols[ghost] = n_u + pos[cols[ghost] - n_u]
-        b_on_a = sp.csr_matrix((loc.data, cols.astype(np.int32), loc.indptr), shape=(n_p, n_u + ga.size))
-        b_on_a.sort_indices()
-        self.B_onA = SparseMatrix.from_scipy(b_on_a, engine=eng)
+        self.B_onA = b_in_layout_of_a(ops.A, ops.B, eng)
 
         us, ps = ops.local_slices()
         fv, gv = ops.vectors(f, g)

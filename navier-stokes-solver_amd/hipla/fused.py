@@ -420,7 +420,7 @@ class Bpcg1State(C.Structure):
                 + [(n, C.c_void_p * 2) for n in ("x", "r", "d", "a", "t1", "t2")]
                 + [("scal", C.c_void_p), ("ctrl", C.c_void_p), ("hist", C.c_void_p),
                    ("partials_a", C.c_void_p), ("partials_b", C.c_void_p), ("partials_c", C.c_void_p),
-                   ("k", C.c_double), ("n_u", C.c_int32), ("n_p", C.c_int32)])
+                   ("k", C.c_double), ("n_u", C.c_int32), ("n_p", C.c_int32), ("local_sums", C.c_int32)])
 
 
 class Bpcg1Loop:
@@ -446,10 +446,13 @@ class Bpcg1Loop:
             return None
         return cls(eng, a_matrix, b_matrix, pa_d, pa_b, ps, k, vecs, pa_amg)
 
-    def __init__(self, eng, A, B, pa_d, pa_b, ps, k, vecs, pa_amg=None):
+    def __init__(self, eng, A, B, pa_d, pa_b, ps, k, vecs, pa_amg=None, BT=None):
+        """`BT`: the rows of B^T this process owns, when they are not the transpose of its B (row-partitioned
+        runs: distributed.Bpcg1DistLoop)."""
         torch = eng.torch
         self.eng, self.lib = eng, eng.lib
-        BT = B.CreateTranspose()
+        if BT is None:
+            BT = B.CreateTranspose()
         self.keep = [A, B, BT, pa_d, pa_b, ps, vecs, pa_amg]
         st = Bpcg1State()
         st.A, st.B, st.BT = A.handle.ptr, B.handle.ptr, BT.handle.ptr
@@ -476,11 +479,14 @@ class Bpcg1Loop:
         eng._check(self.lib.nss_bpcg1_workspace(C.byref(st), C.byref(na), C.byref(nb), C.byref(nc)))
         self.partials = [eng.zeros(max(1, x.value)) for x in (na, nb, nc)]
         st.partials_a, st.partials_b, st.partials_c = (p.data_ptr() for p in self.partials)
-        self.scal = eng.zeros(8)
+        self.scal = eng.zeros(16)
         self.ctrl = torch.zeros(4, dtype=torch.int32, device=eng.device)
         st.scal, st.ctrl = self.scal.data_ptr(), self.ctrl.data_ptr()
         self.state = st
         self.hist = None
+
+    def enqueue(self, it_begin, it_end):
+        self.eng._check(self.lib.nss_bpcg1_iterate(C.byref(self.state), it_begin, it_end, self.eng.stream))
 
     def run(self, rho, err0, tolerance, max_steps, poll_every=None):
         """Returns (errors, converged): errors[i] = err_i/err_0 as appended at :118."""
@@ -488,7 +494,7 @@ class Bpcg1Loop:
         poll_every = poll_every or POLL_EVERY
         self.hist = eng.zeros(max(1, max_steps))
         st.hist = self.hist.data_ptr()
-        scal = np.zeros(8)
+        scal = np.zeros(16)
         scal[0], scal[5], scal[6] = rho, err0, tolerance
         eng.upload(scal, self.scal)
         self.ctrl.zero_()
@@ -496,7 +502,7 @@ class Bpcg1Loop:
         it = 0
         while it < max_steps:
             end = min(max_steps, it + poll_every)
-            eng._check(self.lib.nss_bpcg1_iterate(C.byref(st), it, end, eng.stream))
+            self.enqueue(it, end)
             it = end
             eng._check(self.lib.nss_bpcg1_poll(C.byref(st), C.byref(stop), C.byref(it_stop), C.byref(last), eng.stream))
             if stop.value:

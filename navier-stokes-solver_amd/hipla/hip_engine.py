@@ -84,6 +84,8 @@ def _signatures():
         "nss_cg_workspace": (C.c_int, [vp, c_i64_p, c_i64_p]),
         "nss_cg_iterate": (C.c_int, [vp, i32, i32, vp]),
         "nss_cg_poll": (C.c_int, [vp, c_i32_p, c_i32_p, c_i32_p, vp]),
+        "nss_bpcg1_phases": (C.c_int, [vp, i32, i32, i32, vp]),
+        "nss_bpcg1_iterate_dist": (C.c_int, [vp, vp, vp, vp, i32, i32, vp]),
         "nss_bpcg2_workspace": (C.c_int, [vp, c_i64_p, c_i64_p, c_i64_p]),
         "nss_bpcg2_phase": (C.c_int, [vp, i32, i32, vp]),
         "nss_bpcg2_phases": (C.c_int, [vp, i32, i32, i32, vp]),

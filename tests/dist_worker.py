@@ -101,6 +101,25 @@ def run(rank, world, mode, init_file, out_dir, dim, n, pre, tol, maxsteps):
         um, errs, rel = mr.solve(tol=tol, maxsteps=maxsteps, poll_every=8)
         res["minres_errors"], res["minres_rel"] = np.array(errs), int(rel)
         res["minres_u"], res["minres_p"] = um[0].numpy(), um[1].numpy()
+        # ---- fused row-partitioned BPCG v1 behind the reference's entry point (distributed.Bpcg1DistLoop) ----
+        from bramble_pasciak_cg import bramble_pasciak_cg
+        import distributed
+        created = []
+        orig = distributed.Bpcg1DistLoop.try_create.__func__
+
+        def spy(cls, *a, **k):
+            loop = orig(cls, *a, **k)
+            created.append(loop is not None)
+            return loop
+
+        distributed.Bpcg1DistLoop.try_create = classmethod(spy)
+        fv, gv = ops.vectors(f, g)
+        with contextlib.redirect_stdout(io.StringIO()):
+            x1, errs1 = bramble_pasciak_cg(ops.A, ops.B, None, ops.preA, ops.preM, fv, gv, tolerance=tol,
+                                           max_steps=maxsteps, print_rates=False)
+        res["bpcg1_fused"] = int(created == [True])
+        res["bpcg1_errors"] = np.array(errs1)
+        res["bpcg1_u"], res["bpcg1_p"] = x1[0].numpy(), x1[1].numpy()
     # ---- distributed AMG (replicated coarse levels) as preA, BPCG v2 through the protocol ------------
     if pre == "bjac":
         from distributed import DistributedAMG

@@ -53,6 +53,18 @@ def single_gpu_minres(s, pre, tol, maxsteps):
     return dict(errors=np.array(errors), u=u[0].numpy(), p=u[1].numpy())
 
 
+def single_gpu_bpcg1(s, pre, tol, maxsteps):
+    import hipla
+    from bramble_pasciak_cg import bramble_pasciak_cg
+    f, g = s.rhs(0)
+    A, B = hipla.SparseMatrix.from_scipy(s.A), hipla.SparseMatrix.from_scipy(s.B)
+    preA = hipla.BlockJacobi(A, s.line_blocks(3)) if pre == "bjac" else hipla.JacobiPreconditioner(A)
+    with contextlib.redirect_stdout(io.StringIO()):
+        x, errors = bramble_pasciak_cg(A, B, None, preA, hipla.DiagonalMatrix(1.0 / s.mass), hipla.Vector.from_numpy(f),
+                                       hipla.Vector.from_numpy(g), tolerance=tol, max_steps=maxsteps, print_rates=False)
+    return dict(errors=np.array(errors), u=x[0].numpy(), p=x[1].numpy())
+
+
 @pytest.mark.parametrize("world,dim,n,pre", [(2, 3, 10, "bjac"), (3, 2, 24, "jacobi"), (5, 3, 10, "jacobi")])
 def test_fused_distributed_loop_matches_single_gpu(hip_engine, world, dim, n, pre):
     tol, maxsteps = 1e-8, 4000
@@ -82,6 +94,16 @@ def test_fused_distributed_loop_matches_single_gpu(hip_engine, world, dim, n, pr
         assert int(d["minres_rel"]) == 1
     um = np.concatenate([d["minres_u"] for d in ranks])
     assert np.linalg.norm(um - mref["u"]) < 1e-5 * np.linalg.norm(mref["u"])
+    # fused row-partitioned BPCG v1 (behind bramble_pasciak_cg on distributed operands) against the single-GPU loop
+    vref = single_gpu_bpcg1(s, pre, tol, maxsteps)
+    for d in ranks:
+        assert int(d["bpcg1_fused"]) == 1
+        np.testing.assert_array_equal(d["bpcg1_errors"], ranks[0]["bpcg1_errors"])
+        w = min(30, len(vref["errors"]), len(d["bpcg1_errors"]))
+        np.testing.assert_allclose(d["bpcg1_errors"][:w], vref["errors"][:w], rtol=1e-8)
+        assert abs(len(d["bpcg1_errors"]) - len(vref["errors"])) <= max(3, int(0.03 * len(vref["errors"])))
+    u1 = np.concatenate([d["bpcg1_u"] for d in ranks])
+    assert np.linalg.norm(u1 - vref["u"]) < 1e-5 * np.linalg.norm(vref["u"])
     if pre == "bjac":
         # DistributedAMG (finest level on the slabs, coarse levels replicated on every rank) on the
         # product engine: same hierarchy, same V-cycle and same BPCG history as one GPU
@@ -253,6 +275,58 @@ def test_native_partitioned_minres_single_rank(hip_engine, tmp_path, pre):
     finally:
         lib.nss_minres_fold_mode(-1)
         lib.nss_minres_fuse_mode(-1)
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("pre", ["bjac", "jacobi"])
+def test_native_partitioned_bpcg1_single_rank(hip_engine, tmp_path, pre):
+    """nss_bpcg1_iterate_dist on a 1-rank RCCL communicator (grouped exchange of d, exchanges of t2_u and a_u,
+    out-of-place all-reduces of <d, t1> and rho_new issued from C) and the host-driven schedule over
+    nss_bpcg1_phases, both behind the reference's entry point called with distributed operands: identical bits
+    to the single-GPU loop; the scalars stay frozen after the stop."""
+    import torch
+    import torch.distributed as dist
+    import distributed
+    from bramble_pasciak_cg import bramble_pasciak_cg
+    from distributed import DistributedStokes
+    from rccl_comm import RcclComm
+    s = mac_stokes(3, 12, 0.01)
+    f, g = s.rhs(0)
+    tol, maxsteps = 1e-8, 4000
+    dist.init_process_group("gloo", init_method="file://" + str(tmp_path / "rdv"), rank=0, world_size=1)
+    loops = []
+    orig = distributed.Bpcg1DistLoop.try_create.__func__
+
+    def spy(cls, *a, **k):
+        loops.append(orig(cls, *a, **k))
+        return loops[-1]
+
+    try:
+        distributed.Bpcg1DistLoop.try_create = classmethod(spy)
+        ref = single_gpu_bpcg1(s, pre, tol, maxsteps)
+        comm = RcclComm(dist, hip_engine)
+        ops = DistributedStokes(s, s.line_blocks(3) if pre == "bjac" else None, comm, hip_engine)
+        for native in (True, False):
+            distributed.Bpcg1DistLoop.NATIVE = native
+            fv, gv = ops.vectors(f, g)
+            with contextlib.redirect_stdout(io.StringIO()):
+                x, errors = bramble_pasciak_cg(ops.A, ops.B, None, ops.preA, ops.preM, fv, gv, tolerance=tol,
+                                               max_steps=maxsteps, print_rates=False)
+            run = loops[-1]
+            assert run is not None and (run.native is not None) == native
+            np.testing.assert_array_equal(np.array(errors), ref["errors"])
+            np.testing.assert_array_equal(x[0].numpy(), ref["u"])
+            np.testing.assert_array_equal(x[1].numpy(), ref["p"])
+            before = hip_engine.to_host(run.loop.scal).copy()
+            run.enqueue(len(errors), len(errors) + 9)                   # after the stop: no-ops on the device
+            torch.cuda.synchronize()
+            np.testing.assert_array_equal(hip_engine.to_host(run.loop.scal), before)
+            np.testing.assert_array_equal(x[0].numpy(), ref["u"])
+            run.close()
+        comm.close()
+    finally:
+        distributed.Bpcg1DistLoop.NATIVE = True
+        distributed.Bpcg1DistLoop.try_create = classmethod(orig)
         dist.destroy_process_group()
 
 
