@@ -136,8 +136,13 @@ NSS_API int nss_csr_index_group(nss_csr_t a, int32_t* entries_per_index);
  * gather; 2 = staged -- per row block the runs of consecutive columns it touches are copied to LDS with
  * LDS-DMA issued ahead of the matrix stream, and the 16-bit index is a position in that copy (taken when every
  * row block touches at most 13 runs / `chunk` columns; kernels whose operand is an expression of two vectors
- * use form 1 of the same matrix). */
+ * use form 1 of the same matrix); 3 = fixed-width copy of a large matrix with at most two entries per row
+ * (B^T of the staggered grid), multiplied by the row-per-lane kernel. */
 NSS_API int nss_csr_operand_form(nss_csr_t a, int32_t* form);
+/* matrices created from now on take form 3 from `min_rows` rows on (default 2^21: below, the iteration is
+ * launch-bound and the launch a pair of matrices shares is worth more); -1 restores the default.  Same bits
+ * either way. */
+NSS_API int nss_csr_direct_rows_threshold(int64_t min_rows);
 /* shape, nnz, launch plan (row blocks, lanes per row) and algorithmic bytes of one
  * SpMV: 12*nnz + 4*(rows+1) + 8*cols + 8*rows */
 NSS_API int nss_csr_info(nss_csr_t a, int32_t* nrows, int32_t* ncols, int64_t* nnz,

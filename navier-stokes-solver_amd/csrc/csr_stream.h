@@ -65,6 +65,14 @@ constexpr int kWindows = 16;          // column windows per row block of the 16-
 constexpr int kWindowBits = 12;      // 4096 columns per window
 // Staged operand (nss_csr_s::blkseg): per row block at most kSegMax runs of consecutive columns, together at
 // most `chunk` columns (the products per row block), copied to LDS by LDS-DMA ahead of the matrix stream.
+#ifndef NSS_DIRECT_ROWS
+#define NSS_DIRECT_ROWS 1
+#endif
+constexpr int kDirectWidth = 2;        // entries per row of the fixed-width copy (csr_direct_kernel)
+#ifndef NSS_DIRECT_ROWS_PER_LANE
+#define NSS_DIRECT_ROWS_PER_LANE 2
+#endif
+constexpr int kDirectRows = NSS_DIRECT_ROWS_PER_LANE * 256;   // rows per row block of such a matrix
 constexpr int kSegMax = 13;             // (the LDS copy holds up to `chunk` columns: it shares the product buffer)
 constexpr int kSegWords = 32;        // descriptor: r0, r1, p0, cnt, nseg, total, pre[1..12], off[0..12], spare
 constexpr int kSegPre = 6, kSegOff = 18;
@@ -129,6 +137,13 @@ struct nss_csr_s {
   // decode(index[p / gb]) + p % gb.  The value order stays CSR (rows contiguous), so the kernel, its
   // reduction order and its results are unchanged.  gb == 1: one index per entry.
   int32_t gb = 1;
+  // Fixed-width copy of a large matrix with at most kDirectWidth entries per row (B^T of the staggered grid):
+  // kDirectWidth (column, value) slots per row, column -1 in unused slots.  Such a matrix is multiplied by
+  // csr_direct_kernel: one lane per row, no LDS staging, every load of a lane's rows requested up front -- the
+  // stream kernel spends most of a 2-entry-per-row launch in its per-row phase (1024 rows per workgroup, four
+  // passes, the epilogue's loads of each pass behind the previous one's stores).
+  int32_t* ell_col = nullptr;
+  double* ell_val = nullptr;
   // `stageable`: the kernel's operand functor can be copied to LDS (XOp::kStageable)
   int idx_mode(bool stageable = true) const { return (blkseg && stageable) ? 2 : (col16 ? 1 : 0); }
   // launch view of the row blocks [b0, b1)
@@ -146,6 +161,8 @@ namespace nss {
 
 // Build col16 / blkbase of a matrix whose device arrays and launch plan are complete (spmv.hip).
 void compress_columns(nss_csr_s& A, hipStream_t st);
+
+bool direct_rows_candidate(int32_t m, const int32_t* rowptr);
 
 // Launch plan of a CSR matrix: lanes per row (*rg_out) and the row-block boundaries (spmv.hip).
 void plan_row_blocks(int32_t m, int64_t nnz, const int32_t* rowptr, int32_t* rg_out, int32_t* chunk_out,
@@ -480,6 +497,62 @@ __global__ __launch_bounds__(kBlock) void csr_stream_dual_kernel(CsrView a, CsrV
   }
 }
 
+// Row-per-lane kernel for the fixed-width copy (nss_csr_s::ell_col): workgroup = one row block of at most
+// kDirectRows rows, lane t takes rows r0 + t and r0 + t + 256 (unit stride across the lanes; giving a lane two
+// CONSECUTIVE rows instead makes every per-row access of the epilogue a stride-2 access: C1 +35 %).  All loads of both rows -- slots, epilogue
+// operands -- are requested before the prologue; the operand is gathered (two entries per row: nothing to
+// stage).  The row sum is formed exactly as the stream kernel forms it (0 + p0 + p1, products rounded on their
+// own: mul_unfused), so both kernels give identical bits.
+template <class Epi>
+__global__ __launch_bounds__(kBlock) void csr_direct_kernel(CsrView a, const int32_t* __restrict__ ecol,
+                                                            const double* __restrict__ eval,
+                                                            const double* __restrict__ x, Epi epi) {
+  static_assert(kDirectWidth == 2, "csr_direct_kernel is written for two slots per row");
+  using XOp = typename EpiX<Epi>::type;
+  __shared__ double red[kRedDoubles];
+  if (epi.skip()) return;
+  const int tid = threadIdx.x, wg = int(blockIdx.x);
+  const int lb = (wg & (kXcds - 1)) * a.per_xcd + (wg >> 3);
+  const int b = lb < a.nblk ? a.blk0 + lb : -1;
+  if (b >= 0) {
+    const int r0 = a.rowblk[b], r1 = a.rowblk[b + 1];
+    for (int base = r0; base < r1; base += kDirectRows) {     // (one trip: the plan caps such blocks at kDirectRows rows)
+      constexpr int kRows = kDirectRows / kBlock;
+      typedef int32_t int2v __attribute__((ext_vector_type(2)));
+      int2v c[kRows];
+      dbl2v v[kRows];
+      typename EpiPre<Epi>::type pre[kRows];
+#pragma unroll
+      for (int q = 0; q < kRows; ++q) {
+        const int r = base + tid + q * kBlock;
+        const bool live = r < r1;
+        c[q] = live ? __builtin_nontemporal_load(reinterpret_cast<const int2v*>(ecol) + r) : int2v{-1, -1};
+        v[q] = live ? __builtin_nontemporal_load(reinterpret_cast<const dbl2v*>(eval) + r) : dbl2v{0.0, 0.0};
+        pre[q] = live ? EpiPre<Epi>::fetch(epi, r) : typename EpiPre<Epi>::type{};
+      }
+      if (base == r0 && !EpiPrologue<Epi>::run(epi, red)) return;   // uniform over the workgroup
+      const XOp xop = EpiX<Epi>::get(epi, x);
+      double x0[kRows], x1[kRows];
+#pragma unroll
+      for (int q = 0; q < kRows; ++q) {
+        x0[q] = c[q].x >= 0 ? xop(c[q].x) : 0.0;
+        x1[q] = c[q].y >= 0 ? xop(c[q].y) : 0.0;
+      }
+#pragma unroll
+      for (int q = 0; q < kRows; ++q) {
+        const int r = base + tid + q * kBlock;
+        if (r < r1) {
+          double sum = 0.0;
+          if (c[q].x >= 0) sum += mul_unfused(v[q].x, x0[q]);
+          if (c[q].y >= 0) sum += mul_unfused(v[q].y, x1[q]);
+          EpiPre<Epi>::row(epi, r, sum, pre[q]);
+        }
+      }
+    }
+  }
+  epi.finish(b, red);
+}
+
 // The launch plan only produces (chunk, lanes per row) = (kChunk, 1 | 2) and (kChunkLong, 2 ... 64): lanes per
 // row = the largest power of two with 2 * lanes * chunk / kBlock <= mean row length, and the chunk is kChunkLong
 // from 32 non-zeros per row on (plan_row_blocks).  Other combinations are not instantiated.
@@ -508,6 +581,12 @@ inline void launch_csr_stream(const nss_csr_s& A, const double* x, const Epi& ep
                               int b1 = -1) {
   if (b1 < 0) b1 = A.nblk;
   if (A.m == 0 || b1 <= b0) return;
+  if (A.ell_col) {
+    hipLaunchKernelGGL((csr_direct_kernel<Epi>), dim3(nss_csr_s::grid(b1 - b0)), dim3(kBlock), 0, st, A.view(b0, b1, 0),
+                       A.ell_col, A.ell_val, x, epi);
+    NSS_CHECK_LAUNCH();
+    return;
+  }
   constexpr bool kCanStage = EpiX<Epi>::type::kStageable;
   const int mode = A.idx_mode(kCanStage);
   const bool grp = mode != 0 && A.gb > 1;
@@ -539,6 +618,7 @@ inline bool launch_csr_stream_dual(const nss_csr_s& A, const double* xa, const E
   return false;
 #endif
   if (A.m == 0 || B.m == 0 || A.nblk == 0 || B.nblk == 0) return false;
+  if (A.ell_col || B.ell_col) return false;               // row-per-lane kernel: a launch of its own
   if (A.rg != B.rg || A.chunk != B.chunk) return false;
   constexpr bool kStageA = EpiX<EpiA>::type::kStageable, kStageB = EpiX<EpiB>::type::kStageable;
   const int ma = A.idx_mode(kStageA), mb = B.idx_mode(kStageB);

@@ -110,6 +110,15 @@ __device__ __forceinline__ void store2_nt(double* p, const double2& v) {
   __builtin_nontemporal_store(t, reinterpret_cast<dbl2v*>(p));
 }
 
+// a * b rounded on its own: hipcc (-ffp-contract=fast) fuses a product into a following addition even across
+// __dmul_rn / __dadd_rn (seen: one-ulp differences against the kernel that stages its products in LDS); the
+// inline instruction cannot be fused
+__device__ __forceinline__ double mul_unfused(double a, double b) {
+  double p;
+  asm volatile("v_mul_f64 %0, %1, %2" : "=v"(p) : "v"(a), "v"(b));
+  return p;
+}
+
 __device__ __forceinline__ double2 ld2(const double* p) { return *reinterpret_cast<const double2*>(p); }
 __device__ __forceinline__ void st2(double* p, const double2& v) { *reinterpret_cast<double2*>(p) = v; }
 

@@ -12,6 +12,28 @@ namespace nss {
 #endif
 constexpr int kMinRowBlocks = 2048;   // 256 CUs x 8 resident workgroups
 
+#ifndef NSS_DIRECT_MIN_ROWS
+#define NSS_DIRECT_MIN_ROWS (1 << 21)
+#endif
+
+// Large matrices whose rows hold at most kDirectWidth entries (B^T of the staggered grid: two per row) get a padded
+// fixed-width copy and the row-per-lane kernel (csr_direct_kernel).  Below NSS_DIRECT_MIN_ROWS rows the iteration
+// is launch-bound and the one launch a pair of matrices shares (csr_stream_dual_kernel) is worth more.
+static int64_t g_direct_min_rows = NSS_DIRECT_MIN_ROWS;   // nss_csr_direct_rows_threshold() (tests, measurements)
+
+bool direct_rows_candidate(int32_t m, const int32_t* rowptr) {
+#if NSS_DIRECT_ROWS
+  if (m < g_direct_min_rows) return false;
+  for (int32_t r = 0; r < m; ++r)
+    if (rowptr[r + 1] - rowptr[r] > kDirectWidth) return false;
+  return true;
+#else
+  (void)m;
+  (void)rowptr;
+  return false;
+#endif
+}
+
 void plan_row_blocks(int32_t m, int64_t nnz, const int32_t* rowptr, int32_t* rg_out, int32_t* chunk_out,
                      std::vector<int32_t>& blk, const int32_t* cuts, int ncuts) {
   const double mean = m > 0 ? double(nnz) / double(m) : 0.0;
@@ -35,7 +57,8 @@ void plan_row_blocks(int32_t m, int64_t nnz, const int32_t* rowptr, int32_t* rg_
     while (passes > 1 && int64_t(m) / (int64_t(passes) * rows_per_pass) < kMinRowBlocks) --passes;
 #endif
   }
-  const int row_cap = std::min(kMaxRowsPerBlock, passes * rows_per_pass);
+  int row_cap = std::min(kMaxRowsPerBlock, passes * rows_per_pass);
+  if (direct_rows_candidate(m, rowptr)) row_cap = std::min(row_cap, kDirectRows);   // see csr_direct_kernel
   blk.clear();
   blk.push_back(0);
   int32_t r = 0;
@@ -407,6 +430,61 @@ static void window_columns(nss_csr_s& A, hipStream_t st) {
   (void)hipFree(c16);
 }
 
+// fixed-width copy: kDirectWidth (column, value) pairs per row, column -1 where the row is shorter
+__global__ __launch_bounds__(kBlock) void ell_build_kernel(int32_t m, const int32_t* __restrict__ rowptr,
+                                                            const int32_t* __restrict__ col,
+                                                            const double* __restrict__ val, int32_t* __restrict__ ecol,
+                                                            double* __restrict__ eval, int32_t* __restrict__ wide) {
+  const int64_t stride = int64_t(gridDim.x) * kBlock;
+  for (int64_t r = int64_t(blockIdx.x) * kBlock + threadIdx.x; r < m; r += stride) {
+    const int s = rowptr[r], e = rowptr[r + 1];
+    if (e - s > kDirectWidth) atomicOr(wide, 1);
+    for (int j = 0; j < kDirectWidth; ++j) {
+      const bool has = s + j < e;
+      ecol[r * kDirectWidth + j] = has ? col[s + j] : -1;
+      eval[r * kDirectWidth + j] = has ? val[s + j] : 0.0;
+    }
+  }
+}
+
+static void direct_rows(nss_csr_s& A, hipStream_t st) {
+#if NSS_DIRECT_ROWS
+  if (A.m < g_direct_min_rows || A.nnz > int64_t(kDirectWidth) * A.m) return;
+  int32_t* ecol = nullptr;
+  double* eval = nullptr;
+  int32_t* wide = nullptr;
+  try {
+    NSS_HIP(hipMalloc(&ecol, sizeof(int32_t) * size_t(A.m) * kDirectWidth));
+    NSS_HIP(hipMalloc(&eval, sizeof(double) * size_t(A.m) * kDirectWidth));
+    NSS_HIP(hipMalloc(&wide, sizeof(int32_t)));
+    NSS_HIP(hipMemsetAsync(wide, 0, sizeof(int32_t), st));
+    hipLaunchKernelGGL(ell_build_kernel, dim3(stream_grid(A.m, kBlock * 4)), dim3(kBlock), 0, st, A.m, A.rowptr, A.col,
+                       A.val, ecol, eval, wide);
+    NSS_CHECK_LAUNCH();
+    int32_t h_wide = 1;
+    NSS_HIP(hipMemcpyAsync(&h_wide, wide, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    NSS_HIP(hipStreamSynchronize(st));
+    if (h_wide == 0) {
+      A.ell_col = ecol;
+      A.ell_val = eval;
+      ecol = nullptr;
+      eval = nullptr;
+    }
+  } catch (...) {
+    (void)hipFree(ecol);
+    (void)hipFree(eval);
+    (void)hipFree(wide);
+    throw;
+  }
+  (void)hipFree(ecol);
+  (void)hipFree(eval);
+  (void)hipFree(wide);
+#else
+  (void)A;
+  (void)st;
+#endif
+}
+
 // Both 16-bit forms the matrix admits (the kernels pick per launch: staged where the operand is one stored
 // vector, the window form otherwise), then one index per column run where the matrix is made of runs.
 void compress_columns(nss_csr_s& A, hipStream_t st) {
@@ -415,6 +493,7 @@ void compress_columns(nss_csr_s& A, hipStream_t st) {
   stage_columns(A, st);
   window_columns(A, st);
   group_columns(A, st);
+  direct_rows(A, st);
 #else
   (void)A;
   (void)st;
@@ -499,6 +578,8 @@ int nss_csr_destroy(nss_csr_t a) {
     (void)hipFree(a->blkbase);
     (void)hipFree(a->blkseg);
     (void)hipFree(a->pos16);
+    (void)hipFree(a->ell_col);
+    (void)hipFree(a->ell_val);
     delete a;
   });
 }
@@ -525,10 +606,17 @@ int nss_csr_index_group(nss_csr_t a, int32_t* entries_per_index) {
   });
 }
 
+int nss_csr_direct_rows_threshold(int64_t min_rows) {
+  return guarded([&] {
+    NSS_REQUIRE(min_rows >= -1, "csr_direct_rows_threshold: -1 (default) or a row count");
+    g_direct_min_rows = min_rows < 0 ? int64_t(NSS_DIRECT_MIN_ROWS) : min_rows;
+  });
+}
+
 int nss_csr_operand_form(nss_csr_t a, int32_t* form) {
   return guarded([&] {
     NSS_REQUIRE(a != nullptr && form != nullptr, "csr_operand_form: NULL argument");
-    *form = a->idx_mode();
+    *form = a->ell_col ? 3 : a->idx_mode();
   });
 }
 
@@ -546,7 +634,9 @@ int nss_csr_info(nss_csr_t a, int32_t* nrows, int32_t* ncols, int64_t* nnz, int3
     // bases per row block, or 4-byte columns -- what the plain SpMV of this matrix streams), the row
     // pointers, x once and y once.  (The CSR fp64/int32 textbook figure is 12 nnz + ...; pricing a
     // launch that streams 10 bytes per entry at 12 would overstate its bandwidth.)
-    if (algorithmic_bytes)
+    if (algorithmic_bytes && a->ell_col)      // fixed-width copy: 12 bytes per slot, no row pointers
+      *algorithmic_bytes = int64_t(12) * nss::kDirectWidth * a->m + 8 * int64_t(a->n) + 8 * int64_t(a->m);
+    else if (algorithmic_bytes)
       *algorithmic_bytes = ((a->col16 || a->pos16) ? 8 * a->nnz + 2 * (a->nnz / a->gb) +
                                                            int64_t(4) * (a->blkseg ? kSegWords : kWindows) * a->nblk
                                                      : 12 * a->nnz) +

@@ -48,6 +48,7 @@ def _signatures():
         "nss_csr_index_width": (C.c_int, [vp, c_i32_p]),
         "nss_csr_index_group": (C.c_int, [vp, c_i32_p]),
         "nss_csr_operand_form": (C.c_int, [vp, c_i32_p]),
+        "nss_csr_direct_rows_threshold": (C.c_int, [i64]),
         "nss_scratch_trim": (C.c_int, []),
         "nss_csr_ones_like": (C.c_int, [vp, C.POINTER(vp), vp]),
         "nss_graph_color": (C.c_int, [vp, vp, vp, vp, c_i32_p, vp]),
@@ -157,7 +158,7 @@ class _CsrHandle:
         form = C.c_int32(width.value == 2)
         if hasattr(lib, "nss_csr_operand_form"):                     # (absent in older A/B builds)
             self.engine._check(lib.nss_csr_operand_form(self.ptr, form))
-        return {"operand_form": ("gather32", "gather16", "staged")[form.value],
+        return {"operand_form": ("gather32", "gather16", "staged", "rows")[form.value],
                 "rows": m.value, "cols": n.value, "nnz": nnz.value, "row_blocks": nb.value,
                 "lanes_per_row": rg.value, "algorithmic_bytes": nbytes.value, "index_bytes": width.value,
                 "index_group": group.value}

@@ -156,6 +156,39 @@ def test_spmv_operand_forms(hip_engine):
         assert np.max(np.abs(y.cpu().numpy() - ref)) <= 1e-12 * np.max(np.abs(ref)), shift
 
 
+def test_spmv_row_per_lane_kernel(hip_engine):
+    """Matrices with at most two entries per row (B^T of the staggered grid) above a size threshold are multiplied
+    by the row-per-lane kernel from a fixed-width copy: same bits as the stream kernel, empty and one-entry rows
+    included; the threshold is a run-time knob so that small cases reach it."""
+    import hipla
+    lib = hip_engine.lib
+    s = mac_stokes(3, 14)
+    bt = s.B.T.tocsr()
+    rng = np.random.default_rng(8)
+    ragged = sp.random(3000, 900, density=1.2e-3, random_state=6, format="csr")
+    keep = ragged.getnnz(axis=1) <= 2
+    ragged = sp.csr_matrix(sp.diags(keep.astype(float)) @ ragged)               # rows with 0, 1 or 2 entries
+    ragged.eliminate_zeros()
+    assert set(np.unique(ragged.getnnz(axis=1))) >= {0, 1, 2}
+    for mat in (bt, ragged):
+        x = rng.standard_normal(mat.shape[1])
+        y0 = rng.standard_normal(mat.shape[0])
+        out = {}
+        for name, rows in (("stream", -1), ("rows", 0)):
+            assert lib.nss_csr_direct_rows_threshold(rows) == 0
+            try:
+                M = hipla.SparseMatrix.from_scipy(mat)
+            finally:
+                lib.nss_csr_direct_rows_threshold(-1)
+            assert (M.handle.info()["operand_form"] == "rows") == (name == "rows"), M.handle.info()
+            X, Y = hipla.Vector.from_numpy(x), hipla.Vector.from_numpy(y0)
+            hip_engine.csr_spmv(M.handle, -1.5, X.buf, 0.25, Y.buf)
+            out[name] = Y.numpy()
+        ref = -1.5 * (mat @ x) + 0.25 * y0
+        assert np.max(np.abs(out["rows"] - ref)) <= 1e-13 * (np.max(np.abs(ref)) + 1.0)
+        np.testing.assert_array_equal(out["rows"], out["stream"])
+
+
 def _plan_lanes(mean):
     """The plan rule of csrc/spmv.hip: matrices with mean >= 32 non-zeros per row stage 4096 products
     per row block (16 per lane), the others 2048 (8 per lane); lanes per row = the largest power of

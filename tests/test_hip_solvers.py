@@ -400,6 +400,54 @@ def test_fused_bpcg2_frozen_at_break_and_maxsteps_warning(hip_engine):
     assert it == 8 and "Warning: BPCG did not converge" in out.getvalue()
 
 
+@pytest.mark.parametrize("name", ["stokes3d_n10_bjac", "stokes2d_n24_jacobi"])
+def test_row_per_lane_kernel_in_the_fused_loops(hip_engine, name):
+    """B^T (two entries per row) multiplied by the row-per-lane kernel from its fixed-width copy instead of by the
+    stream kernel (csr_direct_kernel; automatic from 2^21 rows on, forced here): the three fused loops produce the
+    same histories and solutions bit for bit -- the row sums are formed in the same order without fused
+    multiply-adds, and no dot product is grouped by B^T's row blocks."""
+    import hipla
+    from bramble_pasciak_cg import bramble_pasciak_cg
+    from minres import MinRes
+    from solvers.bramblepasciak_new import BramblePasciakCG
+    lib = hip_engine.lib
+    results = {}
+    for mode, rows in (("stream", -1), ("rows", 0)):
+        assert lib.nss_csr_direct_rows_threshold(rows) == 0
+        try:
+            for solver in ("bpcg2", "bpcg1", "minres"):
+                d = np.load(golden_path("%s_%s" % (name, solver)))
+                c, blfA, A, B, preA, preS = case_operands(d)
+                s = c.system
+                assert (B.T.handle.info()["operand_form"] == "rows") == (mode == "rows")
+                fv, gv = hipla.Vector.from_numpy(c.f), hipla.Vector.from_numpy(c.g)
+                out = io.StringIO()
+                with fused_loops_counted() as counts, contextlib.redirect_stdout(out):
+                    if solver == "bpcg2":
+                        sol = hipla.BlockVector([hipla.Vector(s.n_u), hipla.Vector(s.n_p)])
+                        BramblePasciakCG(blfA, Form(B), None, fv, gv, preA, preS, sol, tol=float(d["tol"]),
+                                         maxsteps=int(d["maxsteps"]), printrates=True)
+                        hist = np.array([float(m) for m in re.findall(r"it =\s+\d+\s+err =\s+(\S+)", out.getvalue())])
+                        x = sol.numpy()
+                    elif solver == "bpcg1":
+                        sol, errors = bramble_pasciak_cg(A, B, None, preA, preS, fv, gv, tolerance=float(d["tol"]),
+                                                         max_steps=int(d["maxsteps"]), print_rates=False)
+                        hist, x = np.array(errors), sol.numpy()
+                    else:
+                        K = hipla.BlockMatrix([[A, B.T], [B, None]])
+                        Cm = hipla.BlockMatrix([[preA, None], [None, preS]])
+                        u, errors = MinRes(mat=K, pre=Cm, rhs=hipla.BlockVector([fv, gv]), maxsteps=int(d["maxsteps"]),
+                                           tol=float(d["tol"]), printrates=False)
+                        hist, x = np.array(errors), u.numpy()
+                assert counts[solver] == 1
+                results[mode, solver] = (hist, x)
+        finally:
+            lib.nss_csr_direct_rows_threshold(-1)
+    for solver in ("bpcg2", "bpcg1", "minres"):
+        np.testing.assert_array_equal(results["rows", solver][0], results["stream", solver][0])
+        np.testing.assert_array_equal(results["rows", solver][1], results["stream", solver][1])
+
+
 @pytest.mark.parametrize("case", ["stokes3d_n10_bjac_bpcg2", "stokes2d_n24_jacobi_bpcg2",
                                   "stokes3d_n5_facet_x12_bpcg2", "stokes2d_n16_facet_x5_bpcg2",
                                   "stokes3d_n8_bjac_cond_bpcg2"])
