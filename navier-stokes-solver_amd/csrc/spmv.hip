@@ -348,8 +348,11 @@ static void group_columns(nss_csr_s& A, hipStream_t st) {
 #endif
 }
 
+// Shortest mean row for which the matrix is staged.  Two entries per row (B^T) pay where launches dominate
+// (1e5 DoF: MINRES 23.7-25.2 -> 21.8 us per iteration, BPCG v1 40 -> 37.5; 1e6 DoF: no change); the large
+// two-entry-per-row matrices take the row-per-lane kernel instead (direct_rows).
 #ifndef NSS_STAGE_MIN_MEAN
-#define NSS_STAGE_MIN_MEAN 3     // rows shorter than this on average: the copy costs more than the gathers it saves
+#define NSS_STAGE_MIN_MEAN 2
 #endif
 
 // Staged operand form: A.pos16 / A.blkseg when the matrix takes it.
