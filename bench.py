@@ -568,7 +568,12 @@ def main():
                    "column_index_bytes": {"A": a_info["index_bytes"], "B": b_info["index_bytes"],
                                           "BT": bt_info["index_bytes"]},
                    "entries_per_column_index": {"A": a_info["index_group"], "B": b_info["index_group"],
-                                                "BT": bt_info["index_group"]}},
+                                                "BT": bt_info["index_group"]},
+                   # how the kernels reach the SpMV operand (csrc/csr_stream.h): staged = LDS copy of the row
+                   # block's column runs by LDS-DMA (kernels whose operand is one stored vector; the others
+                   # gather through the 16-bit window form of the same matrix), rows = row-per-lane kernel
+                   "operand_form": {"A": a_info["operand_form"], "B": b_info["operand_form"],
+                                    "BT": bt_info["operand_form"]}},
         "roofline": {"bound": "hbm",
                      "kernel": ("csr_stream_dual_kernel<EpiK2c, EpiK3c>: t2 = A t1 with <s0, t2 - t0> and "
                                 "t3 = B (t1 - s0) with s1 = beta s1 + w1, <s1, t3> in one launch" if dual else
