@@ -139,6 +139,20 @@ def test_spmv_operand_forms(hip_engine):
     rnd = sp.random(20000, 20000, density=4e-4, random_state=5, format="csr")
     M = _spmv_check(hip_engine, rnd, seed=14)
     assert M.handle.info()["operand_form"] in ("gather16", "gather32")
+    # 13 runs per row block is the capacity of the run table, 14 is one too many
+    n = 60000
+    # (pairs of adjacent diagonals: the rows of a block share most of a run, so the copy is half the entries)
+    def banded(runs):
+        offs = [o for j in range(runs) for o in ((j - 6) * 3000, (j - 6) * 3000 + 1)]
+        return sp.diags([1.0 + 0.01 * j for j in range(len(offs))], offs, shape=(n, n), format="csr")
+    assert hipla_info(hip_engine, banded(13))["operand_form"] == "staged"
+    assert hipla_info(hip_engine, banded(14))["operand_form"] in ("gather16", "gather32")
+    # one row longer than a chunk inside a staged matrix: its row block is reduced from the 4-byte columns
+    long_row = sp.diags([1.0, -2.0, 1.0], [-1, 0, 1], shape=(20000, 20000), format="lil")
+    long_row[777, 5000:11000] = 0.5
+    info = hipla_info(hip_engine, long_row.tocsr())
+    assert info["operand_form"] == "staged", info
+    _spmv_check(hip_engine, long_row.tocsr(), seed=16, alpha=0.5, beta=-1.0)
     # odd and even run lengths / starts, operand vectors that are only 8-byte aligned (sub-views of a buffer)
     import hipla
     import torch
