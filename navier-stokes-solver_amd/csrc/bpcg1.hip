@@ -104,6 +104,15 @@ struct EpiV5 {
   }
 };
 
+#ifndef NSS_BPCG1_NT_LOADS
+#define NSS_BPCG1_NT_LOADS 1
+#endif
+#if NSS_BPCG1_NT_LOADS
+#define NSS_V_LD(x) __builtin_nontemporal_load(&(x))
+#else
+#define NSS_V_LD(x) (x)
+#endif
+
 constexpr int kPSum = 1024;
 // which = 0: loop-top bookkeeping; 1: alpha from sum(pa)+sum(pb); 2: rho_new, beta;
 // row-partitioned (local != 0): 1 / 2 only store the local total, 3 / 4 derive alpha / rho_new, beta from the
@@ -184,18 +193,20 @@ __global__ __launch_bounds__(kBlock) void bpcg1_v4_kernel(V4Args a) {
   const double alpha = a.scal[P_ALPHA];
   const int stride = gridDim.x * kBlock;
   double acc = 0.0;
+  // streaming loads for what is not read again before it is rewritten or an iteration has passed (x, r, t1, t2,
+  // a); d stays cached: V6 and the next iteration's SpMVs read it
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < a.n_u; i += stride) {
-    NSS_ST(a.xu[i], fma(alpha, a.du[i], a.xu[i]));
-    const double rn = fma(-alpha, a.t1u[i], a.ru[i]);
-    const double an = fma(-alpha, a.t2u[i], a.au[i]);
+    NSS_ST(a.xu[i], fma(alpha, a.du[i], NSS_V_LD(a.xu[i])));
+    const double rn = fma(-alpha, NSS_V_LD(a.t1u[i]), NSS_V_LD(a.ru[i]));
+    const double an = fma(-alpha, NSS_V_LD(a.t2u[i]), NSS_V_LD(a.au[i]));
     a.ru[i] = rn;
     a.au[i] = an;
     acc = fma(an, rn, acc);
   }
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < a.n_p; i += stride) {
-    NSS_ST(a.xp[i], fma(alpha, a.dp[i], a.xp[i]));
-    a.rp[i] = fma(-alpha, a.t1p[i], a.rp[i]);
-    a.ap[i] = fma(-alpha, a.t2p[i], a.ap[i]);
+    NSS_ST(a.xp[i], fma(alpha, a.dp[i], NSS_V_LD(a.xp[i])));
+    a.rp[i] = fma(-alpha, NSS_V_LD(a.t1p[i]), NSS_V_LD(a.rp[i]));
+    a.ap[i] = fma(-alpha, NSS_V_LD(a.t2p[i]), NSS_V_LD(a.ap[i]));
   }
   const double s = block_sum(acc, lds);
   if (threadIdx.x == 0) a.partials[blockIdx.x] = s;
@@ -209,8 +220,8 @@ __global__ __launch_bounds__(kBlock) void bpcg1_v6_kernel(const int32_t* __restr
   if (ctrl[PC_STOP] != 0) return;
   const double beta = scal[P_BETA];
   const int stride = gridDim.x * kBlock;
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n_u; i += stride) du[i] = fma(beta, du[i], au[i]);
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n_p; i += stride) dp[i] = fma(beta, dp[i], t1p[i]);
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n_u; i += stride) du[i] = fma(beta, NSS_V_LD(du[i]), NSS_V_LD(au[i]));
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n_p; i += stride) dp[i] = fma(beta, NSS_V_LD(dp[i]), NSS_V_LD(t1p[i]));
 }
 
 static int p_grid(const nss_bpcg1_t& s) { return stream_grid(int64_t(s.n_u) + s.n_p, kBlock * 4); }

@@ -42,6 +42,21 @@
 // (SURVEY.md section 8e).
 #include "dist.h"
 
+// Streaming (non-temporal) LOADS of vector operands that are not read again before they are rewritten: they do
+// not displace the operand windows of the SpMV kernels from the 4-MiB XCD L2s.  Interleaved same-box A/B at 1e7
+// DoF (profiles/r02_ab_streaming_loads.txt): packed block-Jacobi inverses +2.3 % iterations/s, C1's q / z0 / t2 /
+// w0 / u0 +5.4 % (C23 gets 7 % faster: t1 and s0 are still in L2 when it stages them), C4's operands +3.6 %;
+// MINRES' element-wise kernels +8 % (minres.hip), BPCG v1's +1.4 % (bpcg1.hip).
+#ifndef NSS_K1C_NT_LOADS
+#define NSS_K1C_NT_LOADS 1
+#endif
+#ifndef NSS_K4_NT_LOADS
+#define NSS_K4_NT_LOADS 1
+#endif
+#ifndef NSS_K2C_NT_LOADS
+#define NSS_K2C_NT_LOADS 0      // t0 in the epilogue of the A rows: no difference measured
+#endif
+
 namespace nss {
 
 enum { S_WD = 0, S_AS = 1, S_WDN = 2, S_ALPHA = 3, S_BETA = 4, S_ERR0 = 5, S_TOL = 6, S_REL = 7, S_WD_ODD = 8,
@@ -257,20 +272,28 @@ __global__ __launch_bounds__(kBlock) void bpcg2_k4_kernel(K4Args a) {
   double2 q0{}, q1{}, q2{}, q3{}, q4{}, q5{};
   const bool vec_u = VEC2 && wg0 < a.gu && e0 + 1 < a.n_u;
   const bool vec_p = VEC2 && wg0 >= a.gu && wg0 < a.gu + a.gp && e0 + 1 < a.n_p;
+  // streaming loads for everything that is dead or rewritten after this kernel (t0, t1, t3, d, u1) or next read
+  // by a streaming load itself (t2, w0); s1 and w1 stay cached: the rows of B^T gather them next
+#if NSS_K4_NT_LOADS
+#define NSS_LD2S ld2_nt
+#else
+#define NSS_LD2S ld2
+#endif
   if (vec_u) {
-    q0 = ld2(a.t0 + e0);
-    q1 = ld2(a.t1 + e0);
-    q2 = ld2(a.t2 + e0);
-    q3 = ld2(a.d0 + e0);
-    q4 = ld2(a.w0 + e0);
+    q0 = NSS_LD2S(a.t0 + e0);
+    q1 = NSS_LD2S(a.t1 + e0);
+    q2 = NSS_LD2S(a.t2 + e0);
+    q3 = NSS_LD2S(a.d0 + e0);
+    q4 = NSS_LD2S(a.w0 + e0);
   } else if (vec_p) {
     q0 = ld2(a.s1 + e0);
-    q1 = ld2(a.t3 + e0);
-    q2 = ld2(a.minv + e0);
-    q3 = ld2(a.u1 + e0);
-    q4 = ld2(a.d1 + e0);
+    q1 = NSS_LD2S(a.t3 + e0);
+    q2 = NSS_LD2S(a.minv + e0);
+    q3 = NSS_LD2S(a.u1 + e0);
+    q4 = NSS_LD2S(a.d1 + e0);
     q5 = ld2(a.w1 + e0);
   }
+#undef NSS_LD2S
   // alpha = wd / <s, K^ s> (:226), evaluated by every lane from the (all-)reduced sum.
   // <s, K^ s> == 0: the reference raises ZeroDivisionError in Python; freeze the state and report
   // it (ctrl[3]) so that the host can raise the same error.
@@ -499,6 +522,7 @@ struct EpiK1c {
 #ifndef NSS_K1C_PREFETCH
 #define NSS_K1C_PREFETCH 0
 #endif
+
 #if NSS_K1C_PREFETCH
   struct Pre { double q = 0.0, z0 = 0.0, t2 = 0.0, s0 = 0.0, w0 = 0.0, u0 = 0.0; };
   __device__ Pre fetch(int r) const {
@@ -509,8 +533,16 @@ struct EpiK1c {
 #else
   struct PreLate { double q, z0, t2, s0, w0, u0; };
   __device__ void row(int r, double bts) const {
-    const PreLate p{q[r], it ? z0[r] : 0.0, it ? t2[r] : 0.0, it ? s0[r] : 0.0, it ? w0[r] : 0.0,
-                    (it && pending) ? u0[r] : 0.0};
+    // q, z0, t2, w0, u0 are read here and nowhere else before they are rewritten: streaming loads keep them
+    // out of the XCD L2s (s0 stays: the rows of A and B read it next)
+#if NSS_K1C_NT_LOADS
+#define NSS_LDS1(a) __builtin_nontemporal_load(&(a))
+#else
+#define NSS_LDS1(a) (a)
+#endif
+    const PreLate p{NSS_LDS1(q[r]), it ? NSS_LDS1(z0[r]) : 0.0, it ? NSS_LDS1(t2[r]) : 0.0, it ? s0[r] : 0.0,
+                    it ? NSS_LDS1(w0[r]) : 0.0, (it && pending) ? NSS_LDS1(u0[r]) : 0.0};
+#undef NSS_LDS1
 #endif
     double qv = p.q;
     if (it != 0) {
@@ -538,7 +570,11 @@ struct EpiK2c {
   double acc = 0.0;
   __device__ bool skip() const { return ctrl[C_DONE] != 0; }
   struct Pre { double s0 = 0.0, t0 = 0.0; };
+#if NSS_K2C_NT_LOADS      // t0 is next read by C4's streaming load; s0 stays cached (the rows of B gather it)
+  __device__ Pre fetch(int r) const { return Pre{s0[r], __builtin_nontemporal_load(&t0[r])}; }
+#else
   __device__ Pre fetch(int r) const { return Pre{s0[r], t0[r]}; }
+#endif
   __device__ void row(int r, double at1, const Pre& p) {
     NSS_ST(t2[r], at1);
     acc = fma(p.s0, at1 - p.t0, acc);

@@ -137,6 +137,15 @@ struct MK4Args {
 
 constexpr int kMPerBlock = 2 * kBlock;     // one-shot element-wise launches: two elements per lane
 
+#ifndef NSS_MINRES_NT_LOADS
+#define NSS_MINRES_NT_LOADS 1
+#endif
+#if NSS_MINRES_NT_LOADS
+#define NSS_M_LD2 ld2_nt
+#else
+#define NSS_M_LD2 ld2
+#endif
+
 __device__ __forceinline__ double m3_delta(const MK4Args& a, double* lds) {
   if (!a.fold) return a.scal[M_DELTA];
   const double d = fixed_sum_1024(a.pa, a.na, a.pb, a.nb, lds);
@@ -161,11 +170,12 @@ __global__ __launch_bounds__(kBlock) void minres_m3_kernel(MK4Args a) {
   const bool fast = (BS == 0 || !velocity) && a.vec && i0 + 1 < n_part;
   double2 qkz{}, qv{}, qvo{}, qd{};
   if (fast) {
-    qkz = ld2((velocity ? a.kz0 : a.kz1) + i0);
-    qv = ld2((velocity ? a.v0 : a.v1) + i0);
-    qvo = ld2((velocity ? a.vo0 : a.vo1) + i0);
-    if (!velocity) qd = ld2(a.minv + i0);
-    else if (a.dinv) qd = ld2(a.dinv + i0);
+    // streaming loads: none of these is read again before it is rewritten or a full iteration has passed
+    qkz = NSS_M_LD2((velocity ? a.kz0 : a.kz1) + i0);
+    qv = NSS_M_LD2((velocity ? a.v0 : a.v1) + i0);
+    qvo = NSS_M_LD2((velocity ? a.vo0 : a.vo1) + i0);
+    if (!velocity) qd = NSS_M_LD2(a.minv + i0);
+    else if (a.dinv) qd = NSS_M_LD2(a.dinv + i0);
   }
   const int blk = wg * kBlock + int(threadIdx.x);        // BS > 0: one lane per block
   const bool live = BS > 0 && velocity && blk < a.nblocks;
@@ -300,10 +310,10 @@ __global__ __launch_bounds__(kBlock) void minres_m4_kernel(MK5Args a) {
   const bool fast = a.vec && i0 + 1 < (velocity ? a.n_u : a.n_p);
   double2 qw{}, qwo{}, qz{}, qu{};
   if (fast) {
-    qw = ld2((velocity ? a.w0 : a.w1) + i0);
-    qwo = ld2((velocity ? a.wo0 : a.wo1) + i0);
-    qz = ld2((velocity ? a.z0 : a.z1) + i0);
-    qu = ld2((velocity ? a.u0 : a.u1) + i0);
+    qw = NSS_M_LD2((velocity ? a.w0 : a.w1) + i0);       // (streaming loads, as in M3)
+    qwo = NSS_M_LD2((velocity ? a.wo0 : a.wo1) + i0);
+    qz = NSS_M_LD2((velocity ? a.z0 : a.z1) + i0);
+    qu = NSS_M_LD2((velocity ? a.u0 : a.u1) + i0);
   }
   const double g2 = a.fold ? fixed_sum_1024(a.pa, a.na, a.pb, a.nb, lds) : s[M_G2];
   const double delta = s[M_DELTA], gamma = s[M_GAMMA];

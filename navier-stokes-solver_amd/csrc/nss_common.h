@@ -120,6 +120,12 @@ __device__ __forceinline__ double mul_unfused(double a, double b) {
 }
 
 __device__ __forceinline__ double2 ld2(const double* p) { return *reinterpret_cast<const double2*>(p); }
+// streaming form: for operands that are not read again before they are rewritten (kept out of the XCD L2s,
+// which the SpMV kernels need for their operand windows)
+__device__ __forceinline__ double2 ld2_nt(const double* p) {
+  const dbl2v t = __builtin_nontemporal_load(reinterpret_cast<const dbl2v*>(p));
+  return double2{t.x, t.y};
+}
 __device__ __forceinline__ void st2(double* p, const double2& v) { *reinterpret_cast<double2*>(p) = v; }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

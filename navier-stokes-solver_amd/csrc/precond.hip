@@ -93,6 +93,10 @@ __global__ __launch_bounds__(kBlock) void bjac_pack_sym_kernel(int bs, int32_t n
   if (bad) atomicAdd(asym, 1);
 }
 
+#ifndef NSS_BJAC_NT
+#define NSS_BJAC_NT 1
+#endif
+
 // symmetric inverse blocks: every stored entry is read once and used for both triangles
 template <int BS>
 __global__ __launch_bounds__(kBlock) void bjac_apply_sym_kernel(int32_t nb, const int32_t* __restrict__ idx,
@@ -127,7 +131,11 @@ __global__ __launch_bounds__(kBlock) void bjac_apply_sym_kernel(int32_t nb, cons
     for (int r = 0; r < BS; ++r) {
 #pragma unroll
       for (int c = r; c < BS; ++c, ++t) {
+#if NSS_BJAC_NT
+        const double m = __builtin_nontemporal_load(&packed[size_t(t) * nb + b]);   // read exactly once per apply
+#else
         const double m = packed[size_t(t) * nb + b];
+#endif
         s[r] = fma(m, xv[c], s[r]);
         if (c > r) s[c] = fma(m, xv[r], s[c]);
       }
