@@ -18,6 +18,16 @@
 
 #include <algorithm>
 
+// streaming loads for operands that are not read again before they are rewritten (see bpcg2.hip)
+#ifndef NSS_BPCG1_NT_LOADS
+#define NSS_BPCG1_NT_LOADS 1
+#endif
+#if NSS_BPCG1_NT_LOADS
+#define NSS_V_LD(x) __builtin_nontemporal_load(&(x))
+#else
+#define NSS_V_LD(x) (x)
+#endif
+
 namespace nss {
 
 enum { P_RHO = 0, P_DSUM = 1, P_RHON = 2, P_ALPHA = 3, P_BETA = 4, P_ERR0 = 5, P_TOL = 6,
@@ -41,7 +51,7 @@ struct EpiV1b {
   double k;
   __device__ bool skip() const { return ctrl[PC_STOP] != 0; }
   struct Pre { double t1u = 0.0, dinv = 0.0; };
-  __device__ Pre fetch(int r) const { return Pre{t1u[r], dinv ? dinv[r] : 0.0}; }
+  __device__ Pre fetch(int r) const { return Pre{NSS_V_LD(t1u[r]), dinv ? NSS_V_LD(dinv[r]) : 0.0}; }
   __device__ void row(int r, double btp, const Pre& p) const {
     const double ku = p.t1u + btp;
     t1u[r] = -ku;
@@ -70,7 +80,7 @@ struct EpiV3 {  // y += A x ; partial <d, y>
   double acc = 0.0;
   __device__ bool skip() const { return ctrl[PC_STOP] != 0; }
   struct Pre { double y = 0.0, d = 0.0; };
-  __device__ Pre fetch(int r) const { return Pre{y[r], d[r]}; }
+  __device__ Pre fetch(int r) const { return Pre{NSS_V_LD(y[r]), d[r]}; }
   __device__ void row(int r, double ax, const Pre& p) {
     const double t = p.y + ax;
     y[r] = t;
@@ -92,7 +102,7 @@ struct EpiV5 {
   double acc = 0.0;
   __device__ bool skip() const { return ctrl[PC_STOP] != 0; }
   struct Pre { double minv = 0.0, ap = 0.0, rp = 0.0; };
-  __device__ Pre fetch(int r) const { return Pre{minv[r], ap[r], rp[r]}; }
+  __device__ Pre fetch(int r) const { return Pre{NSS_V_LD(minv[r]), NSS_V_LD(ap[r]), NSS_V_LD(rp[r])}; }
   __device__ void row(int r, double bau, const Pre& p) {
     const double t = p.minv * (bau - p.ap);
     t1p[r] = t;
@@ -103,15 +113,6 @@ struct EpiV5 {
     if (threadIdx.x == 0 && b >= 0) partials[b] = s;
   }
 };
-
-#ifndef NSS_BPCG1_NT_LOADS
-#define NSS_BPCG1_NT_LOADS 1
-#endif
-#if NSS_BPCG1_NT_LOADS
-#define NSS_V_LD(x) __builtin_nontemporal_load(&(x))
-#else
-#define NSS_V_LD(x) (x)
-#endif
 
 constexpr int kPSum = 1024;
 // which = 0: loop-top bookkeeping; 1: alpha from sum(pa)+sum(pb); 2: rho_new, beta;

@@ -53,6 +53,11 @@
 #ifndef NSS_K4_NT_LOADS
 #define NSS_K4_NT_LOADS 1
 #endif
+#if NSS_K1C_NT_LOADS
+#define NSS_LDS(a) __builtin_nontemporal_load(&(a))
+#else
+#define NSS_LDS(a) (a)
+#endif
 #ifndef NSS_K2C_NT_LOADS
 #define NSS_K2C_NT_LOADS 0      // t0 in the epilogue of the A rows: no difference measured
 #endif
@@ -95,15 +100,15 @@ struct EpiK1 {
   int it;
   __device__ bool skip() const { return ctrl[C_DONE] != 0; }
   __device__ void row(int r, double bts) const {
-    double qv = q[r];
+    double qv = NSS_LDS(q[r]);                       // streaming loads as in EpiK1c
     if (it != 0) {
       const double alpha = scal[S_ALPHA], beta = scal[S_BETA];
-      const double zo = z0[r], t2v = t2[r], so = s0[r];
-      if (ctrl[C_PENDING] == it) NSS_ST(u0[r], fma(alpha, so, u0[r]));   // deferred u += alpha s of iteration it - 1
+      const double zo = NSS_LDS(z0[r]), t2v = NSS_LDS(t2[r]), so = s0[r];
+      if (ctrl[C_PENDING] == it) NSS_ST(u0[r], fma(alpha, so, NSS_LDS(u0[r])));   // deferred u += alpha s of iteration it - 1
       qv = fma(-alpha, t2v, fma(beta, qv, zo));
       NSS_ST(z0[r], fma(-alpha, t2v, zo));
       NSS_ST(q[r], qv);
-      NSS_ST3(s0[r], fma(beta, so, w0[r]));
+      NSS_ST3(s0[r], fma(beta, so, NSS_LDS(w0[r])));
     }
     const double t = qv + bts;
     NSS_ST3(t0[r], t);

@@ -91,7 +91,8 @@ struct EpiMAccDot {  // y (+)= A (scale * x) ; partial <y, scale * z>
   using X = XScaledZ;
   __device__ X xop(const double* x) const { return X{x, sz}; }
   struct Pre { double y = 0.0, z = 0.0; };
-  __device__ Pre fetch(int r) const { return Pre{accumulate ? y[r] : 0.0, z[r]}; }   // (before the prologue)
+  // (before the prologue; y is rewritten by row(): streaming load)
+  __device__ Pre fetch(int r) const { return Pre{accumulate ? __builtin_nontemporal_load(&y[r]) : 0.0, z[r]}; }
   __device__ void row(int r, double ax, const Pre& p) {
     const double t = accumulate ? p.y + ax : ax;
     y[r] = t;
