@@ -11,6 +11,10 @@
 
 namespace nss {
 
+int g_stream_loads_mode = -1;
+int stream_loads_mode() { return g_stream_loads_mode; }
+
+
 static thread_local char g_error[1024] = "";
 
 void set_error(const char* fmt, ...) {
@@ -271,6 +275,13 @@ extern "C" {
 int nss_abi_version(void) { return NSS_ABI_VERSION; }
 
 const char* nss_last_error(void) { return g_error; }
+
+int nss_stream_loads_mode(int32_t mode) {
+  return guarded([&] {
+    NSS_REQUIRE(mode >= -1 && mode <= 1, "stream_loads_mode: -1 (automatic), 0 (never) or 1 (always)");
+    nss::g_stream_loads_mode = mode;
+  });
+}
 
 int nss_device_info(int32_t* cu_count, int64_t* hbm_bytes, int32_t* wavefront_size, char* name, int32_t name_cap) {
   return guarded([&] {

@@ -18,16 +18,6 @@
 
 #include <algorithm>
 
-// streaming loads for operands that are not read again before they are rewritten (see bpcg2.hip)
-#ifndef NSS_BPCG1_NT_LOADS
-#define NSS_BPCG1_NT_LOADS 1
-#endif
-#if NSS_BPCG1_NT_LOADS
-#define NSS_V_LD(x) __builtin_nontemporal_load(&(x))
-#else
-#define NSS_V_LD(x) (x)
-#endif
-
 namespace nss {
 
 enum { P_RHO = 0, P_DSUM = 1, P_RHON = 2, P_ALPHA = 3, P_BETA = 4, P_ERR0 = 5, P_TOL = 6,
@@ -51,7 +41,7 @@ struct EpiV1b {
   double k;
   __device__ bool skip() const { return ctrl[PC_STOP] != 0; }
   struct Pre { double t1u = 0.0, dinv = 0.0; };
-  __device__ Pre fetch(int r) const { return Pre{NSS_V_LD(t1u[r]), dinv ? NSS_V_LD(dinv[r]) : 0.0}; }
+  __device__ Pre fetch(int r) const { return Pre{t1u[r], dinv ? dinv[r] : 0.0}; }
   __device__ void row(int r, double btp, const Pre& p) const {
     const double ku = p.t1u + btp;
     t1u[r] = -ku;
@@ -80,7 +70,7 @@ struct EpiV3 {  // y += A x ; partial <d, y>
   double acc = 0.0;
   __device__ bool skip() const { return ctrl[PC_STOP] != 0; }
   struct Pre { double y = 0.0, d = 0.0; };
-  __device__ Pre fetch(int r) const { return Pre{NSS_V_LD(y[r]), d[r]}; }
+  __device__ Pre fetch(int r) const { return Pre{y[r], d[r]}; }
   __device__ void row(int r, double ax, const Pre& p) {
     const double t = p.y + ax;
     y[r] = t;
@@ -102,7 +92,7 @@ struct EpiV5 {
   double acc = 0.0;
   __device__ bool skip() const { return ctrl[PC_STOP] != 0; }
   struct Pre { double minv = 0.0, ap = 0.0, rp = 0.0; };
-  __device__ Pre fetch(int r) const { return Pre{NSS_V_LD(minv[r]), NSS_V_LD(ap[r]), NSS_V_LD(rp[r])}; }
+  __device__ Pre fetch(int r) const { return Pre{minv[r], ap[r], rp[r]}; }
   __device__ void row(int r, double bau, const Pre& p) {
     const double t = p.minv * (bau - p.ap);
     t1p[r] = t;
@@ -188,6 +178,7 @@ struct V4Args {
   double* partials;
 };
 
+template <bool NT>      // streaming loads of the operands that are not read again (stream_vector_loads, nss_common.h)
 __global__ __launch_bounds__(kBlock) void bpcg1_v4_kernel(V4Args a) {
   __shared__ double lds[kBlock / kWave];
   if (a.ctrl[PC_STOP] != 0) return;
@@ -197,22 +188,23 @@ __global__ __launch_bounds__(kBlock) void bpcg1_v4_kernel(V4Args a) {
   // streaming loads for what is not read again before it is rewritten or an iteration has passed (x, r, t1, t2,
   // a); d stays cached: V6 and the next iteration's SpMVs read it
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < a.n_u; i += stride) {
-    NSS_ST(a.xu[i], fma(alpha, a.du[i], NSS_V_LD(a.xu[i])));
-    const double rn = fma(-alpha, NSS_V_LD(a.t1u[i]), NSS_V_LD(a.ru[i]));
-    const double an = fma(-alpha, NSS_V_LD(a.t2u[i]), NSS_V_LD(a.au[i]));
+    NSS_ST(a.xu[i], fma(alpha, a.du[i], ld1s<NT>(&a.xu[i])));
+    const double rn = fma(-alpha, ld1s<NT>(&a.t1u[i]), ld1s<NT>(&a.ru[i]));
+    const double an = fma(-alpha, ld1s<NT>(&a.t2u[i]), ld1s<NT>(&a.au[i]));
     a.ru[i] = rn;
     a.au[i] = an;
     acc = fma(an, rn, acc);
   }
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < a.n_p; i += stride) {
-    NSS_ST(a.xp[i], fma(alpha, a.dp[i], NSS_V_LD(a.xp[i])));
-    a.rp[i] = fma(-alpha, NSS_V_LD(a.t1p[i]), NSS_V_LD(a.rp[i]));
-    a.ap[i] = fma(-alpha, NSS_V_LD(a.t2p[i]), NSS_V_LD(a.ap[i]));
+    NSS_ST(a.xp[i], fma(alpha, a.dp[i], ld1s<NT>(&a.xp[i])));
+    a.rp[i] = fma(-alpha, ld1s<NT>(&a.t1p[i]), ld1s<NT>(&a.rp[i]));
+    a.ap[i] = fma(-alpha, ld1s<NT>(&a.t2p[i]), ld1s<NT>(&a.ap[i]));
   }
   const double s = block_sum(acc, lds);
   if (threadIdx.x == 0) a.partials[blockIdx.x] = s;
 }
 
+template <bool NT>
 __global__ __launch_bounds__(kBlock) void bpcg1_v6_kernel(const int32_t* __restrict__ ctrl,
                                                            const double* __restrict__ scal, int32_t n_u, int32_t n_p,
                                                            double* __restrict__ du, double* __restrict__ dp,
@@ -221,8 +213,8 @@ __global__ __launch_bounds__(kBlock) void bpcg1_v6_kernel(const int32_t* __restr
   if (ctrl[PC_STOP] != 0) return;
   const double beta = scal[P_BETA];
   const int stride = gridDim.x * kBlock;
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n_u; i += stride) du[i] = fma(beta, NSS_V_LD(du[i]), NSS_V_LD(au[i]));
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n_p; i += stride) dp[i] = fma(beta, NSS_V_LD(dp[i]), NSS_V_LD(t1p[i]));
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n_u; i += stride) du[i] = fma(beta, ld1s<NT>(&du[i]), ld1s<NT>(&au[i]));
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n_p; i += stride) dp[i] = fma(beta, ld1s<NT>(&dp[i]), ld1s<NT>(&t1p[i]));
 }
 
 static int p_grid(const nss_bpcg1_t& s) { return stream_grid(int64_t(s.n_u) + s.n_p, kBlock * 4); }
@@ -309,7 +301,8 @@ static void bpcg1_iteration(const nss_bpcg1_t& s, int it, hipStream_t st, int fi
     if (s.local_sums) scalar_step(s, 3, it, kWave, 0, s.partials_a, 0, s.partials_b, st);
     V4Args a4{s.ctrl, s.scal, s.n_u, s.n_p, s.x[0], s.x[1], s.r[0], s.r[1], s.a[0], s.a[1],
               s.d[0], s.d[1], s.t1[0], s.t1[1], s.t2[0], s.t2[1], s.partials_c};
-    hipLaunchKernelGGL(bpcg1_v4_kernel, dim3(p_grid(s)), dim3(kBlock), 0, st, a4);
+    if (stream_vector_loads(s.n_u)) hipLaunchKernelGGL(bpcg1_v4_kernel<true>, dim3(p_grid(s)), dim3(kBlock), 0, st, a4);
+    else hipLaunchKernelGGL(bpcg1_v4_kernel<false>, dim3(p_grid(s)), dim3(kBlock), 0, st, a4);
     NSS_CHECK_LAUNCH();
   }
   if (on(4)) {
@@ -320,8 +313,12 @@ static void bpcg1_iteration(const nss_bpcg1_t& s, int it, hipStream_t st, int fi
   }
   if (on(5)) {
     if (s.local_sums) scalar_step(s, 4, it, kWave, 0, s.partials_a, 0, s.partials_b, st);
-    hipLaunchKernelGGL(bpcg1_v6_kernel, dim3(p_grid(s)), dim3(kBlock), 0, st, s.ctrl, s.scal, s.n_u, s.n_p, s.d[0],
-                       s.d[1], s.a[0], s.t1[1]);
+    if (stream_vector_loads(s.n_u))
+      hipLaunchKernelGGL(bpcg1_v6_kernel<true>, dim3(p_grid(s)), dim3(kBlock), 0, st, s.ctrl, s.scal, s.n_u, s.n_p, s.d[0],
+                         s.d[1], s.a[0], s.t1[1]);
+    else
+      hipLaunchKernelGGL(bpcg1_v6_kernel<false>, dim3(p_grid(s)), dim3(kBlock), 0, st, s.ctrl, s.scal, s.n_u, s.n_p, s.d[0],
+                         s.d[1], s.a[0], s.t1[1]);
     NSS_CHECK_LAUNCH();
   }
 }

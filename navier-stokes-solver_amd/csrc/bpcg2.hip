@@ -46,21 +46,9 @@
 // not displace the operand windows of the SpMV kernels from the 4-MiB XCD L2s.  Interleaved same-box A/B at 1e7
 // DoF (profiles/r02_ab_streaming_loads.txt): packed block-Jacobi inverses +2.3 % iterations/s, C1's q / z0 / t2 /
 // w0 / u0 +5.4 % (C23 gets 7 % faster: t1 and s0 are still in L2 when it stages them), C4's operands +3.6 %;
-// MINRES' element-wise kernels +8 % (minres.hip), BPCG v1's +1.4 % (bpcg1.hip).
-#ifndef NSS_K1C_NT_LOADS
-#define NSS_K1C_NT_LOADS 1
-#endif
-#ifndef NSS_K4_NT_LOADS
-#define NSS_K4_NT_LOADS 1
-#endif
-#if NSS_K1C_NT_LOADS
-#define NSS_LDS(a) __builtin_nontemporal_load(&(a))
-#else
-#define NSS_LDS(a) (a)
-#endif
-#ifndef NSS_K2C_NT_LOADS
-#define NSS_K2C_NT_LOADS 0      // t0 in the epilogue of the A rows: no difference measured
-#endif
+// MINRES' element-wise kernels +8 % (minres.hip), BPCG v1's +1.4 % (bpcg1.hip).  At 1e6 DoF, where the vectors
+// fit the caches, the same loads cost 5 %: the choice is a template parameter (NT) made per launch from the
+// vector length (stream_vector_loads, nss_common.h).
 
 namespace nss {
 
@@ -100,15 +88,15 @@ struct EpiK1 {
   int it;
   __device__ bool skip() const { return ctrl[C_DONE] != 0; }
   __device__ void row(int r, double bts) const {
-    double qv = NSS_LDS(q[r]);                       // streaming loads as in EpiK1c
+    double qv = q[r];
     if (it != 0) {
       const double alpha = scal[S_ALPHA], beta = scal[S_BETA];
-      const double zo = NSS_LDS(z0[r]), t2v = NSS_LDS(t2[r]), so = s0[r];
-      if (ctrl[C_PENDING] == it) NSS_ST(u0[r], fma(alpha, so, NSS_LDS(u0[r])));   // deferred u += alpha s of iteration it - 1
+      const double zo = z0[r], t2v = t2[r], so = s0[r];
+      if (ctrl[C_PENDING] == it) NSS_ST(u0[r], fma(alpha, so, u0[r]));   // deferred u += alpha s of iteration it - 1
       qv = fma(-alpha, t2v, fma(beta, qv, zo));
       NSS_ST(z0[r], fma(-alpha, t2v, zo));
       NSS_ST(q[r], qv);
-      NSS_ST3(s0[r], fma(beta, so, NSS_LDS(w0[r])));
+      NSS_ST3(s0[r], fma(beta, so, w0[r]));
     }
     const double t = qv + bts;
     NSS_ST3(t0[r], t);
@@ -267,7 +255,7 @@ struct K4Args {
 // 5.5 TB/s for <= 2048 striding workgroups).
 constexpr int kK4PerBlock = 2 * kBlock;
 
-template <bool VEC2, bool FOLD>
+template <bool VEC2, bool FOLD, bool NT>
 __global__ __launch_bounds__(kBlock) void bpcg2_k4_kernel(K4Args a) {
   __shared__ double lds[kRedDoubles];
   if (a.ctrl[C_DONE] != 0) return;
@@ -277,28 +265,22 @@ __global__ __launch_bounds__(kBlock) void bpcg2_k4_kernel(K4Args a) {
   double2 q0{}, q1{}, q2{}, q3{}, q4{}, q5{};
   const bool vec_u = VEC2 && wg0 < a.gu && e0 + 1 < a.n_u;
   const bool vec_p = VEC2 && wg0 >= a.gu && wg0 < a.gu + a.gp && e0 + 1 < a.n_p;
-  // streaming loads for everything that is dead or rewritten after this kernel (t0, t1, t3, d, u1) or next read
-  // by a streaming load itself (t2, w0); s1 and w1 stay cached: the rows of B^T gather them next
-#if NSS_K4_NT_LOADS
-#define NSS_LD2S ld2_nt
-#else
-#define NSS_LD2S ld2
-#endif
+  // NT: streaming loads for everything that is dead or rewritten after this kernel (t0, t1, t3, d, u1) or next
+  // read by a streaming load itself (t2, w0); s1 and w1 stay cached: the rows of B^T gather them next
   if (vec_u) {
-    q0 = NSS_LD2S(a.t0 + e0);
-    q1 = NSS_LD2S(a.t1 + e0);
-    q2 = NSS_LD2S(a.t2 + e0);
-    q3 = NSS_LD2S(a.d0 + e0);
-    q4 = NSS_LD2S(a.w0 + e0);
+    q0 = ld2s<NT>(a.t0 + e0);
+    q1 = ld2s<NT>(a.t1 + e0);
+    q2 = ld2s<NT>(a.t2 + e0);
+    q3 = ld2s<NT>(a.d0 + e0);
+    q4 = ld2s<NT>(a.w0 + e0);
   } else if (vec_p) {
     q0 = ld2(a.s1 + e0);
-    q1 = NSS_LD2S(a.t3 + e0);
-    q2 = NSS_LD2S(a.minv + e0);
-    q3 = NSS_LD2S(a.u1 + e0);
-    q4 = NSS_LD2S(a.d1 + e0);
+    q1 = ld2s<NT>(a.t3 + e0);
+    q2 = ld2s<NT>(a.minv + e0);
+    q3 = ld2s<NT>(a.u1 + e0);
+    q4 = ld2s<NT>(a.d1 + e0);
     q5 = ld2(a.w1 + e0);
   }
-#undef NSS_LD2S
   // alpha = wd / <s, K^ s> (:226), evaluated by every lane from the (all-)reduced sum.
   // <s, K^ s> == 0: the reference raises ZeroDivisionError in Python; freeze the state and report
   // it (ctrl[3]) so that the host can raise the same error.
@@ -486,7 +468,7 @@ __global__ __launch_bounds__(kBlock) void bpcg2_close_kernel(CloseArgs a) {
 // C1: K1 with the books of the previous iteration in front and the operand beta * s1 + w1 on the fly.
 // FOLD (short sums) is a template parameter: the registers of the in-kernel sum must not cost the
 // bandwidth-bound large systems their occupancy.
-template <bool FOLD>
+template <bool FOLD, bool NT = false>
 struct EpiK1c {
   CloseArgs cl;
   double* __restrict__ u0;
@@ -538,16 +520,10 @@ struct EpiK1c {
 #else
   struct PreLate { double q, z0, t2, s0, w0, u0; };
   __device__ void row(int r, double bts) const {
-    // q, z0, t2, w0, u0 are read here and nowhere else before they are rewritten: streaming loads keep them
-    // out of the XCD L2s (s0 stays: the rows of A and B read it next)
-#if NSS_K1C_NT_LOADS
-#define NSS_LDS1(a) __builtin_nontemporal_load(&(a))
-#else
-#define NSS_LDS1(a) (a)
-#endif
-    const PreLate p{NSS_LDS1(q[r]), it ? NSS_LDS1(z0[r]) : 0.0, it ? NSS_LDS1(t2[r]) : 0.0, it ? s0[r] : 0.0,
-                    it ? NSS_LDS1(w0[r]) : 0.0, (it && pending) ? NSS_LDS1(u0[r]) : 0.0};
-#undef NSS_LDS1
+    // NT: q, z0, t2, w0, u0 are read here and nowhere else before they are rewritten -- streaming loads keep
+    // them out of the XCD L2s (s0 stays: the rows of A and B read it next)
+    const PreLate p{ld1s<NT>(q + r), it ? ld1s<NT>(z0 + r) : 0.0, it ? ld1s<NT>(t2 + r) : 0.0, it ? s0[r] : 0.0,
+                    it ? ld1s<NT>(w0 + r) : 0.0, (it && pending) ? ld1s<NT>(u0 + r) : 0.0};
 #endif
     double qv = p.q;
     if (it != 0) {
@@ -575,11 +551,7 @@ struct EpiK2c {
   double acc = 0.0;
   __device__ bool skip() const { return ctrl[C_DONE] != 0; }
   struct Pre { double s0 = 0.0, t0 = 0.0; };
-#if NSS_K2C_NT_LOADS      // t0 is next read by C4's streaming load; s0 stays cached (the rows of B gather it)
-  __device__ Pre fetch(int r) const { return Pre{s0[r], __builtin_nontemporal_load(&t0[r])}; }
-#else
-  __device__ Pre fetch(int r) const { return Pre{s0[r], t0[r]}; }
-#endif
+  __device__ Pre fetch(int r) const { return Pre{s0[r], t0[r]}; }   // (t0 as a streaming load: no difference measured)
   __device__ void row(int r, double at1, const Pre& p) {
     NSS_ST(t2[r], at1);
     acc = fma(p.s0, at1 - p.t0, acc);
@@ -664,10 +636,13 @@ static void launch_k4(const nss_bpcg2_t& s, int it, bool fold, hipStream_t st) {
                         (const void*)s.s1, (const void*)s.t0, (const void*)s.t1, (const void*)s.t2, (const void*)s.t3,
                         (const void*)s.minv})
     vec = vec && aligned16(p);
-  if (vec && fold) hipLaunchKernelGGL((bpcg2_k4_kernel<true, true>), dim3(grid), dim3(kBlock), 0, st, a);
-  else if (vec) hipLaunchKernelGGL((bpcg2_k4_kernel<true, false>), dim3(grid), dim3(kBlock), 0, st, a);
-  else if (fold) hipLaunchKernelGGL((bpcg2_k4_kernel<false, true>), dim3(grid), dim3(kBlock), 0, st, a);
-  else hipLaunchKernelGGL((bpcg2_k4_kernel<false, false>), dim3(grid), dim3(kBlock), 0, st, a);
+  const bool nt = vec && stream_vector_loads(s.n_u);
+  if (vec && fold && nt) hipLaunchKernelGGL((bpcg2_k4_kernel<true, true, true>), dim3(grid), dim3(kBlock), 0, st, a);
+  else if (vec && fold) hipLaunchKernelGGL((bpcg2_k4_kernel<true, true, false>), dim3(grid), dim3(kBlock), 0, st, a);
+  else if (vec && nt) hipLaunchKernelGGL((bpcg2_k4_kernel<true, false, true>), dim3(grid), dim3(kBlock), 0, st, a);
+  else if (vec) hipLaunchKernelGGL((bpcg2_k4_kernel<true, false, false>), dim3(grid), dim3(kBlock), 0, st, a);
+  else if (fold) hipLaunchKernelGGL((bpcg2_k4_kernel<false, true, false>), dim3(grid), dim3(kBlock), 0, st, a);
+  else hipLaunchKernelGGL((bpcg2_k4_kernel<false, false, false>), dim3(grid), dim3(kBlock), 0, st, a);
   NSS_CHECK_LAUNCH();
 }
 
@@ -821,12 +796,17 @@ void bpcg2_cphase(const nss_bpcg2_t& s, int which, int it, hipStream_t st) {
   switch (which) {
     case NSS_BPCG2C_C1: {
       const double* dinv = (s.pre_amg || s.pre_dist_amg || s.cond_HT) ? nullptr : s.pre_diag;
-      if (fold)
-        launch_csr_stream(*s.BT, s.s1, EpiK1c<true>{close_args(s, true), s.u0, s.q, s.z0, s.t2, s.s0, s.w0, s.t0, s.t1,
-                                                    dinv, s.k, it, s.s1, s.w1}, st);
-      else
-        launch_csr_stream(*s.BT, s.s1, EpiK1c<false>{close_args(s, false), s.u0, s.q, s.z0, s.t2, s.s0, s.w0, s.t0, s.t1,
-                                                     dinv, s.k, it, s.s1, s.w1}, st);
+      // (streaming operand loads only where B^T takes the row-per-lane kernel: that is the large-system regime,
+      // and the stream-kernel instantiations of the epilogue are not doubled)
+      const bool nt = s.BT->ell_col != nullptr && stream_vector_loads(s.n_u);
+#define NSS_C1(FOLD, NT, LAUNCH)                                                                                       \
+  LAUNCH(*s.BT, s.s1, EpiK1c<FOLD, NT>{close_args(s, FOLD), s.u0, s.q, s.z0, s.t2, s.s0, s.w0, s.t0, s.t1, dinv, s.k, it, \
+                                       s.s1, s.w1}, st)
+      if (nt && fold) NSS_C1(true, true, launch_csr_direct);
+      else if (nt) NSS_C1(false, true, launch_csr_direct);
+      else if (fold) NSS_C1(true, false, launch_csr_stream);
+      else NSS_C1(false, false, launch_csr_stream);
+#undef NSS_C1
       bpcg2_k1_finish(s, st);
       break;
     }

@@ -575,6 +575,18 @@ __global__ __launch_bounds__(kBlock) void csr_direct_kernel(CsrView a, const int
     }                                                                                              \
   }
 
+// the row-per-lane kernel alone (A must hold the fixed-width copy): for epilogue variants that only exist for it
+template <class Epi>
+inline void launch_csr_direct(const nss_csr_s& A, const double* x, const Epi& epi, hipStream_t st, int b0 = 0,
+                              int b1 = -1) {
+  if (b1 < 0) b1 = A.nblk;
+  if (A.m == 0 || b1 <= b0) return;
+  if (!A.ell_col) throw Error("csr_direct: the matrix has no fixed-width copy");
+  hipLaunchKernelGGL((csr_direct_kernel<Epi>), dim3(nss_csr_s::grid(b1 - b0)), dim3(kBlock), 0, st, A.view(b0, b1, 0),
+                     A.ell_col, A.ell_val, x, epi);
+  NSS_CHECK_LAUNCH();
+}
+
 // rows of the row blocks [b0, b1) (default: all)
 template <class Epi>
 inline void launch_csr_stream(const nss_csr_s& A, const double* x, const Epi& epi, hipStream_t st, int b0 = 0,
@@ -582,9 +594,7 @@ inline void launch_csr_stream(const nss_csr_s& A, const double* x, const Epi& ep
   if (b1 < 0) b1 = A.nblk;
   if (A.m == 0 || b1 <= b0) return;
   if (A.ell_col) {
-    hipLaunchKernelGGL((csr_direct_kernel<Epi>), dim3(nss_csr_s::grid(b1 - b0)), dim3(kBlock), 0, st, A.view(b0, b1, 0),
-                       A.ell_col, A.ell_val, x, epi);
-    NSS_CHECK_LAUNCH();
+    launch_csr_direct(A, x, epi, st, b0, b1);
     return;
   }
   constexpr bool kCanStage = EpiX<Epi>::type::kStageable;

@@ -91,8 +91,7 @@ struct EpiMAccDot {  // y (+)= A (scale * x) ; partial <y, scale * z>
   using X = XScaledZ;
   __device__ X xop(const double* x) const { return X{x, sz}; }
   struct Pre { double y = 0.0, z = 0.0; };
-  // (before the prologue; y is rewritten by row(): streaming load)
-  __device__ Pre fetch(int r) const { return Pre{accumulate ? __builtin_nontemporal_load(&y[r]) : 0.0, z[r]}; }
+  __device__ Pre fetch(int r) const { return Pre{accumulate ? y[r] : 0.0, z[r]}; }   // (before the prologue)
   __device__ void row(int r, double ax, const Pre& p) {
     const double t = accumulate ? p.y + ax : ax;
     y[r] = t;
@@ -138,14 +137,7 @@ struct MK4Args {
 
 constexpr int kMPerBlock = 2 * kBlock;     // one-shot element-wise launches: two elements per lane
 
-#ifndef NSS_MINRES_NT_LOADS
-#define NSS_MINRES_NT_LOADS 1
-#endif
-#if NSS_MINRES_NT_LOADS
-#define NSS_M_LD2 ld2_nt
-#else
-#define NSS_M_LD2 ld2
-#endif
+// (NT = streaming loads of the element-wise operands: see stream_vector_loads, nss_common.h)
 
 __device__ __forceinline__ double m3_delta(const MK4Args& a, double* lds) {
   if (!a.fold) return a.scal[M_DELTA];
@@ -157,7 +149,7 @@ __device__ __forceinline__ double m3_delta(const MK4Args& a, double* lds) {
 // BS == 0: the velocity part is element-wise (point Jacobi when a.dinv, else v_new only);
 // BS > 0: one lane per block of <= BS consecutive dofs, z_new0 = J v_new0 from the packed symmetric
 // inverse blocks (the arithmetic of bjac_apply_sym_kernel)
-template <int BS>
+template <int BS, bool NT>
 __global__ __launch_bounds__(kBlock) void minres_m3_kernel(MK4Args a) {
   __shared__ double lds[kRedDoubles];
   if (minres_skip(a.ctrl, a.k)) return;
@@ -172,11 +164,11 @@ __global__ __launch_bounds__(kBlock) void minres_m3_kernel(MK4Args a) {
   double2 qkz{}, qv{}, qvo{}, qd{};
   if (fast) {
     // streaming loads: none of these is read again before it is rewritten or a full iteration has passed
-    qkz = NSS_M_LD2((velocity ? a.kz0 : a.kz1) + i0);
-    qv = NSS_M_LD2((velocity ? a.v0 : a.v1) + i0);
-    qvo = NSS_M_LD2((velocity ? a.vo0 : a.vo1) + i0);
-    if (!velocity) qd = NSS_M_LD2(a.minv + i0);
-    else if (a.dinv) qd = NSS_M_LD2(a.dinv + i0);
+    qkz = ld2s<NT>((velocity ? a.kz0 : a.kz1) + i0);
+    qv = ld2s<NT>((velocity ? a.v0 : a.v1) + i0);
+    qvo = ld2s<NT>((velocity ? a.vo0 : a.vo1) + i0);
+    if (!velocity) qd = ld2s<NT>(a.minv + i0);
+    else if (a.dinv) qd = ld2s<NT>(a.dinv + i0);
   }
   const int blk = wg * kBlock + int(threadIdx.x);        // BS > 0: one lane per block
   const bool live = BS > 0 && velocity && blk < a.nblocks;
@@ -299,6 +291,7 @@ __device__ __forceinline__ void minres_k5_body(int i, double sz, double a1inv, d
   NSS_ST(u[i], fma(uc, t, u[i]));                     // :118
 }
 
+template <bool NT>
 __global__ __launch_bounds__(kBlock) void minres_m4_kernel(MK5Args a) {
   __shared__ double lds[kRedDoubles];
   if (minres_skip(a.ctrl, a.k)) return;
@@ -311,10 +304,10 @@ __global__ __launch_bounds__(kBlock) void minres_m4_kernel(MK5Args a) {
   const bool fast = a.vec && i0 + 1 < (velocity ? a.n_u : a.n_p);
   double2 qw{}, qwo{}, qz{}, qu{};
   if (fast) {
-    qw = NSS_M_LD2((velocity ? a.w0 : a.w1) + i0);       // (streaming loads, as in M3)
-    qwo = NSS_M_LD2((velocity ? a.wo0 : a.wo1) + i0);
-    qz = NSS_M_LD2((velocity ? a.z0 : a.z1) + i0);
-    qu = NSS_M_LD2((velocity ? a.u0 : a.u1) + i0);
+    qw = ld2s<NT>((velocity ? a.w0 : a.w1) + i0);       // (streaming loads, as in M3)
+    qwo = ld2s<NT>((velocity ? a.wo0 : a.wo1) + i0);
+    qz = ld2s<NT>((velocity ? a.z0 : a.z1) + i0);
+    qu = ld2s<NT>((velocity ? a.u0 : a.u1) + i0);
   }
   const double g2 = a.fold ? fixed_sum_1024(a.pa, a.na, a.pb, a.nb, lds) : s[M_G2];
   const double delta = s[M_DELTA], gamma = s[M_GAMMA];
@@ -434,7 +427,8 @@ static void minres_check(const nss_minres_t* s) {
 
 template <int BS>
 static void launch_m3(const MK4Args& a, int grid, hipStream_t st) {
-  hipLaunchKernelGGL((minres_m3_kernel<BS>), dim3(grid), dim3(kBlock), 0, st, a);
+  if (BS == 0 && stream_vector_loads(a.n_u)) hipLaunchKernelGGL((minres_m3_kernel<BS, true>), dim3(grid), dim3(kBlock), 0, st, a);
+  else hipLaunchKernelGGL((minres_m3_kernel<BS, false>), dim3(grid), dim3(kBlock), 0, st, a);
 }
 
 // phases of one iteration (nss_minres_phases; the row-partitioned schedules all-reduce between them):
@@ -539,7 +533,8 @@ static void minres_iteration(const nss_minres_t& s, int k, hipStream_t st, int f
   MK5Args a5{s.ctrl, s.scal, s.hist, s.n_u, s.n_p, k, s.z[zn][0], s.z[zn][1], s.v[in][0], s.v[in][1], s.w[in][0],
              s.w[in][1], s.u[0], s.u[1], s.z[zc][0], s.z[zc][1], s.w[io][0], s.w[io][1], s.w[ic][0], s.w[ic][1],
              m_gu(s), fold ? 1 : 0, nb2, g3, s.partials_a, s.partials_c, vec ? 1 : 0};
-  hipLaunchKernelGGL(minres_m4_kernel, dim3(m_gu(s) + m_gp(s)), dim3(kBlock), 0, st, a5);
+  if (stream_vector_loads(s.n_u)) hipLaunchKernelGGL(minres_m4_kernel<true>, dim3(m_gu(s) + m_gp(s)), dim3(kBlock), 0, st, a5);
+  else hipLaunchKernelGGL(minres_m4_kernel<false>, dim3(m_gu(s) + m_gp(s)), dim3(kBlock), 0, st, a5);
   NSS_CHECK_LAUNCH();
 }
 

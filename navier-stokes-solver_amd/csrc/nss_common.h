@@ -128,6 +128,29 @@ __device__ __forceinline__ double2 ld2_nt(const double* p) {
 }
 __device__ __forceinline__ void st2(double* p, const double2& v) { *reinterpret_cast<double2*>(p) = v; }
 
+// Streaming (non-temporal) loads of vector operands that are not read again before they are rewritten pay when
+// the vectors do not fit the caches anyway (1e7 DoF: BPCG v2 +11 %, MINRES +8 %) and cost where they do (1e6 DoF,
+// 6-MB vectors: -5 %): the element-wise kernels take the choice as a template parameter, made per launch from the
+// vector length.  Measured crossover between 2.5e6 and 5e6 DoF (profiles/r02_size_sweep.md, r02_ab_streaming_loads.txt).
+#ifndef NSS_STREAM_LOADS_MIN_BYTES
+#define NSS_STREAM_LOADS_MIN_BYTES (24u << 20)
+#endif
+int stream_loads_mode();                      // -1 automatic, 0 never, 1 always (nss_stream_loads_mode)
+inline bool stream_vector_loads(int64_t n) {
+  const int mode = stream_loads_mode();
+  return mode < 0 ? n * int64_t(sizeof(double)) >= int64_t(NSS_STREAM_LOADS_MIN_BYTES) : mode != 0;
+}
+template <bool NT>
+__device__ __forceinline__ double ld1s(const double* p) {
+  if constexpr (NT) return __builtin_nontemporal_load(p);
+  else return *p;
+}
+template <bool NT>
+__device__ __forceinline__ double2 ld2s(const double* p) {
+  if constexpr (NT) return ld2_nt(p);
+  else return ld2(p);
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // ---- device-side reductions -------------------------------------------------------

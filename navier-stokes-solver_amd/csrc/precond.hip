@@ -93,12 +93,9 @@ __global__ __launch_bounds__(kBlock) void bjac_pack_sym_kernel(int bs, int32_t n
   if (bad) atomicAdd(asym, 1);
 }
 
-#ifndef NSS_BJAC_NT
-#define NSS_BJAC_NT 1
-#endif
-
-// symmetric inverse blocks: every stored entry is read once and used for both triangles
-template <int BS>
+// symmetric inverse blocks: every stored entry is read once and used for both triangles (NT: with a streaming
+// load -- stream_vector_loads, nss_common.h)
+template <int BS, bool NT>
 __global__ __launch_bounds__(kBlock) void bjac_apply_sym_kernel(int32_t nb, const int32_t* __restrict__ idx,
                                                                  const int32_t* __restrict__ run,
                                                                  const double* __restrict__ packed, double alpha,
@@ -131,11 +128,7 @@ __global__ __launch_bounds__(kBlock) void bjac_apply_sym_kernel(int32_t nb, cons
     for (int r = 0; r < BS; ++r) {
 #pragma unroll
       for (int c = r; c < BS; ++c, ++t) {
-#if NSS_BJAC_NT
-        const double m = __builtin_nontemporal_load(&packed[size_t(t) * nb + b]);   // read exactly once per apply
-#else
-        const double m = packed[size_t(t) * nb + b];
-#endif
+        const double m = ld1s<NT>(&packed[size_t(t) * nb + b]);
         s[r] = fma(m, xv[c], s[r]);
         if (c > r) s[c] = fma(m, xv[r], s[c]);
       }
@@ -287,8 +280,11 @@ template <int BS>
 static void launch_bjac(const nss_bjac_s& j, double alpha, const double* x, double beta, double* y,
                         const int32_t* done, double* partials, hipStream_t st) {
   const int grid = bjac_dot_grid(j);
-  if (j.inv_sym)
-    hipLaunchKernelGGL((bjac_apply_sym_kernel<BS>), dim3(grid), dim3(kBlock), 0, st, j.nblocks, j.idx, j.run,
+  if (j.inv_sym && stream_vector_loads(j.n))
+    hipLaunchKernelGGL((bjac_apply_sym_kernel<BS, true>), dim3(grid), dim3(kBlock), 0, st, j.nblocks, j.idx, j.run,
+                       j.inv_sym, alpha, x, beta, y, done, partials);
+  else if (j.inv_sym)
+    hipLaunchKernelGGL((bjac_apply_sym_kernel<BS, false>), dim3(grid), dim3(kBlock), 0, st, j.nblocks, j.idx, j.run,
                        j.inv_sym, alpha, x, beta, y, done, partials);
   else
     hipLaunchKernelGGL((bjac_apply_kernel<BS>), dim3(grid), dim3(kBlock), 0, st, j.nblocks, j.idx, j.inv, alpha, x,

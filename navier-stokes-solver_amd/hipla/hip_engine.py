@@ -50,6 +50,7 @@ def _signatures():
         "nss_csr_operand_form": (C.c_int, [vp, c_i32_p]),
         "nss_csr_direct_rows_threshold": (C.c_int, [i64]),
         "nss_scratch_trim": (C.c_int, []),
+        "nss_stream_loads_mode": (C.c_int, [i32]),
         "nss_csr_ones_like": (C.c_int, [vp, C.POINTER(vp), vp]),
         "nss_graph_color": (C.c_int, [vp, vp, vp, vp, c_i32_p, vp]),
         "nss_csr_select_rows": (C.c_int, [vp, i32, vp, i32, vp, C.POINTER(vp), vp]),
@@ -129,6 +130,8 @@ def load_library(path=None):
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
+    if os.environ.get("NSS_STREAM_LOADS") and hasattr(lib, "nss_stream_loads_mode"):     # measurements: -1 / 0 / 1
+        lib.nss_stream_loads_mode(int(os.environ["NSS_STREAM_LOADS"]))
     return lib
 
 

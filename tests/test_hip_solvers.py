@@ -401,6 +401,57 @@ def test_fused_bpcg2_frozen_at_break_and_maxsteps_warning(hip_engine):
 
 
 @pytest.mark.parametrize("name", ["stokes3d_n10_bjac", "stokes2d_n24_jacobi"])
+def test_streaming_loads_do_not_change_a_bit(hip_engine, name):
+    """The element-wise kernels of the three fused loops load the vector operands they do not read again with
+    streaming (non-temporal) loads from 24 MB per vector on -- a cache policy, chosen per launch
+    (nss_stream_loads_mode: automatic / never / always).  Forced on and off here (with the row-per-lane kernel for
+    B^T, which carries the streaming variant of C1): identical histories and solutions."""
+    import hipla
+    from bramble_pasciak_cg import bramble_pasciak_cg
+    from minres import MinRes
+    from solvers.bramblepasciak_new import BramblePasciakCG
+    lib = hip_engine.lib
+    results = {}
+    assert lib.nss_csr_direct_rows_threshold(0) == 0
+    try:
+        for mode in (0, 1):
+            assert lib.nss_stream_loads_mode(mode) == 0
+            for solver in ("bpcg2", "bpcg1", "minres"):
+                d = np.load(golden_path("%s_%s" % (name, solver)))
+                c, blfA, A, B, preA, preS = case_operands(d)
+                s = c.system
+                fv, gv = hipla.Vector.from_numpy(c.f), hipla.Vector.from_numpy(c.g)
+                out = io.StringIO()
+                with fused_loops_counted() as counts, contextlib.redirect_stdout(out):
+                    if solver == "bpcg2":
+                        sol = hipla.BlockVector([hipla.Vector(s.n_u), hipla.Vector(s.n_p)])
+                        BramblePasciakCG(blfA, Form(B), None, fv, gv, preA, preS, sol, tol=float(d["tol"]),
+                                         maxsteps=int(d["maxsteps"]), printrates=True)
+                        hist = np.array([float(m) for m in re.findall(r"it =\s+\d+\s+err =\s+(\S+)", out.getvalue())])
+                        x = sol.numpy()
+                    elif solver == "bpcg1":
+                        sol, errors = bramble_pasciak_cg(A, B, None, preA, preS, fv, gv, tolerance=float(d["tol"]),
+                                                         max_steps=int(d["maxsteps"]), print_rates=False)
+                        hist, x = np.array(errors), sol.numpy()
+                    else:
+                        K = hipla.BlockMatrix([[A, B.T], [B, None]])
+                        Cm = hipla.BlockMatrix([[preA, None], [None, preS]])
+                        u, errors = MinRes(mat=K, pre=Cm, rhs=hipla.BlockVector([fv, gv]), maxsteps=int(d["maxsteps"]),
+                                           tol=float(d["tol"]), printrates=False)
+                        hist, x = np.array(errors), u.numpy()
+                assert counts[solver] == 1
+                check = d["history"] if solver == "bpcg2" else d["errors"]
+                check_history(hist, check, d["window"])
+                results[mode, solver] = (hist, x)
+    finally:
+        lib.nss_stream_loads_mode(-1)
+        lib.nss_csr_direct_rows_threshold(-1)
+    for solver in ("bpcg2", "bpcg1", "minres"):
+        np.testing.assert_array_equal(results[1, solver][0], results[0, solver][0])
+        np.testing.assert_array_equal(results[1, solver][1], results[0, solver][1])
+
+
+@pytest.mark.parametrize("name", ["stokes3d_n10_bjac", "stokes2d_n24_jacobi"])
 def test_row_per_lane_kernel_in_the_fused_loops(hip_engine, name):
     """B^T (two entries per row) multiplied by the row-per-lane kernel from its fixed-width copy instead of by the
     stream kernel (csr_direct_kernel; automatic from 2^21 rows on, forced here): the three fused loops produce the
