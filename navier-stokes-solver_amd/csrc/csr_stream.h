@@ -477,23 +477,35 @@ __global__ __launch_bounds__(kBlock) void csr_stream_kernel(CsrView a, const dou
   csr_stream_body<RG, Epi, IDX, CH, GRP>(a, x, epi, int(blockIdx.x), prod, red, window);
 }
 
-// Two matrices with the same launch-plan parameters in ONE launch: workgroups [0, grid_a) stream the
-// row blocks of `a` with `ea`, the rest those of `b` with `eb` -- two SpMVs that do not depend on each
-// other (the fused BPCG iteration: t2 = A t1 and t3 = B (t1 - s0)) share a kernel boundary.  The two halves
-// may use different column streams (IDXA / IDXB).
+// Two matrices with the same launch-plan parameters in ONE launch: two SpMVs that do not depend on each other
+// (the fused BPCG iteration: t2 = A t1 and t3 = B (t1 - s0)) share a kernel boundary.  The two halves may use
+// different column streams (IDXA / IDXB).  The workgroups of the SECOND matrix come first in the grid
+// (`grid_b` of them, then those of the first): in every use it is the smaller one with the less regular
+// operand access (B: gathers over three grid planes), and at the end of the grid its few, slow workgroups
+// would be the tail of the launch while the chip drains -- in front they overlap the long uniform stream of A.
+#ifndef NSS_DUAL_SECOND_FIRST
+#define NSS_DUAL_SECOND_FIRST 1
+#endif
 template <int RG, class EpiA, class EpiB, int IDXA, int IDXB, int CH, bool GRP>
-__global__ __launch_bounds__(kBlock) void csr_stream_dual_kernel(CsrView a, CsrView b, int grid_a,
+__global__ __launch_bounds__(kBlock) void csr_stream_dual_kernel(CsrView a, CsrView b, int grid_a, int grid_b,
                                                                   const double* __restrict__ xa,
                                                                   const double* __restrict__ xb, EpiA ea, EpiB eb) {
   __shared__ double prod[CH];
   __shared__ double red[kRedDoubles];
   __shared__ int32_t window[kWindows];
-  if (int(blockIdx.x) < grid_a) {
+#if NSS_DUAL_SECOND_FIRST
+  const bool first = int(blockIdx.x) >= grid_b;
+  const int wg = first ? int(blockIdx.x) - grid_b : int(blockIdx.x);
+#else
+  const bool first = int(blockIdx.x) < grid_a;
+  const int wg = first ? int(blockIdx.x) : int(blockIdx.x) - grid_a;
+#endif
+  if (first) {
     if (ea.skip()) return;
-    csr_stream_body<RG, EpiA, IDXA, CH, (GRP && IDXA != 0)>(a, xa, ea, int(blockIdx.x), prod, red, window);
+    csr_stream_body<RG, EpiA, IDXA, CH, (GRP && IDXA != 0)>(a, xa, ea, wg, prod, red, window);
   } else {
     if (eb.skip()) return;
-    csr_stream_body<RG, EpiB, IDXB, CH, (GRP && IDXB != 0)>(b, xb, eb, int(blockIdx.x) - grid_a, prod, red, window);
+    csr_stream_body<RG, EpiB, IDXB, CH, (GRP && IDXB != 0)>(b, xb, eb, wg, prod, red, window);
   }
 }
 
@@ -638,7 +650,7 @@ inline bool launch_csr_stream_dual(const nss_csr_s& A, const double* xa, const E
   const int ga = nss_csr_s::grid(A.nblk), gb = nss_csr_s::grid(B.nblk);
   const dim3 grid(ga + gb), block(kBlock);
 #define NSS_DUAL_GO(N, CHK, IA, IB, G) \
-  hipLaunchKernelGGL((csr_stream_dual_kernel<N, EpiA, EpiB, IA, IB, CHK, G>), grid, block, 0, st, va, vb, ga, xa, xb, ea, eb)
+  hipLaunchKernelGGL((csr_stream_dual_kernel<N, EpiA, EpiB, IA, IB, CHK, G>), grid, block, 0, st, va, vb, ga, gb, xa, xb, ea, eb)
 #define NSS_DUAL_PAIR(N, CHK, IA, IB) \
   if (grp) NSS_DUAL_GO(N, CHK, IA, IB, true); else NSS_DUAL_GO(N, CHK, IA, IB, false);
 #define NSS_LAUNCH_DUAL_ONE(N, CHK)                                                        \
