@@ -51,14 +51,10 @@ namespace nss {
 #define NSS_CHUNK 2048
 #endif
 constexpr int kChunk = NSS_CHUNK;       // products staged per workgroup: 16 KiB of LDS
-// Matrices with long rows (mean >= kLongRowMean non-zeros) stage twice as many: a row block then
-// holds enough rows to keep the phase-2 lanes busy and 16 loads per lane are in flight (K2 +5 % at
-// 82 non-zeros per row, +1.5 % at 34); short-row matrices lose occupancy to the 32 KiB and stay at kChunk.
-constexpr int kChunkLong = 2 * kChunk;
-#ifndef NSS_LONG_ROW_MEAN
-#define NSS_LONG_ROW_MEAN 32
-#endif
-constexpr int kLongRowMean = NSS_LONG_ROW_MEAN;
+// (Round 1 staged 4096 products for matrices with >= 32 non-zeros per row: with the gathered operand that was
+// worth +5 % at 82 non-zeros per row.  With the staged operand the short chunk wins -- 16 KiB of LDS and ~56
+// VGPRs keep 8 workgroups per CU: plain SpMV 0.346 -> 0.309 ms = 6.7 TB/s, C23 -7 % at 82 non-zeros per row,
+// profiles/r02_ab_chunk.txt -- and there is one chunk size again.)
 constexpr int kMaxRowsPerBlock = 2048;  // bound for blocks of empty / very short rows
 constexpr int kXcds = 8;
 constexpr int kWindows = 16;          // column windows per row block of the 16-bit index stream
@@ -106,7 +102,7 @@ struct nss_csr_s {
   int32_t* rowblk = nullptr;
   int32_t nblk = 0;
   int32_t rg = 1;
-  int32_t chunk = nss::kChunk;   // products per row block: kChunk or kChunkLong (plan_row_blocks)
+  int32_t chunk = nss::kChunk;   // products per row block
   // Compressed column stream: when the columns of every row block fall into at most 16 aligned
   // windows of 4096 columns (grid operators: a row block touches its own grid plane and the two
   // neighbouring ones -- a few narrow clusters far apart) the kernel streams 2 bytes per entry,
@@ -565,26 +561,17 @@ __global__ __launch_bounds__(kBlock) void csr_direct_kernel(CsrView a, const int
   epi.finish(b, red);
 }
 
-// The launch plan only produces (chunk, lanes per row) = (kChunk, 1 | 2) and (kChunkLong, 2 ... 64): lanes per
-// row = the largest power of two with 2 * lanes * chunk / kBlock <= mean row length, and the chunk is kChunkLong
-// from 32 non-zeros per row on (plan_row_blocks).  Other combinations are not instantiated.
+// one instantiation per lanes-per-row value of the launch plan
 #define NSS_FOR_PLAN(A, ONE)                                                                      \
-  if ((A).chunk == kChunk) {                                                                       \
-    switch ((A).rg) {                                                                              \
-      case 1: ONE(1, kChunk) break;                                                                \
-      case 2: ONE(2, kChunk) break;                                                                \
-      default: throw Error("csr_stream: bad lanes-per-row in the launch plan");                    \
-    }                                                                                              \
-  } else {                                                                                         \
-    switch ((A).rg) {                                                                              \
-      case 2: ONE(2, kChunkLong) break;                                                            \
-      case 4: ONE(4, kChunkLong) break;                                                            \
-      case 8: ONE(8, kChunkLong) break;                                                            \
-      case 16: ONE(16, kChunkLong) break;                                                          \
-      case 32: ONE(32, kChunkLong) break;                                                          \
-      case 64: ONE(64, kChunkLong) break;                                                          \
-      default: throw Error("csr_stream: bad lanes-per-row in the launch plan");                    \
-    }                                                                                              \
+  switch ((A).rg) {                                                                                \
+    case 1: ONE(1, kChunk) break;                                                                  \
+    case 2: ONE(2, kChunk) break;                                                                  \
+    case 4: ONE(4, kChunk) break;                                                                  \
+    case 8: ONE(8, kChunk) break;                                                                  \
+    case 16: ONE(16, kChunk) break;                                                                \
+    case 32: ONE(32, kChunk) break;                                                                \
+    case 64: ONE(64, kChunk) break;                                                                \
+    default: throw Error("csr_stream: bad lanes-per-row in the launch plan");                      \
   }
 
 // the row-per-lane kernel alone (A must hold the fixed-width copy): for epilogue variants that only exist for it

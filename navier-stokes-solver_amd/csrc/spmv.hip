@@ -37,7 +37,7 @@ bool direct_rows_candidate(int32_t m, const int32_t* rowptr) {
 void plan_row_blocks(int32_t m, int64_t nnz, const int32_t* rowptr, int32_t* rg_out, int32_t* chunk_out,
                      std::vector<int32_t>& blk, const int32_t* cuts, int ncuts) {
   const double mean = m > 0 ? double(nnz) / double(m) : 0.0;
-  const int chunk = mean >= double(kLongRowMean) ? kChunkLong : kChunk;
+  const int chunk = kChunk;
   *chunk_out = chunk;
   // Lanes per row: the largest power of two for which one reduce pass (kBlock / rg rows) still
   // covers a full chunk of products, i.e. rg ~ mean / 8.  Long rows then fill the LDS chunk
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(kBlock) void seg_build_kernel(int32_t nblk, const i
                                                             const int32_t* __restrict__ col, int32_t chunk,
                                                             int32_t ncols, int32_t* __restrict__ desc,
                                                             uint16_t* __restrict__ pos16, int32_t* __restrict__ nbad) {
-  __shared__ int32_t cols[kChunkLong];
+  __shared__ int32_t cols[kChunk];
   __shared__ int32_t hidx[kSegMax];
   __shared__ int32_t sstart[kSegMax], spre[kSegMax];
   __shared__ int32_t hcount, ok;

@@ -202,35 +202,33 @@ def test_spmv_row_per_lane_kernel(hip_engine):
 
 
 def _plan_lanes(mean):
-    """The plan rule of csrc/spmv.hip: matrices with mean >= 32 non-zeros per row stage 4096 products
-    per row block (16 per lane), the others 2048 (8 per lane); lanes per row = the largest power of
-    two for which one reduce pass still covers a full chunk."""
-    per = 16 if mean >= 32 else 8
+    """The plan rule of csrc/spmv.hip: 2048 products per row block (8 per lane); lanes per row = the largest power
+    of two for which one reduce pass still covers a full chunk."""
     lanes = 1
-    while lanes < 64 and 2 * lanes * per <= mean:
+    while lanes < 64 and 2 * lanes * 8 <= mean:
         lanes *= 2
     return lanes
 
 
 def test_spmv_row_length_regimes(hip_engine):
-    """Every lanes-per-row instantiation of the CSR-stream kernel (1 ... 64) in both chunk sizes,
-    picked from the mean row length by the plan rule."""
+    """Every lanes-per-row instantiation of the CSR-stream kernel (1 ... 64), picked from the mean row length by the
+    plan rule."""
     s = mac_stokes(3, 6)
     seen = set()
-    for bs in (1, 3, 6, 9, 12, 22, 44, 90):         # ~6 ... ~560 non-zeros per row
+    for bs in (1, 3, 6, 12, 22, 44, 90):            # ~6 ... ~530 non-zeros per row: 1, 2, 4 ... 64 lanes per row
         infl = s.inflate(bs) if bs > 1 else s
         M = _spmv_check(hip_engine, infl.A)
         mean = infl.A.nnz / infl.A.shape[0]
         info = M.handle.info()
         assert info["lanes_per_row"] == _plan_lanes(mean)
         if info["index_bytes"] == 2:                 # block-structured operator: one 16-bit index per run of columns
-            expect = {1: 1, 3: 3, 6: 6, 9: 9, 12: 12, 22: 11, 44: 11, 90: 15}[bs]
+            expect = {1: 1, 3: 3, 6: 6, 12: 12, 22: 11, 44: 11, 90: 15}[bs]
             assert info["index_group"] == expect, (bs, info)
             per_block = 128 if info["operand_form"] == "staged" else 64    # segment descriptor / window bases
             assert info["algorithmic_bytes"] == (8 * infl.A.nnz + 2 * (infl.A.nnz // expect)
                                                  + per_block * info["row_blocks"]
                                                  + 4 * (infl.A.shape[0] + 1) + 16 * infl.A.shape[0])
-        seen.add((mean >= 32, _plan_lanes(mean)))
+        seen.add(_plan_lanes(mean))
         if bs <= 12:
             _spmv_check(hip_engine, infl.B, seed=5, alpha=2.0, beta=-1.0)
     rng = np.random.default_rng(3)
@@ -238,16 +236,15 @@ def test_spmv_row_length_regimes(hip_engine):
         mat = sp.csr_matrix(rng.standard_normal((m, n)))
         M = _spmv_check(hip_engine, mat, seed=m + n)
         assert M.handle.info()["lanes_per_row"] == _plan_lanes(float(n))
-        seen.add((True, _plan_lanes(float(n))))
-    # long-row matrix with rows beyond the 4096-product chunk (whole-workgroup row reduction)
+        seen.add(_plan_lanes(float(n)))
+    # long-row matrix with rows beyond the 2048-product chunk (whole-workgroup row reduction)
     lens = np.full(400, 60)
     lens[7], lens[399] = 4500, 9000
     rows = np.repeat(np.arange(400), lens)
     cols = np.concatenate([rng.choice(12000, size=k, replace=False) for k in lens])
     mat = sp.csr_matrix((rng.standard_normal(rows.size), (rows, cols)), shape=(400, 12000))
     _spmv_check(hip_engine, mat, seed=8, alpha=-0.5, beta=2.0)
-    assert {l for long_rows, l in seen if not long_rows} == {1, 2}
-    assert {l for long_rows, l in seen if long_rows} == {2, 4, 8, 16, 32, 64}
+    assert seen == {1, 2, 4, 8, 16, 32, 64}
 
 
 def test_spmv_ragged_empty_and_long_rows(hip_engine):
