@@ -123,7 +123,7 @@ NSS_API int nss_csr_select_rows(nss_csr_t a, int32_t nrows, const int32_t* d_row
  * temporaries in a pool between calls; this returns the unused ones to the driver */
 NSS_API int nss_scratch_trim(void);
 /* Streaming (non-temporal) loads of the vector operands the fused loops do not read again before they are
- * rewritten: -1 = automatic (from 24 MB per vector on: they pay when the vectors do not fit the caches and cost
+ * rewritten: -1 = automatic (from 20 MB per vector on: they pay when the vectors do not fit the caches and cost
  * when they do), 0 = never, 1 = always.  Same bits either way. */
 NSS_API int nss_stream_loads_mode(int32_t mode);
 /* copy the CSR arrays back to HOST buffers (rows+1 / nnz / nnz entries; sizes from nss_csr_info) */

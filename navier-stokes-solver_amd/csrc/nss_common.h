@@ -131,9 +131,10 @@ __device__ __forceinline__ void st2(double* p, const double2& v) { *reinterpret_
 // Streaming (non-temporal) loads of vector operands that are not read again before they are rewritten pay when
 // the vectors do not fit the caches anyway (1e7 DoF: BPCG v2 +11 %, MINRES +8 %) and cost where they do (1e6 DoF,
 // 6-MB vectors: -5 %): the element-wise kernels take the choice as a template parameter, made per launch from the
-// vector length.  Measured crossover between 2.5e6 and 5e6 DoF (profiles/r02_size_sweep.md, r02_ab_streaming_loads.txt).
+// vector length.  Measured: off is better at 15 MB per vector (-4 % with them), on at 24 MB (+5 %, the 82-non-zero
+// operator) and 30 MB (+2 %) (profiles/r02_ab_streaming_loads.txt).
 #ifndef NSS_STREAM_LOADS_MIN_BYTES
-#define NSS_STREAM_LOADS_MIN_BYTES (24u << 20)
+#define NSS_STREAM_LOADS_MIN_BYTES (20u << 20)
 #endif
 int stream_loads_mode();                      // -1 automatic, 0 never, 1 always (nss_stream_loads_mode)
 inline bool stream_vector_loads(int64_t n) {

@@ -403,7 +403,7 @@ def test_fused_bpcg2_frozen_at_break_and_maxsteps_warning(hip_engine):
 @pytest.mark.parametrize("name", ["stokes3d_n10_bjac", "stokes2d_n24_jacobi"])
 def test_streaming_loads_do_not_change_a_bit(hip_engine, name):
     """The element-wise kernels of the three fused loops load the vector operands they do not read again with
-    streaming (non-temporal) loads from 24 MB per vector on -- a cache policy, chosen per launch
+    streaming (non-temporal) loads from 20 MB per vector on -- a cache policy, chosen per launch
     (nss_stream_loads_mode: automatic / never / always).  Forced on and off here (with the row-per-lane kernel for
     B^T, which carries the streaming variant of C1): identical histories and solutions."""
     import hipla
