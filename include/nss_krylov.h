@@ -147,8 +147,11 @@ NSS_API int nss_csr_operand_form(nss_csr_t a, int32_t* form);
  * launch-bound and the launch a pair of matrices shares is worth more); -1 restores the default.  Same bits
  * either way. */
 NSS_API int nss_csr_direct_rows_threshold(int64_t min_rows);
-/* shape, nnz, launch plan (row blocks, lanes per row) and algorithmic bytes of one
- * SpMV: 12*nnz + 4*(rows+1) + 8*cols + 8*rows */
+/* shape, nnz, launch plan (row blocks, lanes per row) and algorithmic bytes of one SpMV AS THIS MATRIX IS
+ * STORED: value stream 8*nnz + column stream (2*nnz/g with a 16-bit form and one index per g entries, 4*nnz
+ * without; + the per-row-block table: 128 B staged / 64 B windows) + 4*(rows+1) + 8*cols + 8*rows; the
+ * fixed-width copy (form 3): 24*rows + 8*cols + 8*rows.  (SURVEY.md section 8d states the fp64 / int32 CSR
+ * figure, 12*nnz + ...; pricing a launch that streams fewer bytes at that figure would overstate its rate.) */
 NSS_API int nss_csr_info(nss_csr_t a, int32_t* nrows, int32_t* ncols, int64_t* nnz,
                          int32_t* nblocks, int32_t* lanes_per_row, int64_t* algorithmic_bytes);
 NSS_API int nss_csr_diagonal(nss_csr_t a, double* diag_dev, nss_stream_t stream);
