@@ -43,10 +43,6 @@ namespace nss {
 #define NSS_PREFETCH_ROWS 1     // phase-2 rows per lane whose bounds and epilogue operands are requested up front (RG == 1)
 #endif
 
-#ifndef NSS_STREAM_VEC2
-#define NSS_STREAM_VEC2 0   // 1: 16-byte (val) / 8-byte (col) loads, two consecutive entries per lane
-#endif
-
 #ifndef NSS_CHUNK
 #define NSS_CHUNK 2048
 #endif
@@ -59,8 +55,6 @@ constexpr int kMaxRowsPerBlock = 2048;  // bound for blocks of empty / very shor
 constexpr int kXcds = 8;
 constexpr int kWindows = 16;          // column windows per row block of the 16-bit index stream
 constexpr int kWindowBits = 12;      // 4096 columns per window
-// Staged operand (nss_csr_s::blkseg): per row block at most kSegMax runs of consecutive columns, together at
-// most `chunk` columns (the products per row block), copied to LDS by LDS-DMA ahead of the matrix stream.
 #ifndef NSS_DIRECT_ROWS
 #define NSS_DIRECT_ROWS 1
 #endif
@@ -69,7 +63,10 @@ constexpr int kDirectWidth = 2;        // entries per row of the fixed-width cop
 #define NSS_DIRECT_ROWS_PER_LANE 2
 #endif
 constexpr int kDirectRows = NSS_DIRECT_ROWS_PER_LANE * 256;   // rows per row block of such a matrix
-constexpr int kSegMax = 13;             // (the LDS copy holds up to `chunk` columns: it shares the product buffer)
+// Staged operand (nss_csr_s::blkseg): per row block at most kSegMax runs of consecutive columns, together at
+// most `chunk` columns (the LDS copy shares the product buffer), copied to LDS by LDS-DMA ahead of the matrix
+// stream.
+constexpr int kSegMax = 13;
 constexpr int kSegWords = 32;        // descriptor: r0, r1, p0, cnt, nseg, total, pre[1..12], off[0..12], spare
 constexpr int kSegPre = 6, kSegOff = 18;
 
