@@ -616,7 +616,11 @@ static int k4_ghost_blocks(const nss_bpcg2_t& s) {
 // Sums with at most this many terms are evaluated inside the consuming kernel by every workgroup
 // (compact plan); longer ones by the stand-alone sum kernel.  nss_bpcg2_fold_mode() overrides (tests,
 // measurements): -1 automatic, 0 never, 1 always.
-constexpr int kFoldMax = 4096;
+// Measured (profiles/r02_ab_fold_threshold.txt, folded vs stand-alone at 1.5e4 ... 1e6 DoF): folding wins by
+// 3-30 % up to 2.5e5 DoF (~800 + ~500 partials) and LOSES 11-13 % from 4.4e5 DoF (~1400 + ~850) on -- every one of
+// the ~1000-2000 workgroups of the consumer then re-reads all partials from L2, as many bytes as the kernel's own
+// HBM traffic.  (Round-2 first value: 4096.)
+constexpr int kFoldMax = 1024;
 static int g_fold_mode = -1;
 static bool fold_sums(const nss_bpcg2_t& s) {
   const int forced = g_fold_mode;

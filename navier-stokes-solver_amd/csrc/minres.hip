@@ -382,18 +382,19 @@ static int m3_gu(const nss_minres_t& s) {
   return m_fused_bjac(s) ? (s.pre_bjac->nblocks + kBlock - 1) / kBlock : m_gu(s);
 }
 
-constexpr int kMFoldMax = 4096;
+constexpr int kMFoldMax = 1024;      // as kFoldMax of bpcg2.hip (measured there and here: 1e6 DoF +9 % unfolded)
+constexpr int kMFuseMax = 4096;      // the block Jacobi fused into M3 still pays at 1e6 DoF (+5 %)
 static int g_minres_fold_mode = -1;
-static bool m_small(const nss_minres_t& s) {       // launch-bound regime: every sum of the iteration is short
+static bool m_small(const nss_minres_t& s, int limit) {       // launch-bound regime: every sum of the iteration is short
   int64_t dotg = m_dot_grid(s);
   if (s.pre_bjac) dotg = std::max<int64_t>(dotg, bjac_dot_grid(*s.pre_bjac));
   const int64_t m3 = std::max<int64_t>((s.pre_bjac ? (s.pre_bjac->nblocks + kBlock - 1) / kBlock : 0), m_gu(s)) + m_gp(s);
-  return s.A->nblk + s.B->nblk <= kMFoldMax && m3 <= kMFoldMax && dotg <= kMFoldMax;
+  return s.A->nblk + s.B->nblk <= limit && m3 <= limit && dotg <= limit;
 }
 static bool m_fold(const nss_minres_t& s) {
   if (s.local_sums) return false;          // row-partitioned: the sums are all-reduced between the kernels
   if (g_minres_fold_mode >= 0) return g_minres_fold_mode != 0;
-  return m_small(s);
+  return m_small(s, kMFoldMax);
 }
 // Fusing the block-Jacobi apply into M3 saves a launch and the re-read of v_new, but turns M3's three
 // input streams into 24-byte-strided per-lane accesses: a win where launches dominate, a loss where
@@ -401,7 +402,7 @@ static bool m_fold(const nss_minres_t& s) {
 static bool m_fused_bjac(const nss_minres_t& s) {
   if (!m_fusable_bjac(s)) return false;
   if (g_minres_fuse_mode >= 0) return g_minres_fuse_mode != 0;
-  return m_small(s);
+  return m_small(s, kMFuseMax);
 }
 
 static void minres_check(const nss_minres_t* s) {

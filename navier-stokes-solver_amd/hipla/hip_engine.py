@@ -132,6 +132,10 @@ def load_library(path=None):
         fn.argtypes = args
     if os.environ.get("NSS_STREAM_LOADS") and hasattr(lib, "nss_stream_loads_mode"):     # measurements: -1 / 0 / 1
         lib.nss_stream_loads_mode(int(os.environ["NSS_STREAM_LOADS"]))
+    if os.environ.get("NSS_FOLD_SUMS"):                                                   # measurements: -1 / 0 / 1
+        for name in ("nss_bpcg2_fold_mode", "nss_minres_fold_mode"):
+            if hasattr(lib, name):
+                getattr(lib, name)(int(os.environ["NSS_FOLD_SUMS"]))
     return lib
 
 
