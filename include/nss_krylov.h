@@ -298,6 +298,20 @@ typedef struct nss_bpcg2_s {
   /* row-partitioned runs: V-cycle with replicated coarse levels as (part of) preA, applied natively with its
    * two halo exchanges and one coarse all-reduce (nss_dist_amg_create); NULL otherwise */
   struct nss_dist_amg_s* pre_dist_amg;
+  /* row-partitioned runs on the COMPACT plan (C1, preA, exchange of t1, C23, sum, all-reduce, C4, sum,
+   * all-reduce: six launches and three collectives per iteration instead of nine launches).  The state is laid
+   * out so that every ghost entry sits behind the owned entries of its vector:
+   *   s0, w0, t1 : buffers [n_u owned | ghost_n ghosts] in the layout of A's operand (ghost_s0 = s0 + n_u,
+   *                ghost_w0 = w0 + n_u; ghost_map = NULL: the ghost of t1 that belongs to ghost i is t1[n_u + i]);
+   *   s1, w1, t3 : buffers [n_p owned | ghost_p_n ghosts] in the layout of B^T's operand (ghost_w1 = w1 + n_p,
+   *                ghost_t3 = t3 + n_p, ghost_minv as above);
+   *   B          : n_p + ghost_p_n rows -- the slab's pressure rows followed by the rows of the ghost pressure
+   *                cells -- with columns in the layout of A's operand (it multiplies t1 - s0 formed on the fly);
+   *                no row block of its launch plan spans row n_p; ghost_b and t4 are not used.
+   * The ghost copies follow the recurrences of their owners: s0_g = beta s0_g + w0_g in C1, s1_g = beta s1_g +
+   * w1_g and t3_g with the rows of B in C23 (ghost rows add nothing to the dot partials), w0_g and w1_g in C4.
+   * 0: the eight-phase layout described above. */
+  int32_t dist_compact;
 } nss_bpcg2_t;
 
 enum {
@@ -386,7 +400,11 @@ NSS_API int nss_dist_destroy(nss_dist_t d);
 /* iterations [it_begin, it_end) of the partitioned loop: per iteration 3 halo exchanges, the
  * phases of nss_bpcg2_phase split into interior / boundary row blocks, 2 all-reduces.
  * overlap: 0 = exchange then multiply on `stream`; 1 = interior rows overlap the exchange;
- * 2 = as 1 but also when this rank has no neighbour (exercises the split path in tests). */
+ * 2 = as 1 but also when this rank has no neighbour (exercises the split path in tests).
+ * A state with dist_compact != 0 runs the COMPACT plan instead -- per iteration C1 (+ preA), the exchange of t1
+ * (halo_t1; halo_s1 / halo_t4 may be NULL, `overlap` is ignored), C23, sum, all-reduce, C4, sum, all-reduce: six
+ * launches and three collectives; the books of an iteration are done by C1 of the next one from the all-reduced
+ * <w, d> (or by nss_bpcg2_poll).  Same arithmetic per lane as the eight-phase form. */
 NSS_API int nss_bpcg2_iterate_dist(const nss_bpcg2_t* s, nss_dist_t d, const nss_halo_t* halo_s1,
                                    const nss_halo_t* halo_t1, const nss_halo_t* halo_t4, int32_t overlap,
                                    int32_t it_begin, int32_t it_end, nss_stream_t stream);
@@ -408,7 +426,8 @@ NSS_API int nss_dist_amg_apply_f64(nss_dist_amg_t h, double scale, const double*
  *   0 K1 (B^T rows; + the s1 exchange unless that operand is kept by recurrence) + preA,  1 t1 halo exchange,
  *   2 K2 (A rows),  3 K3 (B rows; + the t4 exchange if any) + local sum,  4 all-reduce <s, K s>,
  *   5 K4 + local sum,  6 all-reduce <w, d>,  7 K5.   (Non-overlapped mode; what tells WHICH collective costs
- * what on a real node.) */
+ * what on a real node.)  Compact plan (dist_compact): 0 C1 + preA,  1 t1 halo exchange,  2 C23 (rows of A and B),
+ * 3 local sum,  4 all-reduce <s, K s>,  5 C4 + local sum,  6 all-reduce <w, d>,  7 empty (no K5). */
 NSS_API int nss_dist_profile_begin(nss_dist_t d, int32_t max_iterations);
 NSS_API int nss_dist_profile_end(nss_dist_t d, double* h_segment_ms /* 8 */, int32_t* iterations);
 

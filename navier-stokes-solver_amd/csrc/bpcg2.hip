@@ -358,7 +358,7 @@ __global__ __launch_bounds__(kBlock) void bpcg2_k4_kernel(K4Args a) {
   } else {                                       // row-partitioned runs: ghost copies, same recurrences
     const int first = wg - a.gu - a.gp, stride = (int(gridDim.x) - a.gu - a.gp) * kBlock;
     for (int i = first * kBlock + int(threadIdx.x); i < a.ghost_n; i += stride)
-      a.ghost_w0[i] = fma(-alpha, a.t1[a.ghost_map[i]], a.ghost_w0[i]);
+      a.ghost_w0[i] = fma(-alpha, a.t1[a.ghost_map ? a.ghost_map[i] : a.n_u + i], a.ghost_w0[i]);
     for (int i = first * kBlock + int(threadIdx.x); i < a.ghost_p_n; i += stride)
       a.ghost_w1[i] = fma(-alpha, a.ghost_minv[i] * a.ghost_t3[i], a.ghost_w1[i]);
     return;
@@ -484,6 +484,11 @@ struct EpiK1c {
   int it;
   const double* __restrict__ s1;
   const double* __restrict__ w1;
+  // row-partitioned runs on the compact plan: the ghost copies of s0 follow s0 = beta s0 + w0 here (K5's job in
+  // the eight-phase form); 0 entries on one GPU
+  int32_t ghost_n = 0;
+  double* __restrict__ ghost_s0 = nullptr;
+  const double* __restrict__ ghost_w0 = nullptr;
   double alpha = 0.0, beta = 0.0;
   bool pending = false;
   __device__ bool skip() const { return cl.ctrl[C_DONE] != 0; }
@@ -538,7 +543,11 @@ struct EpiK1c {
     NSS_ST3(t0[r], t);
     if (dinv) t1[r] = k * (dinv[r] * t);
   }
-  __device__ void finish(int, double*) const {}
+  __device__ void finish(int, double*) const {
+    if (it == 0 || ghost_n == 0) return;
+    const int stride = gridDim.x * kBlock;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < ghost_n; i += stride) ghost_s0[i] = fma(beta, ghost_s0[i], ghost_w0[i]);
+  }
 };
 
 // C23, rows of A: K2 without t4
@@ -574,6 +583,8 @@ struct EpiK3c {
   double* __restrict__ t3;
   double* __restrict__ partials;
   int it;
+  int n_own;          // rows from n_own on are the ghost pressure rows of a row-partitioned run: same recurrences,
+                      // nothing added to the inner product (one GPU: n_own = rows of B)
   double acc = 0.0;
   double beta = 0.0;
   __device__ bool skip() const { return ctrl[C_DONE] != 0; }
@@ -597,7 +608,7 @@ struct EpiK3c {
       s1[r] = sv;
     }
     NSS_ST2(t3[r], bt4);
-    acc = fma(sv, bt4, acc);
+    if (r < n_own) acc = fma(sv, bt4, acc);
   }
   __device__ void finish(int b, double* lds) {
     const double s = block_sum(acc, lds);
@@ -653,7 +664,20 @@ static void launch_k4(const nss_bpcg2_t& s, int it, bool fold, hipStream_t st) {
 void bpcg2_check_state(const nss_bpcg2_t* s) {
   NSS_REQUIRE(s != nullptr, "bpcg2: NULL state");
   NSS_REQUIRE(s->A && s->B && s->BT, "bpcg2: NULL matrix handle");
-  NSS_REQUIRE(s->A->m == s->n_u && s->BT->m == s->n_u && s->B->m == s->n_p, "bpcg2: matrix row counts do not match n_u/n_p");
+  NSS_REQUIRE(s->A->m == s->n_u && s->BT->m == s->n_u, "bpcg2: matrix row counts do not match n_u");
+  if (s->dist_compact) {
+    NSS_REQUIRE(s->local_sums && s->ghost_mode && s->ghost_p_mode && s->ghost_n >= 0 && s->ghost_p_n >= 0,
+                "bpcg2: the compact partitioned plan keeps all ghosts by recurrence (ghost_mode, ghost_p_mode, local_sums)");
+    NSS_REQUIRE(s->B->m == s->n_p + s->ghost_p_n, "bpcg2: compact partitioned plan: B must hold the owned and the ghost pressure rows");
+    NSS_REQUIRE(s->A->n == s->n_u + s->ghost_n && s->B->n == s->A->n && s->BT->n == s->n_p + s->ghost_p_n,
+                "bpcg2: compact partitioned plan: operand layouts [owned | ghosts] of A (also B's) and B^T do not match the ghost counts");
+    NSS_REQUIRE(s->ghost_map == nullptr && s->ghost_s0 == s->s0 + s->n_u && s->ghost_w0 == s->w0 + s->n_u &&
+                    s->ghost_w1 == s->w1 + s->n_p && s->ghost_t3 == s->t3 + s->n_p && (s->ghost_p_n == 0 || s->ghost_minv),
+                "bpcg2: compact partitioned plan: ghost copies must sit behind the owned entries of s0, w0, w1, t3");
+    NSS_REQUIRE(!s->cond_HT, "bpcg2: compact partitioned plan takes no condensed form");
+  } else {
+    NSS_REQUIRE(s->B->m == s->n_p, "bpcg2: matrix row counts do not match n_p");
+  }
   NSS_REQUIRE(!(s->pre_diag && s->pre_bjac), "bpcg2: pre_diag and pre_bjac are exclusive");
   NSS_REQUIRE(s->pre_diag || s->pre_bjac || s->pre_amg || s->pre_dist_amg, "bpcg2: no preconditioner for the velocity block");
   NSS_REQUIRE(!s->pre_dist_amg || (!s->pre_amg && !s->cond_HT && s->pre_dist_amg->n == s->n_u),
@@ -667,12 +691,12 @@ void bpcg2_check_state(const nss_bpcg2_t* s) {
   NSS_REQUIRE(!s->pre_bjac || s->pre_bjac->n == s->n_u, "bpcg2: block-Jacobi size mismatch");
   NSS_REQUIRE(s->minv && s->scal && s->ctrl && s->hist && s->partials_a && s->partials_b && s->partials_c,
               "bpcg2: NULL work buffer");
-  NSS_REQUIRE(!s->ghost_mode || s->ghost_n == 0 || (s->ghost_map && s->ghost_s0 && s->ghost_w0),
+  NSS_REQUIRE(!s->ghost_mode || s->ghost_n == 0 || ((s->ghost_map || s->dist_compact) && s->ghost_s0 && s->ghost_w0),
               "bpcg2: ghost mode without ghost arrays");
   NSS_REQUIRE(s->ghost_n >= 0 && s->ghost_p_n >= 0, "bpcg2: negative ghost count");
   NSS_REQUIRE(!s->ghost_p_mode || s->ghost_p_n == 0 ||
-                  (s->ghost_mode && s->ghost_b && s->ghost_t3 && s->ghost_w1 && s->ghost_minv &&
-                   s->ghost_b->m == s->ghost_p_n),
+                  (s->ghost_mode && s->ghost_t3 && s->ghost_w1 && s->ghost_minv &&
+                   (s->dist_compact || (s->ghost_b && s->ghost_b->m == s->ghost_p_n))),
               "bpcg2: pressure ghost mode without its arrays (it also needs the velocity ghost mode)");
   const bool cond = s->cond_HT || s->cond_H || s->cond_inner || s->cond_f;
   if (cond) {
@@ -688,6 +712,7 @@ void bpcg2_check_state(const nss_bpcg2_t* s) {
 // SpMV phases over the row blocks [b0, b1) of their matrix (b1 < 0: all).  The block-Jacobi
 // apply that completes K1 is a separate step (`bpcg2_k1_finish`) because it needs all of t0.
 void bpcg2_spmv_phase(const nss_bpcg2_t& s, int which, int it, hipStream_t st, int b0, int b1, bool ghost_tail) {
+  if (s.dist_compact) throw Error("bpcg2: a state laid out for the compact partitioned plan takes the compact phases only");
   switch (which) {
     case NSS_BPCG2_K1: {
       // the point-Jacobi apply rides in the epilogue unless an AMG term comes first
@@ -768,6 +793,7 @@ void bpcg2_phase(const nss_bpcg2_t& s, int which, int it, hipStream_t st) {
     case NSS_BPCG2_ALPHA:   // folded into K4 (kept as a phase id for callers that list all phases)
       break;
     case NSS_BPCG2_K4:
+      if (s.dist_compact) throw Error("bpcg2: a state laid out for the compact partitioned plan takes the compact phases only");
       if (s.ghost_p_mode && s.ghost_p_n > 0)     // t3 on the ghost pressure rows (t4 and its ghosts are complete)
         launch_csr_stream(*s.ghost_b, s.t4, EpiGuardedStore{s.ctrl, s.ghost_t3}, st);
       launch_k4(s, it, false, st);
@@ -780,6 +806,7 @@ void bpcg2_phase(const nss_bpcg2_t& s, int which, int it, hipStream_t st) {
     case NSS_BPCG2_BETA:    // folded into K5
       break;
     case NSS_BPCG2_K5:
+      if (s.dist_compact) throw Error("bpcg2: a state laid out for the compact partitioned plan takes the compact phases only");
       hipLaunchKernelGGL(bpcg2_k5_kernel, dim3(stream_grid(s.n_p, kBlock * 4)), dim3(kBlock), 0, st, s.ctrl, s.scal,
                          s.hist, it, s.n_p, s.s1, s.w1, s.ghost_mode ? s.ghost_n : 0, s.ghost_s0, s.ghost_w0,
                          s.ghost_p_mode ? s.ghost_p_n : 0, s.s1 + s.n_p, s.ghost_w1);
@@ -805,7 +832,7 @@ void bpcg2_cphase(const nss_bpcg2_t& s, int which, int it, hipStream_t st) {
       const bool nt = s.BT->ell_col != nullptr && stream_vector_loads(s.n_u);
 #define NSS_C1(FOLD, NT, LAUNCH)                                                                                       \
   LAUNCH(*s.BT, s.s1, EpiK1c<FOLD, NT>{close_args(s, FOLD), s.u0, s.q, s.z0, s.t2, s.s0, s.w0, s.t0, s.t1, dinv, s.k, it, \
-                                       s.s1, s.w1}, st)
+                                       s.s1, s.w1, s.dist_compact ? s.ghost_n : 0, s.ghost_s0, s.ghost_w0}, st)
       if (nt && fold) NSS_C1(true, true, launch_csr_direct);
       else if (nt) NSS_C1(false, true, launch_csr_direct);
       else if (fold) NSS_C1(true, false, launch_csr_stream);
@@ -816,7 +843,7 @@ void bpcg2_cphase(const nss_bpcg2_t& s, int which, int it, hipStream_t st) {
     }
     case NSS_BPCG2C_C23: {
       EpiK2c ea{s.ctrl, s.t0, s.s0, s.t2, s.partials_a};
-      EpiK3c eb{s.ctrl, s.scal, s.t1, s.s0, s.s1, s.w1, s.t3, s.partials_b, it};
+      EpiK3c eb{s.ctrl, s.scal, s.t1, s.s0, s.s1, s.w1, s.t3, s.partials_b, it, s.n_p};
       if (!launch_csr_stream_dual(*s.A, s.t1, ea, *s.B, s.t1, eb, st)) {   // launch plans differ: two launches
         launch_csr_stream(*s.A, s.t1, ea, st);
         launch_csr_stream(*s.B, s.t1, eb, st);
@@ -891,7 +918,8 @@ int nss_bpcg2_cphases(const nss_bpcg2_t* s, int32_t first, int32_t last, int32_t
   return guarded([&] {
     bpcg2_check_state(s);
     NSS_REQUIRE(first >= NSS_BPCG2C_C1 && last <= NSS_BPCG2C_SUMW && first <= last, "bpcg2_cphases: bad phase range");
-    NSS_REQUIRE(!s->ghost_mode && !s->ghost_p_mode && !s->local_sums, "bpcg2_cphases: single-GPU states only");
+    NSS_REQUIRE(s->dist_compact || (!s->ghost_mode && !s->ghost_p_mode && !s->local_sums),
+                "bpcg2_cphases: single-GPU states, or row-partitioned states laid out for the compact plan");
     for (int ph = first; ph <= last; ++ph) bpcg2_cphase(*s, ph, it, as_stream(stream));
   });
 }

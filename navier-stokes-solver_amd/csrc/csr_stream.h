@@ -305,7 +305,11 @@ __device__ __forceinline__ bool csr_phase1(const CsrView& a, const double* __res
   const XOp xop = EpiX<Epi>::get(epi, x);
   double xv[kPer];
   if constexpr (IDX == 2) {
-    __syncthreads();                                     // the LDS copy has landed (the barrier drains the DMA)
+    // LDS-DMA is tracked by vmcnt and gfx950 does not drain it at s_barrier: every wave waits for its own copies
+    // before the barrier that publishes them to the other waves.  (hipcc already placed this wait here -- the
+    // matrix stream is consumed right behind the barrier -- the statement pins it against code motion.)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                     // the LDS copy has landed in every wave's part
 #pragma unroll
     for (int k = 0; k < kPer; ++k)
       xv[k] = (tid + k * kBlock < cnt) ? xop.value(prod[int(c16[k]) + (GRP ? c[k] : 0)]) : 0.0;

@@ -37,7 +37,7 @@ struct nss_dist_amg_s {
   const nss_amg_s* coarse = nullptr;   // levels 1.. (replicated)
   nss_halo_t halo{};                   // of the iterate x (ext = x's halo-extended buffer)
   int32_t n = 0, nc = 0;
-  double *res = nullptr, *rc = nullptr, *ec = nullptr;   // work vectors (owned by the handle)
+  double *res = nullptr, *rc = nullptr, *rc_local = nullptr, *ec = nullptr;   // work vectors (owned by the handle)
 };
 
 namespace nss {

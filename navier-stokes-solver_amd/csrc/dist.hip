@@ -11,6 +11,10 @@
 //   X: wait(C) . pack(t1) . group{send,recv} ;  C: K2 interior . wait(X) . K2 boundary
 //   X: wait(C) . pack(t4) . group{send,recv} ;  C: K3 interior . wait(X) . K3 boundary   (ghost mode: no exchange)
 //   C: SUM1 . allreduce(as_s) . K4 . SUM2 . allreduce(wdn) . K5
+// States laid out for it (nss_bpcg2_t.dist_compact) run the COMPACT plan on C instead:
+//   C1 (books of the previous iteration from the all-reduced <w, d>; rows of B^T; ghost copies of s0) . preA .
+//   exchange(t1) . C23 (rows of A | owned + ghost rows of B on t1 - s0) . sum . allreduce(as_s) . C4 . sum .
+//   allreduce(wdn)                                  -- 6 launches + 3 collectives instead of 9 + 3.
 // Interior row blocks touch no ghost column, so they overlap the exchange; xGMI is
 // point-to-point and only slab neighbours talk.  With overlap == 0 everything runs on C.
 #include "dist.h"
@@ -23,6 +27,7 @@ namespace nss {
 //   0 K1 (B^T rows, incl. the s1 exchange when that operand is not kept by recurrence) + preA
 //   1 halo exchange of t1      2 K2 (A rows)      3 K3 (B rows, incl. the t4 exchange if any) + local sum
 //   4 all-reduce <s, K s>      5 K4 (+ ghost rows of B) + local sum      6 all-reduce <w, d>      7 K5
+// compact plan: 0 C1 + preA   1 exchange of t1   2 C23   3 local sum   4 all-reduce   5 C4 + local sum   6 all-reduce   7 -
 constexpr int kProfMarks = 9;
 
 enum { S_AS_SLOT = 1, S_WDN_SLOT = 2, S_LOCAL_OFFSET = 8 };   // local sums: slots 9 / 10 (bpcg2.hip)
@@ -164,8 +169,10 @@ void dist_amg_apply(const nss_dist_amg_s& a, double scale, const double* b, doub
   diag_apply(a.n, a.wdinv, 1.0, b, 0.0, x, done, st);                        // pre-smoothing from zero
   exchange(*a.d, a.halo, st);
   launch_csr_stream(*a.A, x, EpiResidual{b, a.res, done}, st);               // res = b - A x
-  launch_csr_stream(*a.R, a.res, EpiAxpby{1.0, 0.0, a.rc, done}, st);        // this slab's share of R res
-  allreduce_sum(*a.d, a.rc, a.rc, size_t(a.nc), st);
+  launch_csr_stream(*a.R, a.res, EpiAxpby{1.0, 0.0, a.rc_local, done}, st);  // this slab's share of R res
+  // out of place: once *done is set the kernels return at once but the collectives still run -- an in-place
+  // all-reduce would multiply the frozen rc by the number of ranks on every further iteration
+  allreduce_sum(*a.d, a.rc_local, a.rc, size_t(a.nc), st);
   amg_apply(*a.coarse, 1.0, a.rc, a.ec, st, done);                           // levels 1.. on every rank
   launch_csr_stream(*a.P, a.ec, EpiAxpby{1.0, 1.0, x, done}, st);            // x += P e
   exchange(*a.d, a.halo, st);
@@ -200,6 +207,7 @@ int nss_dist_amg_create(nss_dist_t d, nss_csr_t a_loc, const nss_halo_t* halo_x,
       h->nc = nc;
       NSS_HIP(hipMalloc(&h->res, sizeof(double) * size_t(std::max(1, n))));
       NSS_HIP(hipMalloc(&h->rc, sizeof(double) * size_t(std::max(1, nc))));
+      NSS_HIP(hipMalloc(&h->rc_local, sizeof(double) * size_t(std::max(1, nc))));
       NSS_HIP(hipMalloc(&h->ec, sizeof(double) * size_t(std::max(1, nc))));
     } catch (...) {
       nss_dist_amg_destroy(h);
@@ -214,6 +222,7 @@ int nss_dist_amg_destroy(nss_dist_amg_t h) {
     if (!h) return;
     (void)hipFree(h->res);
     (void)hipFree(h->rc);
+    (void)hipFree(h->rc_local);
     (void)hipFree(h->ec);
     delete h;
   });
@@ -311,12 +320,45 @@ int nss_bpcg2_iterate_dist(const nss_bpcg2_t* s, nss_dist_t d, const nss_halo_t*
   return guarded([&] {
     bpcg2_check_state(s);
     NSS_REQUIRE(d != nullptr, "iterate_dist: NULL dist handle");
+    NSS_REQUIRE(d->nranks == 1 || d->comm != nullptr, "iterate_dist: multi-rank run without a communicator");
+    if (s->dist_compact) {
+      // Compact plan: C1 (books of the previous iteration from the ALL-REDUCED <w, d>, rows of B^T, ghost copies of
+      // s0) . preA . exchange of t1 . C23 (rows of A; owned and ghost rows of B on t1 - s0) . sum . all-reduce .
+      // C4 . sum . all-reduce -- six launches and three collectives (eight-phase form: nine launches).
+      check_halo(halo_t1, *s->A, "halo_t1");
+      NSS_REQUIRE(halo_t1->ext == s->t1, "iterate_dist: the halo buffer is not the loop's SpMV operand t1");
+      hipStream_t cs = as_stream(stream);
+      for (int it = it_begin; it < it_end; ++it) {
+        hipEvent_t* ev = d->prof_iters < d->prof_cap ? &d->prof_ev[size_t(d->prof_iters) * kProfMarks] : nullptr;
+        auto mark = [&](int i) {
+          if (ev) NSS_HIP(hipEventRecord(ev[i], cs));
+        };
+        mark(0);
+        bpcg2_cphase(*s, NSS_BPCG2C_C1, it, cs);           // + preA
+        mark(1);
+        exchange(*d, *halo_t1, cs);
+        mark(2);
+        bpcg2_cphase(*s, NSS_BPCG2C_C23, it, cs);
+        mark(3);
+        bpcg2_cphase(*s, NSS_BPCG2C_SUMA, it, cs);
+        mark(4);
+        allreduce_slot(*s, *d, S_AS_SLOT, cs);
+        mark(5);
+        bpcg2_cphase(*s, NSS_BPCG2C_C4, it, cs);           // alpha inside
+        bpcg2_cphase(*s, NSS_BPCG2C_SUMW, it, cs);
+        mark(6);
+        allreduce_slot(*s, *d, S_WDN_SLOT, cs);             // read by C1 of the next iteration (or the poll)
+        mark(7);
+        mark(8);
+        if (ev) ++d->prof_iters;
+      }
+      return;
+    }
     check_halo(halo_s1, *s->BT, "halo_s1");
     check_halo(halo_t1, *s->A, "halo_t1");
     check_halo(halo_t4, *s->B, "halo_t4");
     NSS_REQUIRE(halo_s1->ext == s->s1 && halo_t1->ext == s->t1 && halo_t4->ext == s->t4,
                 "iterate_dist: halo buffers are not the loop's SpMV operands");
-    NSS_REQUIRE(d->nranks == 1 || d->comm != nullptr, "iterate_dist: multi-rank run without a communicator");
     hipStream_t cs = as_stream(stream);
     const int ov = overlap;
     for (int it = it_begin; it < it_end; ++it) {

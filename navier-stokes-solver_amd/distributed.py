@@ -307,9 +307,14 @@ class DistSparseMatrix(BaseMatrix):
             setattr(h, name, arr.ctypes.data if arr.size else None)
         h.n_pack, h.n_send, h.n_recv = (0 if direct else int(plan.send_idx.size)), len(sp), len(rp)
         h.direct = 1 if direct else 0
-        h.send_idx = self._send_idx.data_ptr() if plan.send_idx.size else None
-        h.sendbuf = self._sendbuf.data_ptr() if plan.send_idx.size else None
-        h.ext = hv.ext.data_ptr()
+        def ptr(buf):          # device pointer (HIP engine) or host address (numpy checker engine: descriptor tests)
+            return buf.data_ptr() if hasattr(buf, "data_ptr") else buf.ctypes.data
+
+        h.send_idx = ptr(self._send_idx) if plan.send_idx.size else None
+        h.sendbuf = ptr(self._sendbuf) if plan.send_idx.size else None
+        h.ext = ptr(hv.ext)
+        if interior is None and not hasattr(self.local.handle, "row_blocks"):
+            interior = (0, 0)      # (checker engine: no launch plan)
         h.int_begin, h.int_end = interior if interior is not None else self.interior_row_blocks()
         h._keep = (keep, hv, self)
         return h
@@ -499,6 +504,8 @@ class DistributedStokes:
             raise RuntimeError("ghost rows of B reference columns outside B's operand")
         newc[~own] = self.B.plan.n_owned + pos
         self.ghost_p = ghost_p
+        self._rows_gp, self._v_range = rows_gp, (v0g, v1g)
+        self._b_ext = None
         self.ghost_rows_B = sp.csr_matrix((rows_gp.data, newc.astype(np.int32), rows_gp.indptr),
                                           shape=(ghost_p.size, self.B.plan.n_owned + self.B.plan.n_ghost))
         self.ghost_rows_B.sort_indices()
@@ -534,6 +541,52 @@ class DistributedStokes:
         r = self.comm.rank
         return slice(int(self.vel[r]), int(self.vel[r + 1])), slice(int(self.prs[r]), int(self.prs[r + 1]))
 
+    def compact_layout_ok(self):
+        """The compact partitioned plan keeps every ghost by recurrence: B's ghost columns must be among those
+        of A's operand and the ghost pressure cells must be exactly the ghosts of B^T's operand (both arranged
+        by the constructor; checked because a caller may pass its own partition)."""
+        gb, ga = self.B.plan.ghosts, self.A.plan.ghosts
+        return bool(np.all(np.isin(gb, ga)) and np.array_equal(self.ghost_p, self.BT.plan.ghosts))
+
+    def b_extended_scipy(self):
+        """Rows [this slab's pressure rows | rows of the ghost pressure cells of B^T's operand] of B with the
+        columns numbered in the layout of A's operand ([owned | A's ghosts]): what the compact partitioned
+        plan multiplies with `t1 - s0` formed on the fly (nss_bpcg2_t.dist_compact)."""
+        v0, v1 = self._v_range
+        n_u, ga = self.A.plan.n_owned, self.A.plan.ghosts
+
+        def on_a(cols_global):
+            cols = np.asarray(cols_global, dtype=np.int64)
+            own = (cols >= v0) & (cols < v1)
+            out = np.empty_like(cols)
+            out[own] = cols[own] - v0
+            pos = np.searchsorted(ga, cols[~own])
+            if cols[~own].size and (pos.max(initial=0) >= ga.size or not np.array_equal(ga[np.minimum(pos, ga.size - 1)], cols[~own])):
+                raise RuntimeError("a row of B references a column outside A's operand")
+            out[~own] = n_u + pos
+            return out.astype(np.int32)
+
+        loc = self.B.local_scipy                                    # columns in B's layout -> global -> A's layout
+        cols_b = loc.indices.astype(np.int64)
+        glob = np.where(cols_b < self.B.plan.n_owned, cols_b + v0,
+                        self.B.plan.ghosts[np.maximum(cols_b - self.B.plan.n_owned, 0)] if self.B.plan.n_ghost else 0)
+        width = n_u + ga.size
+        own_rows = sp.csr_matrix((loc.data, on_a(glob), loc.indptr), shape=(loc.shape[0], width))
+        gp = self._rows_gp
+        ghost_rows = sp.csr_matrix((gp.data, on_a(gp.indices), gp.indptr), shape=(gp.shape[0], width))
+        ext = sp.vstack([own_rows, ghost_rows]).tocsr()
+        ext.sort_indices()
+        return ext
+
+    def b_extended(self):
+        """`b_extended_scipy()` on the device; no row block of its launch plan spans the owned / ghost boundary."""
+        if self._b_ext is None:
+            ext = self.b_extended_scipy()
+            handle = self.engine.csr_create(ext.shape[0], ext.shape[1], ext.indptr, ext.indices, ext.data, cuts=[self.n_p])
+            self._b_ext = SparseMatrix(ext.shape[0], ext.shape[1], ext.indptr, ext.indices, ext.data, engine=self.engine,
+                                       handle=handle)
+        return self._b_ext
+
     def vectors(self, f_global, g_global):
         """This rank's slabs of a global (velocity, pressure) pair as vectors that know the
         communicator: `InnerProduct` / `Norm` of them -- and of every vector the solvers create from
@@ -561,13 +614,19 @@ class DistributedBpcg2:
     SCHEDULE = (("halo", "s1"), ("phases", ("K1", "K1")), ("halo", "t1"), ("phases", ("K2", "K2")),
                 ("halo", "t4"), ("phases", ("K3", "SUM1")), ("allreduce", 1), ("phases", ("ALPHA", "SUM2")),
                 ("allreduce", 2), ("phases", ("BETA", "K5")))
+    # the compact plan (default): 6 launches + 3 collectives per iteration instead of 9 + 3
+    SCHEDULE_COMPACT = (("cphases", ("C1", "C1")), ("halo", "t1"), ("cphases", ("C23", "SUMA")), ("allreduce", 1),
+                        ("cphases", ("C4", "SUMW")), ("allreduce", 2))
 
-    def __init__(self, sysm, f, g, blocks, dist, engine=None, comm=None, quiet=True, native=True, pre=None):
+    def __init__(self, sysm, f, g, blocks, dist, engine=None, comm=None, quiet=True, native=True, pre=None, plan=None):
         """`native=False` keeps the Python-driven schedule even when `comm` is an `RcclComm` (its
         collectives are then single ctypes calls into librccl between the device phases).
         `pre="amg"`: preA = the V-cycle with replicated coarse levels (`DistributedAMG`), applied inside the
         native loop (needs the RCCL communicator: the cycle's exchanges and its coarse all-reduce are issued
-        from C); `pre="amg+bjac"` adds the block Jacobi (additive MypreA)."""
+        from C); `pre="amg+bjac"` adds the block Jacobi (additive MypreA).
+        `plan`: "compact" (default; NSS_DIST_PLAN overrides) = C1 / preA / exchange / C23 / sum / all-reduce / C4 /
+        sum / all-reduce with every ghost kept by recurrence behind the owned entries of its vector; "classic" = the
+        eight-phase form (the only one with the interior / boundary overlap)."""
         import contextlib
         self.want_native = bool(native)
         import io
@@ -587,11 +646,18 @@ class DistributedBpcg2:
         self.sol = BlockVector([Vector(ops.n_u, engine=self.engine), Vector(ops.n_p, engine=self.engine)])
         # operands of the three SpMVs of the loop live in halo-extended buffers
         self.t1, self.t4, self.s1 = ops.A.operand(), ops.B.operand(), ops.BT.operand()
+        plan = plan or os.environ.get("NSS_DIST_PLAN", "compact")
+        if plan not in ("compact", "classic"):
+            raise ValueError("plan must be 'compact' or 'classic'")
+        self.compact = plan == "compact" and ops.compact_layout_ok() and os.environ.get("NSS_GHOST_T4", "1") == "1" \
+            and os.environ.get("NSS_GHOST_S1", "1") == "1"
+        workspace = dict(t1=self.t1, t4=self.t4, s1=self.s1)
+        if self.compact:       # ghost copies behind the owned entries: s0, w0 like A's operand, w1, t3 like B^T's
+            workspace.update(s0=ops.A.operand(), w0=ops.A.operand(), w1=ops.BT.operand(), t3=ops.BT.operand())
         sink = io.StringIO() if quiet or self.comm.rank != 0 else None
         with (contextlib.redirect_stdout(sink) if sink is not None else contextlib.nullcontext()):
             ses = BpcgSession(Form(ops.A), Form(ops.B), None, fv, gv, ops.preA, ops.preM, sol=self.sol,
-                              initialize=True, inner=ops.inner,
-                              workspace=dict(t1=self.t1, t4=self.t4, s1=self.s1))
+                              initialize=True, inner=ops.inner, workspace=workspace)
         self.k, self.wdn, self.err0 = ses.k, ses.wdn, ses.err0
         self.first_direction = ses.first_direction
         self._attach(dict(u0=ses.u[0], u1=ses.u[1], d0=ses.d[0], d1=ses.d[1], w0=ses.w[0], w1=ses.w[1],
@@ -607,6 +673,7 @@ class DistributedBpcg2:
         self.engine, self.comm, self.ops = ops.engine, ops.comm, ops
         self.k, self.wdn, self.err0 = k, wdn, err0
         self.t1, self.t4, self.s1 = vecs["t1"], vecs["t4"], vecs["s1"]
+        self.compact = False
         self.first_direction = lambda: None
         self._attach(vecs)
         return self
@@ -625,15 +692,24 @@ class DistributedBpcg2:
             handle = C.c_void_p()
             self.engine._check(self.engine.lib.nss_dist_create(comm_handle, self.comm.size, self.comm.rank, C.byref(handle)))
             self._amg_dist_handle = handle
-            self.loop = Bpcg2Loop.try_create(ops.A.local, ops.B.local, ops.BT.local, self.jacobi_part, self.k, ops.preM,
-                                             vecs, distributed=True, dist_amg=dist_amg.native_handle(handle))
+        compact = getattr(self, "compact", False)
+        matB = ops.b_extended() if compact else ops.B.local
+        extra = dict(ghost_rows_b=int(ops.BT.plan.n_ghost)) if compact else {}
+        if dist_amg is not None:
+            self.loop = Bpcg2Loop.try_create(ops.A.local, matB, ops.BT.local, self.jacobi_part, self.k, ops.preM,
+                                             vecs, distributed=True, dist_amg=dist_amg.native_handle(self._amg_dist_handle),
+                                             **extra)
+            self.loop.keep.append(dist_amg)        # the object, not just its raw handle
         else:
-            self.loop = Bpcg2Loop.try_create(ops.A.local, ops.B.local, ops.BT.local, ops.preA, self.k, ops.preM, vecs,
-                                             distributed=True)
+            self.loop = Bpcg2Loop.try_create(ops.A.local, matB, ops.BT.local, ops.preA, self.k, ops.preM, vecs,
+                                             distributed=True, **extra)
         if self.loop is None:
             raise RuntimeError("fused distributed BPCG loop needs the HIP engine and native operands")
         self.halo = {"s1": (ops.BT, self.s1), "t1": (ops.A, self.t1), "t4": (ops.B, self.t4)}
-        self.ghost_mode = os.environ.get("NSS_GHOST_T4", "1") == "1" and self._setup_ghosts()
+        if compact:
+            self.ghost_mode = self._setup_ghosts_compact()
+        else:
+            self.ghost_mode = os.environ.get("NSS_GHOST_T4", "1") == "1" and self._setup_ghosts()
         self.native = None
         # 0: exchange, then one launch per SpMV, all on the compute stream.  1: exchange on a second
         # stream while the interior row blocks are multiplied.  Measured on one GPU at 1/8 of the
@@ -677,9 +753,33 @@ class DistributedBpcg2:
             self.ghost_p_mode = True
         return True
 
+    def _setup_ghosts_compact(self):
+        """nss_bpcg2_t.dist_compact: the ghost copies are the tails of the vectors themselves."""
+        ops, eng, st, v = self.ops, self.engine, self.loop.state, self.vecs
+        n_u, n_p = ops.n_u, ops.n_p
+        for name, mat in (("s0", ops.A), ("w0", ops.A), ("t1", ops.A), ("s1", ops.BT), ("w1", ops.BT), ("t3", ops.BT)):
+            if not (isinstance(v[name], HaloVector) and v[name].plan is mat.plan):
+                raise RuntimeError("compact partitioned plan: %s must be an operand buffer of %s" % (name, "A" if mat is ops.A else "B^T"))
+        self._ghost_minv = eng.from_host(ops.ghost_minv) if ops.ghost_p.size else eng.zeros(1)
+        st.dist_compact = 1
+        st.ghost_mode, st.ghost_n, st.ghost_map = 1, int(ops.A.plan.n_ghost), None
+        st.ghost_s0 = v["s0"].ext.data_ptr() + 8 * n_u
+        st.ghost_w0 = v["w0"].ext.data_ptr() + 8 * n_u
+        st.ghost_p_mode, st.ghost_p_n, st.ghost_b = 1, int(ops.BT.plan.n_ghost), None
+        st.ghost_t3 = v["t3"].ext.data_ptr() + 8 * n_p
+        st.ghost_w1 = v["w1"].ext.data_ptr() + 8 * n_p
+        st.ghost_minv = self._ghost_minv.data_ptr()
+        self.ghost_p_mode = True
+        return True
+
     def _fill_ghosts(self):
         """Initial values of the ghost copies: one exchange each of s0 and w0 over B's halo plan."""
         ops, eng = self.ops, self.engine
+        if getattr(self, "compact", False):      # the vectors are operand buffers: exchange them in place, once
+            v = self.vecs
+            for name, mat in (("s0", ops.A), ("w0", ops.A), ("s1", ops.BT), ("w1", ops.BT)):
+                mat.exchange(v[name])
+            return
         n_own, n_g = ops.B.plan.n_owned, ops.B.plan.n_ghost
         for src, dst in ((self.vecs["s0"], self._ghost_s0), (self.vecs["w0"], self._ghost_w0)):
             eng.copy(src.buf, self._ghost_tmp.buf)
@@ -705,7 +805,7 @@ class DistributedBpcg2:
         ops = self.ops
         interior = interior or {}
         halos = (ops.BT.native_halo(self.s1, interior.get("s1")), ops.A.native_halo(self.t1, interior.get("t1")),
-                 ops.B.native_halo(self.t4, interior.get("t4")))
+                 ops.B.native_halo(self.t4, interior.get("t4")))      # (the compact plan uses the middle one only)
         self.native = (handle, halos)
 
     def close(self):
@@ -713,9 +813,21 @@ class DistributedBpcg2:
             self.engine.lib.nss_dist_destroy(self.native[0])
             self.native = None
 
+    def release(self):
+        """Free the native handles in dependency order: the loop's dist handle, the V-cycle's native handle (it
+        points into the dist handle created for it), then that dist handle."""
+        self.close()
+        amg = getattr(self, "dist_amg", None)
+        if amg is not None and getattr(amg, "_native", None) is not None:
+            amg.engine.lib.nss_dist_amg_destroy(amg._native[0])
+            amg._native = None
+        if getattr(self, "_amg_dist_handle", None) is not None:
+            self.engine.lib.nss_dist_destroy(self._amg_dist_handle)
+            self._amg_dist_handle = None
+
     def __del__(self):
         try:
-            self.close()
+            self.release()
         except Exception:
             pass
 
@@ -731,7 +843,10 @@ class DistributedBpcg2:
             return
         loop, comm = self.loop, self.comm
         for it in range(it_begin, it_end):
-            for kind, what in self.SCHEDULE:
+            for kind, what in (self.SCHEDULE_COMPACT if getattr(self, "compact", False) else self.SCHEDULE):
+                if kind == "cphases":
+                    loop.cphases(what[0], what[1], it)
+                    continue
                 if kind == "halo" and what == "t4" and self.ghost_mode:
                     continue                             # t4's ghosts are derived from t1's in K2
                 if kind == "halo" and what == "s1" and getattr(self, "ghost_p_mode", False):
@@ -745,6 +860,11 @@ class DistributedBpcg2:
                     comm.allreduce_sum_into(loop.scal[8 + what:9 + what], loop.scal[what:what + 1])
 
     PHASE_NAMES = ("K1_BT_preA", "exchange_t1", "K2_A", "K3_B_sum", "allreduce_sKs", "K4_sum", "allreduce_wd", "K5")
+    PHASE_NAMES_COMPACT = ("C1_BT_preA", "exchange_t1", "C23_A_B", "sum_sKs", "allreduce_sKs", "C4_sum", "allreduce_wd",
+                           "unused")
+
+    def phase_names(self):
+        return self.PHASE_NAMES_COMPACT if getattr(self, "compact", False) else self.PHASE_NAMES
 
     def profile(self, it_begin, iterations):
         """Per-phase device times (ms, averaged) of `iterations` further iterations.  Native loop: HIP
@@ -758,12 +878,31 @@ class DistributedBpcg2:
             out = (C.c_double * 8)()
             n = C.c_int32()
             eng._check(eng.lib.nss_dist_profile_end(self.native[0], out, C.byref(n)))
-            return dict(zip(self.PHASE_NAMES, [float(v) for v in out])), n.value
+            return dict(zip(self.phase_names(), [float(v) for v in out])), n.value
         torch = eng.torch
         loop, comm = self.loop, self.comm
         acc = [0.0] * 8
         marks = []
-        for it in range(it_begin, it_begin + iterations):
+        for it in range(it_begin, it_begin + (iterations if getattr(self, "compact", False) else 0)):
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(9)]
+            ev[0].record()
+            loop.cphases("C1", "C1", it)
+            ev[1].record()
+            self.halo["t1"][0].exchange(self.halo["t1"][1])
+            ev[2].record()
+            loop.cphases("C23", "C23", it)
+            ev[3].record()
+            loop.cphases("SUMA", "SUMA", it)
+            ev[4].record()
+            comm.allreduce_sum_into(loop.scal[9:10], loop.scal[1:2])
+            ev[5].record()
+            loop.cphases("C4", "SUMW", it)
+            ev[6].record()
+            comm.allreduce_sum_into(loop.scal[10:11], loop.scal[2:3])
+            ev[7].record()
+            ev[8].record()
+            marks.append(ev)
+        for it in range(it_begin, it_begin + (0 if getattr(self, "compact", False) else iterations)):
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(9)]
             ev[0].record()
             if not getattr(self, "ghost_p_mode", False):
@@ -791,7 +930,7 @@ class DistributedBpcg2:
         for ev in marks:
             for k in range(8):
                 acc[k] += ev[k].elapsed_time(ev[k + 1]) / len(marks)
-        return dict(zip(self.PHASE_NAMES, acc)), len(marks)
+        return dict(zip(self.phase_names(), acc)), len(marks)
 
     def poll(self):
         return self.loop.poll()

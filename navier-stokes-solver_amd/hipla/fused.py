@@ -37,7 +37,7 @@ class Bpcg2State(C.Structure):
                    ("ghost_s0", C.c_void_p), ("ghost_w0", C.c_void_p),
                    ("ghost_p_mode", C.c_int32), ("ghost_p_n", C.c_int32), ("ghost_b", C.c_void_p),
                    ("ghost_t3", C.c_void_p), ("ghost_w1", C.c_void_p), ("ghost_minv", C.c_void_p),
-                   ("local_sums", C.c_int32), ("pre_dist_amg", C.c_void_p)])
+                   ("local_sums", C.c_int32), ("pre_dist_amg", C.c_void_p), ("dist_compact", C.c_int32)])
 
 
 class HaloStruct(C.Structure):
@@ -143,18 +143,20 @@ class Bpcg2Loop:
 
     @classmethod
     def try_create(cls, matA, matB, matBT, preA_unscaled, k, preM, vecs, distributed=False, condensed=None,
-                   dist_amg=None):
+                   dist_amg=None, ghost_rows_b=0):
         """`distributed`: the matrices are the local row blocks of a partitioned run -- their
         column spaces carry halo entries behind the owned ones and t1 / t4 / s1 are the owned
         views of halo-extended buffers (same base pointer).  `condensed`: dict(HT, H, inner) of
-        `SparseMatrix` for a statically condensed form (matA is then the explicit product)."""
+        `SparseMatrix` for a statically condensed form (matA is then the explicit product).
+        `ghost_rows_b` > 0: matB carries that many ghost pressure rows behind the slab's own (the compact
+        partitioned plan, nss_bpcg2_t.dist_compact)."""
         if not (isinstance(matA, SparseMatrix) and isinstance(matB, SparseMatrix) and isinstance(matBT, SparseMatrix)):
             return None
         eng = matA.engine
         if not ENABLED or not _hip(eng):
             return None
-        n_u, n_p = matA.height, matB.height
-        if matBT.height != n_u:
+        n_u, n_p = matA.height, matB.height - int(ghost_rows_b)
+        if matBT.height != n_u or (ghost_rows_b and not distributed):
             return None
         if not distributed and (matA.width != n_u or matB.width != n_u or matBT.width != n_p):
             return None
@@ -183,9 +185,10 @@ class Bpcg2Loop:
                 return None
             if not _extension_is_in_place_safe(condensed["H"]):
                 return None
-        return cls(eng, matA, matB, matBT, pa, k, pm, vecs, condensed, distributed, dist_amg)
+        return cls(eng, matA, matB, matBT, pa, k, pm, vecs, condensed, distributed, dist_amg, n_p)
 
-    def __init__(self, eng, matA, matB, matBT, pa, k, pm, vecs, condensed=None, distributed=False, dist_amg=None):
+    def __init__(self, eng, matA, matB, matBT, pa, k, pm, vecs, condensed=None, distributed=False, dist_amg=None,
+                 n_p=None):
         torch = eng.torch
         self.eng, self.lib = eng, eng.lib
         self.keep = [matA, matB, matBT, vecs, pa, pm, condensed]       # keep device memory alive
@@ -207,7 +210,7 @@ class Bpcg2Loop:
         st.minv = self.minv.data_ptr()
         for name in ("u0", "u1", "d0", "d1", "w0", "w1", "s0", "s1", "z0", "q", "t0", "t1", "t2", "t3", "t4"):
             setattr(st, name, vecs[name].buf.data_ptr())
-        st.n_u, st.n_p = matA.height, matB.height
+        st.n_u, st.n_p = matA.height, (matB.height if n_p is None else int(n_p))
         st.local_sums = 1 if distributed else 0     # the caller all-reduces scal[9], scal[10] into scal[1], scal[2]
         st.pre_dist_amg = dist_amg
         self.keep.append(dist_amg)

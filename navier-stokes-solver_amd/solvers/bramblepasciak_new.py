@@ -97,7 +97,8 @@ class BpcgSession:
                  inner=InnerProduct, workspace=None):
         """``inner`` is the inner product (a row-partitioned run passes the all-reducing one);
         ``workspace`` may pre-allocate ``t1``, ``t4`` and ``s1`` (the SpMV operands of the loop)
-        in halo-extended buffers."""
+        in halo-extended buffers -- and, for the compact partitioned plan, ``s0``, ``w0``, ``w1``, ``t3``
+        (vectors whose ghost copies sit behind their owned entries)."""
         self.blfA = blfA
         self.inner = inner
         workspace = workspace or {}
@@ -131,14 +132,16 @@ class BpcgSession:
             u[:] = 0.0
         d, w, v = rhs.CreateVector(), rhs.CreateVector(), rhs.CreateVector()
         z, z_old, s = rhs.CreateVector(), rhs.CreateVector(), rhs.CreateVector()
-        if "s1" in workspace:
-            s = BlockVector([s[0], workspace["s1"]])
+        if "s1" in workspace or "s0" in workspace:
+            s = BlockVector([workspace.get("s0", s[0]), workspace.get("s1", s[1])])
+        if "w0" in workspace or "w1" in workspace:
+            w = BlockVector([workspace.get("w0", w[0]), workspace.get("w1", w[1])])
         self.d, self.w, self.v, self.z, self.z_old, self.s = d, w, v, z, z_old, s
 
         t0 = self.t0 = blfA.mat.CreateColVector()
         t1 = self.t1 = workspace["t1"] if "t1" in workspace else blfA.mat.CreateColVector()
         t2 = self.t2 = blfA.mat.CreateColVector()
-        t3 = self.t3 = matB.CreateColVector()
+        t3 = self.t3 = workspace["t3"] if "t3" in workspace else matB.CreateColVector()
         t4 = self.t4 = workspace["t4"] if "t4" in workspace else blfA.mat.CreateColVector()
         self.As0 = blfA.mat.CreateColVector()
         self.BTs1 = matB.CreateRowVector()

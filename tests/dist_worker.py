@@ -89,9 +89,21 @@ def run(rank, world, mode, init_file, out_dir, dim, n, pre, tol, maxsteps):
         res["bpcg1_errors"] = np.array(errs1)
         res["bpcg1_u"] = x1[0].numpy()
     else:
-        run_ = DistributedBpcg2(sysm, f, g, blocks, dist, eng, comm=comm)
+        run_ = DistributedBpcg2(sysm, f, g, blocks, dist, eng, comm=comm)          # compact plan (default)
         it, conv = run_.solve(tol=tol, maxsteps=maxsteps, poll_every=8)
         res["hist"] = run_.history(it)
+        res["compact"] = int(bool(run_.compact))
+        # the same solve on the eight-phase plan: per lane the same arithmetic, so -- where B's launch plan is the
+        # same with and without the ghost pressure rows behind it -- the same bits
+        classic = DistributedBpcg2(sysm, f, g, blocks, dist, eng, comm=comm, plan="classic")
+        it_c, _ = classic.solve(tol=tol, maxsteps=maxsteps, poll_every=5)
+        res["hist_classic"], res["it_classic"] = classic.history(it_c), it_c
+        res["u_classic"], res["p_classic"] = classic.sol[0].numpy(), classic.sol[1].numpy()
+        rb_ext = run_.ops.b_extended().handle.row_blocks()
+        rb_loc = run_.ops.B.local.handle.row_blocks()
+        res["same_plan"] = int(np.array_equal(rb_ext[: rb_loc.size], rb_loc))
+        res["launch_forms"] = np.array([run_.ops.b_extended().handle.info()["lanes_per_row"],
+                                        run_.ops.B.local.handle.info()["lanes_per_row"]])
         res["ghost_mode"] = int(bool(run_.ghost_mode)) + int(bool(getattr(run_, "ghost_p_mode", False)))
         res["it"], res["k"], res["err0"] = it, run_.k, run_.err0
         res["u"], res["p"] = run_.sol[0].numpy(), run_.sol[1].numpy()

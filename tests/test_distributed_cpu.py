@@ -251,3 +251,113 @@ def test_rccl_direct_exchange_issues_the_right_segments():
     comm.exchange(plan, sendbuf, ext)
     assert calls == [("start",), ("send", 1 << 24, 7, 0), ("send", (1 << 24) + 8 * 7, 5, 2),
                      ("recv", base + 8 * 100, 4, 0), ("recv", base + 8 * 104, 6, 2), ("end",)]
+
+
+def _simulated_ranks(s, nranks, engine, blocks=None):
+    """`DistributedStokes` of every rank of an `nranks`-way partition, built in this process.  Two passes: the
+    first records what every rank would contribute to the set-up all-gather of halo requests (call by call: B,
+    A, B^T -- including the extra ghosts A's and B's operands receive for the redundant ghost updates), the
+    second hands every rank the gathered lists, as `TorchComm.gather_requests` would."""
+    from distributed import DistributedStokes
+    recorded = [[] for _ in range(nranks)]
+
+    def build(rank, replay):
+        class FakeComm:
+            size = nranks
+
+            def __init__(self):
+                self.calls = 0
+
+            def gather_requests(self, mine, compute):
+                k, self.calls = self.calls, self.calls + 1
+                if not replay:
+                    recorded[rank].append(mine)
+                    return [compute(q) for q in range(nranks)]
+                return [recorded[q][k] for q in range(nranks)]
+
+        FakeComm.rank = rank
+        return DistributedStokes(s, blocks, FakeComm(), engine)
+
+    for rank in range(nranks):
+        build(rank, False)
+    return [build(rank, True) for rank in range(nranks)]
+
+
+def _replay_native_exchange(mats, ext, x_global):
+    """Move data exactly as csrc/dist.hip::exchange would from the `nss_halo_t` descriptors of every rank
+    (`mats[r]`: the rank's DistSparseMatrix, `ext[r]`: its operand buffer [owned | ghosts]): per rank the sends in
+    descriptor order out of ext (direct) or out of the packed buffer, matched to the receiver's descriptor entry
+    of that peer.  Returns nothing; fills the ghost tails of `ext`."""
+    import ctypes as C
+
+    def arr(ptr, n, ct):
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ct)), shape=(n,)).copy() if n else np.zeros(0, dtype=np.int64)
+
+    desc = []
+    for r, m in enumerate(mats):
+        hv = m.operand()
+        hv.ext[:] = ext[r]
+        h = m.native_halo(hv, interior=(0, 0))
+        desc.append(dict(direct=h.direct, n_pack=h.n_pack,
+                         sp=arr(h.h_send_peer, h.n_send, C.c_int32), so=arr(h.h_send_off, h.n_send, C.c_int64),
+                         sc=arr(h.h_send_cnt, h.n_send, C.c_int64), rp=arr(h.h_recv_peer, h.n_recv, C.c_int32),
+                         ro=arr(h.h_recv_off, h.n_recv, C.c_int64), rc=arr(h.h_recv_cnt, h.n_recv, C.c_int64),
+                         keep=h))
+    wire = {}
+    for r, (m, d) in enumerate(zip(mats, desc)):
+        src = ext[r] if d["direct"] else ext[r][m.plan.send_idx]        # pack kernel: sendbuf[i] = ext[send_idx[i]]
+        assert d["direct"] or d["n_pack"] == m.plan.send_idx.size
+        for peer, off, cnt in zip(d["sp"], d["so"], d["sc"]):
+            assert (r, int(peer)) not in wire                             # one message per ordered pair
+            wire[(r, int(peer))] = src[int(off): int(off) + int(cnt)].copy()
+    for r, (m, d) in enumerate(zip(mats, desc)):
+        for peer, off, cnt in zip(d["rp"], d["ro"], d["rc"]):
+            msg = wire.pop((int(peer), r))
+            assert msg.size == int(cnt) and int(off) >= m.plan.n_owned
+            ext[r][int(off): int(off) + int(cnt)] = msg
+    assert not wire                                                       # every send has its receive
+
+
+@pytest.mark.parametrize("nranks", [2, 3, 8])
+def test_native_halo_descriptors_move_the_right_entries(numpy_engine, nranks):
+    """What the C loops hand to RCCL (`nss_halo_t`: send_off / cnt / peer, recv_off into the ext layout) for
+    simulated ranks 0..R-1, replayed in numpy: afterwards every ghost tail holds the owner's entries -- for A's,
+    B's and B^T's operands -- so that a multi-GPU run only has to confirm transport, not indexing.  Also the
+    renumbered matrices the native loops multiply those buffers with: B in the layout of A's operand (MINRES,
+    BPCG v1) and B with the ghost pressure rows behind its own (compact BPCG v2 plan)."""
+    from distributed import b_in_layout_of_a
+    s = mac_stokes(3, 16, 0.01)
+    ranks = _simulated_ranks(s, nranks, numpy_engine)
+    rng = np.random.default_rng(11)
+    xu, xp = rng.standard_normal(s.n_u), rng.standard_normal(s.n_p)
+    vel, prs = ranks[0].vel, ranks[0].prs
+    for name, xg, offs in (("A", xu, vel), ("B", xu, vel), ("BT", xp, prs)):
+        mats = [getattr(o, name) for o in ranks]
+        ext = []
+        for r, m in enumerate(mats):
+            e = np.full(m.plan.n_owned + m.plan.n_ghost, np.nan)
+            e[: m.plan.n_owned] = xg[offs[r]: offs[r + 1]]
+            ext.append(e)
+        _replay_native_exchange(mats, ext, xg)
+        for r, m in enumerate(mats):
+            np.testing.assert_array_equal(ext[r][m.plan.n_owned:], xg[m.plan.ghosts])
+            # ... and the local block times the filled buffer is the global product on the slab
+            rows = slice(int(m.row_offsets[r]), int(m.row_offsets[r + 1]))
+            glob = {"A": s.A, "B": s.B, "BT": s.B.T.tocsr()}[name]
+            np.testing.assert_allclose(m.local_scipy @ ext[r], (glob @ xg)[rows], rtol=1e-13, atol=1e-13)
+        if name == "A":
+            ext_a = ext
+    for r, o in enumerate(ranks):
+        # B's slab with its columns renumbered into A's operand layout multiplies A's buffer
+        b_on_a = b_in_layout_of_a(o.A, o.B, numpy_engine).to_scipy()
+        np.testing.assert_allclose(b_on_a @ ext_a[r], (s.B @ xu)[prs[r]: prs[r + 1]], rtol=1e-13, atol=1e-13)
+        # compact plan: [owned pressure rows | ghost pressure rows], same layout, same entry order per row
+        assert o.compact_layout_ok()
+        b_ext = o.b_extended_scipy()
+        assert b_ext.shape == (o.n_p + o.BT.plan.n_ghost, o.A.plan.n_owned + o.A.plan.n_ghost)
+        want = (s.B @ xu)[np.concatenate([np.arange(prs[r], prs[r + 1]), o.BT.plan.ghosts])]
+        np.testing.assert_allclose(b_ext @ ext_a[r], want, rtol=1e-13, atol=1e-13)
+        own = b_ext[: o.n_p]
+        np.testing.assert_array_equal(own.indptr, o.B.local_scipy.indptr)
+        np.testing.assert_array_equal(own.data, o.B.local_scipy.data)      # owned/ghost order is kept: same row sums bit for bit
+        np.testing.assert_array_equal(own.indices, b_on_a.indices)

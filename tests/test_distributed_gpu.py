@@ -72,6 +72,13 @@ def test_fused_distributed_loop_matches_single_gpu(hip_engine, world, dim, n, pr
     ranks = launch(world, "gpu", dim, n, pre, tol, maxsteps)
     for d in ranks:
         assert int(d["ghost_mode"]) == 2      # one halo exchange per iteration: t4's and s1's ghosts are kept locally
+        assert int(d["compact"]) == 1         # ... on the compact plan: 6 launches + 3 collectives per iteration
+        # compact plan == eight-phase plan, bit for bit (same launch plan of the owned rows of B in both)
+        assert int(d["same_plan"]) == 1 and d["launch_forms"][0] == d["launch_forms"][1]
+        assert int(d["it_classic"]) == int(d["it"])
+        np.testing.assert_array_equal(d["hist_classic"], d["hist"])
+        np.testing.assert_array_equal(d["u_classic"], d["u"])
+        np.testing.assert_array_equal(d["p_classic"], d["p"])
         assert abs(d["k"] - ref["k"]) < 1e-9 * ref["k"]
         assert abs(d["err0"] - ref["err0"]) < 1e-10 * ref["err0"]
         assert d["err_AxBTp"] < 1e-12 and d["err_Bx"] < 1e-12
@@ -173,9 +180,11 @@ def test_native_partitioned_loop_split_and_streams_single_rank(hip_engine, tmp_p
     dist.init_process_group("gloo", init_method="file://" + str(tmp_path / "rdv"), rank=0, world_size=1)
     try:
         comm = RcclComm(dist, hip_engine)
-        for overlap, interior in [(0, None), (1, None), (2, None), (2, "middle"), (2, "empty")]:
-            run = DistributedBpcg2(s, f, g, s.line_blocks(3), dist, hip_engine, comm=comm)
-            assert run.native is not None
+        for overlap, interior in [("compact", None), (0, None), (1, None), (2, None), (2, "middle"), (2, "empty")]:
+            plan = "compact" if overlap == "compact" else "classic"      # the overlap modes belong to the eight-phase plan
+            overlap = 0 if overlap == "compact" else overlap
+            run = DistributedBpcg2(s, f, g, s.line_blocks(3), dist, hip_engine, comm=comm, plan=plan)
+            assert run.native is not None and run.compact == (plan == "compact")
             if interior is not None:
                 nbs = {k: m.local.handle.info()["row_blocks"] for k, m in (("s1", run.ops.BT), ("t1", run.ops.A),
                                                                             ("t4", run.ops.B))}
@@ -213,25 +222,27 @@ def test_native_loop_profile_and_frozen_scalars_single_rank(hip_engine, tmp_path
     dist.init_process_group("gloo", init_method="file://" + str(tmp_path / "rdv"), rank=0, world_size=1)
     try:
         comm = RcclComm(dist, hip_engine)
-        for native in (True, False):
-            run = DistributedBpcg2(s, f, g, s.line_blocks(3), dist, hip_engine, comm=comm, native=native)
+        for plan, native in (("compact", True), ("compact", False), ("classic", True), ("classic", False)):
+            run = DistributedBpcg2(s, f, g, s.line_blocks(3), dist, hip_engine, comm=comm, native=native, plan=plan)
             assert (run.native is not None) == native
             run.start(tol=0.0, maxsteps=64)
             run.iterate(0, 8)
             phases, n = run.profile(8, 12)
-            assert n == 12 and set(phases) == set(run.PHASE_NAMES)
-            assert all(v >= 0.0 for v in phases.values()) and phases["K2_A"] > 0.0 and phases["K4_sum"] > 0.0
+            assert n == 12 and set(phases) == set(run.phase_names())
+            busy = ("C23_A_B", "C4_sum") if plan == "compact" else ("K2_A", "K4_sum")
+            assert all(v >= 0.0 for v in phases.values()) and all(phases[b] > 0.0 for b in busy)
             assert sum(phases.values()) < 50.0                                 # ms per iteration: sane
-        run = DistributedBpcg2(s, f, g, s.line_blocks(3), dist, hip_engine, comm=comm)
-        it, conv = run.solve(tol=1e-6, maxsteps=4000, poll_every=16)
-        assert conv
-        before = hip_engine.to_host(run.loop.scal).copy()
-        hist_before = run.history(it).copy()
-        run.iterate(it + 1, it + 20)                                           # all no-ops on the device
-        done, it_final, _ = run.poll()
-        assert done and it_final == it
-        np.testing.assert_array_equal(hip_engine.to_host(run.loop.scal), before)
-        np.testing.assert_array_equal(run.history(it), hist_before)
+        for plan in ("compact", "classic"):
+            run = DistributedBpcg2(s, f, g, s.line_blocks(3), dist, hip_engine, comm=comm, plan=plan)
+            it, conv = run.solve(tol=1e-6, maxsteps=4000, poll_every=16)
+            assert conv
+            before = hip_engine.to_host(run.loop.scal).copy()
+            hist_before = run.history(it).copy()
+            run.iterate(it + 1, it + 20)                                       # all no-ops on the device
+            done, it_final, _ = run.poll()
+            assert done and it_final == it
+            np.testing.assert_array_equal(hip_engine.to_host(run.loop.scal), before)
+            np.testing.assert_array_equal(run.history(it), hist_before)
         comm.close()
     finally:
         dist.destroy_process_group()
