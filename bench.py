@@ -60,6 +60,12 @@ def parse_args():
                          "(12 -> ~84 nnz per row as the reference's order-2 3-D spaces); preA = facet blocks")
     ap.add_argument("--cpu-iters", type=int, default=-1, help="oracle iterations to time (-1: auto, 0: skip)")
     ap.add_argument("--kernel-reps", type=int, default=30)
+    ap.add_argument("--windows", type=int, default=5,
+                    help="consecutive timed windows of --steps iterations each; `value` is their median "
+                         "(a single ~0.1-s window cannot separate a 3 %% change from noise), all reported as window_values")
+    ap.add_argument("--secondary", type=int, default=1,
+                    help="1: also time the other BASELINE configurations (cfg2 MINRES, cfg3 BPCG v2) and MINRES / BPCG v1 "
+                         "at the headline size through their entry points (`secondary_configs`); 0 skips them")
     ap.add_argument("--hdg", type=int, default=36,
                     help="grid of the secondary HDG-like measurement (facet blocks of 12 dofs, ~84 non-zeros per "
                          "row: the reference's row regime, SURVEY.md A7); 0 skips it")
@@ -125,6 +131,76 @@ def hdg_like_roofline(torch, eng, grid, reps=40):
 class Form:
     def __init__(self, mat):
         self.mat, self.condense = mat, False
+
+
+def entry_point_rates(torch, hipla, sysm, A, B, preA, solvers, k1, k2):
+    """Iterations / second of the fused loops THROUGH THEIR DROP-IN ENTRY POINTS (set-up, polling and all): each
+    solver runs k1 and k2 iterations with the stop test disabled (tolerance 0); the difference of the two wall
+    times cancels the set-up (scale factor, initial residuals).  Returns {solver: {...}}."""
+    import contextlib
+    import io
+    from bramble_pasciak_cg import bramble_pasciak_cg
+    from minres import MinRes
+    from solvers.bramblepasciak_new import BramblePasciakCG
+    f, g = sysm.rhs(0)
+    preS = hipla.DiagonalMatrix(1.0 / sysm.mass)
+    fv, gv = hipla.Vector.from_numpy(f), hipla.Vector.from_numpy(g)
+
+    def v2(k):
+        sol = hipla.BlockVector([hipla.Vector(sysm.n_u), hipla.Vector(sysm.n_p)])
+        BramblePasciakCG(Form(A), Form(B), None, fv, gv, preA, preS, sol, tol=0.0, maxsteps=k, printrates=False)
+
+    def v1(k):
+        bramble_pasciak_cg(A, B, None, preA, preS, fv, gv, tolerance=0.0, max_steps=k, print_rates=False)
+
+    def mr(k):
+        K = hipla.BlockMatrix([[A, B.T], [B, None]])
+        Cm = hipla.BlockMatrix([[preA, None], [None, preS]])
+        MinRes(mat=K, pre=Cm, rhs=hipla.BlockVector([fv, gv]), maxsteps=k, tol=0.0, printrates=False)
+
+    def timed(fn, k):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+            fn(k)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    table = {"bpcg_v2": (v2, "solvers/bramblepasciak_new.BramblePasciakCG", 3),
+             "bpcg_v1": (v1, "bramble_pasciak_cg.bramble_pasciak_cg", 6), "minres": (mr, "minres.MinRes", 3)}
+    out = {}
+    for name in solvers:
+        fn, entry, spmv = table[name]
+        timed(fn, 10)                                        # warm-up: transposes, workspaces
+        t1 = min(timed(fn, k1) for _ in range(2))
+        t2 = min(timed(fn, k2) for _ in range(2))
+        per = (t2 - t1) / (k2 - k1)
+        out[name] = {"entry_point": entry, "iters_per_s": 1.0 / per, "us_per_iteration": 1e6 * per,
+                     "spmv_per_iteration": spmv, "iterations_timed": [k1, k2]}
+    return out
+
+
+def secondary_configs(torch, hipla, headline=None):
+    """The other BASELINE.json configurations that fit one GPU in a second each -- cfg2 (stokes_hcurldiv.py restated:
+    2-D n=183, ~1e5 DoF, MINRES) and cfg3 (NavierStokesSIMPLE_test.py restated: 2-D n=577, ~1e6 DoF, BPCG v2) --
+    and, on the headline matrices (`headline` = (sysm, A, B, preA)), MINRES and BPCG v1: all three fused loops at
+    all sizes, timed by the driver's own run (block-Jacobi bs=3 preA, lumped-mass preS)."""
+    from staggered_grid import mac_stokes
+    out = {}
+    if headline is not None:
+        sysm, A, B, preA = headline
+        out["cfg4_other_solvers"] = {"workload": "headline matrices (%d DoF)" % sysm.ndof,
+                                     **entry_point_rates(torch, hipla, sysm, A, B, preA, ("minres", "bpcg_v1"), 50, 350)}
+    for name, dim, n, solvers, ref in (("cfg2", 2, 183, ("minres", "bpcg_v2"), "stokes_hcurldiv.py 2D, MINRES, ~1e5 DoF"),
+                                       ("cfg3", 2, 577, ("bpcg_v2", "minres"), "templates/NavierStokesSIMPLE_test.py 2D, BPCG, ~1e6 DoF")):
+        sysm = mac_stokes(dim, n, 0.01)
+        A, B = hipla.SparseMatrix.from_scipy(sysm.A), hipla.SparseMatrix.from_scipy(sysm.B)
+        preA = hipla.BlockJacobi(A, sysm.line_blocks(3))
+        out[name] = {"workload": "%s restated: %d-D MAC Stokes n=%d, %d DoF" % (ref, dim, n, sysm.ndof),
+                     **entry_point_rates(torch, hipla, sysm, A, B, preA, solvers, 500, 4500)}
+        del A, B, preA
+        torch.cuda.empty_cache()
+    return out
 
 
 def pmc_traffic(kernel_substring, workload_args):
@@ -268,7 +344,8 @@ def main():
     info = eng.device_info()
     quiet = contextlib.redirect_stdout(sys.stderr)      # stdout carries the ONE JSON line only
     K, W = args.steps, args.warmup
-    total_its = W + K
+    NWIN = max(1, args.windows)          # consecutive timed windows of exactly K steps each; value = their median
+    total_its = W + NWIN * K
 
     t_asm = time.perf_counter()
     sysm = mac_stokes(args.dim, args.n, args.nu)
@@ -365,18 +442,21 @@ def main():
         prof_its = 30
         run.start(tol=0.0, maxsteps=total_its + prof_its)
         run.iterate(0, W)
-        torch.cuda.synchronize()
-        dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        run.iterate(W, total_its)
-        torch.cuda.synchronize()
-        dist.barrier()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        windows = []
+        for w in range(NWIN):                               # each window: K steps, barrier + synchronize on both sides
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run.iterate(W + w * K, W + (w + 1) * K)
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+            windows.append(time.perf_counter() - t0)
+        tt = torch.tensor(windows, dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)           # per window: the slowest rank
+        windows = [float(v) for v in tt.tolist()]
+        elapsed = float(np.median(windows))
         done, _, last = run.poll()
         hist = run.history(total_its - 1)
         ok = (not done) and last == total_its - 1 and bool(np.all(np.isfinite(hist)))
@@ -420,6 +500,8 @@ def main():
                 "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": 1e3 * elapsed / K,
                 "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
                 "data": "synthetic",
+                "timing": "median of %d consecutive windows of %d steps (max over ranks per window)" % (NWIN, K),
+                "window_values": [K / w for w in windows],
                 "config": {"workload": "templates/NavierStokesSIMPLE_test_3D.py restated: 3-D MAC Stokes n=%d, "
                                        "%d DoF, BPCG v2, %s preA, row-partitioned over %d GPUs"
                                        % (args.n, sysm.ndof, args.pre, world),
@@ -458,16 +540,19 @@ def main():
         raise RuntimeError("fused BPCG loop unavailable for native operands")
     ses.first_direction()
     probe_its = 48                                           # extra iterations for the in-loop kernel timings
-    loop.start(ses.wdn, ses.err0, 0.0, True, total_its + probe_its)   # tol = 0: never stops inside the run
+    loop.start(ses.wdn, ses.err0, 0.0, True, total_its + 2 * probe_its)   # tol = 0: never stops inside the run
     torch.cuda.synchronize()
     t_setup = time.perf_counter() - t_setup
 
     loop.enqueue(0, W)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    loop.enqueue(W, total_its)
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    windows = []
+    for w in range(NWIN):                                   # each window: exactly K steps between two synchronisations
+        t0 = time.perf_counter()
+        loop.enqueue(W + w * K, W + (w + 1) * K)
+        torch.cuda.synchronize()
+        windows.append(time.perf_counter() - t0)
+    elapsed = float(np.median(windows))
     done, _, last = loop.poll()
     hist = loop.history(total_its - 1)
     valid = (not done) and last == total_its - 1 and bool(np.all(np.isfinite(hist)))
@@ -490,6 +575,9 @@ def main():
     names = ("C1", "C23", "SUMA", "C4", "SUMW")
     phase_ms = dict.fromkeys(names, 0.0)
     marks = []
+    xs, ys = eng.zeros(sysm.n_u), eng.zeros(sysm.n_u)
+    xs.fill_(1.0)
+    spmv_marks = []
     for it in range(total_its, total_its + probe_its):
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(len(names) + 1)]
         ev[0].record()
@@ -497,6 +585,16 @@ def main():
             loop.cphases(name, name, it)
             ev[k + 1].record()
         marks.append(ev)
+    # the plain y = A x launch in the loop's cache state: between two whole iterations (it finds the caches as the
+    # A rows of C23 find them behind C1 + preA), never back to back with itself; a second stretch of iterations so
+    # that the phase timings above are not disturbed by it
+    for it in range(total_its + probe_its, total_its + 2 * probe_its):
+        loop.cphases("C1", "SUMW", it)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        eng.csr_spmv(A.handle, 1.0, xs, 0.0, ys)
+        e1.record()
+        spmv_marks.append((e0, e1))
     torch.cuda.synchronize()
     skip = 8                                                 # event creation, clocks
     for ev in marks[skip:]:
@@ -504,9 +602,8 @@ def main():
             phase_ms[name] += ev[k].elapsed_time(ev[k + 1]) / (len(marks) - skip)
     k1_ms, k2_ms, k4_ms = phase_ms["C1"], phase_ms["C23"], phase_ms["C4"]
     sums_ms = phase_ms["SUMA"] + phase_ms["SUMW"]
-    xs, ys = eng.zeros(sysm.n_u), eng.zeros(sysm.n_u)
-    xs.fill_(1.0)
-    spmv_ms = event_time_ms(torch, lambda: eng.csr_spmv(A.handle, 1.0, xs, 0.0, ys), reps)
+    spmv_ms = sum(a.elapsed_time(b) for a, b in spmv_marks[skip:]) / (len(spmv_marks) - skip)
+    spmv_b2b_ms = event_time_ms(torch, lambda: eng.csr_spmv(A.handle, 1.0, xs, 0.0, ys), reps)
     ntri = 1 << 26
     ta, tb, tc = eng.zeros(ntri), eng.zeros(ntri), eng.zeros(ntri)
     triad_ms = event_time_ms(torch, lambda: eng.stream_triad(0.5, ta, tb, tc), reps)
@@ -561,6 +658,12 @@ def main():
 
     hdg = None
     scale_k, folds = ses.k, loop.folds_sums()
+    secondary = None
+    if args.secondary and args.inflate == 1 and args.pre == "bjac3":
+        try:                                                # secondary measurements must never cost the headline line
+            secondary = secondary_configs(torch, hipla, (sysm, A, B, preA))
+        except Exception as exc:
+            secondary = {"error": repr(exc)}
     if args.hdg > 0 and args.inflate == 1:
         del ses, loop, sol, A, B, preA                      # the headline system's device memory
         torch.cuda.empty_cache()
@@ -575,6 +678,8 @@ def main():
         "metric": "Krylov iters/sec, 3D SIMPLE Stokes solve (BPCG)", "value": K / elapsed, "unit": "iters/s",
         "n_gpus": 1, "steps": K, "warmup": W, "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "timing": "median of %d consecutive windows of %d steps" % (NWIN, K),
+        "window_values": [K / w for w in windows],
         "config": {"workload": "templates/NavierStokesSIMPLE_test_3D.py restated: %d-D MAC Stokes n=%d, %d DoF, "
                                "BPCG v2 (solvers/bramblepasciak_new.py), %s preA, lumped-mass preM, Re=%g"
                                % (args.dim, args.n, sysm.ndof, args.pre, 1.0 / args.nu),
@@ -608,11 +713,15 @@ def main():
                      "timing": "HIP events around the kernel inside %d iterations of the running loop" % (probe_its - 8)},
         "cpu_baseline": cpu,
         "roofline_hdg_like": hdg,
+        "secondary_configs": secondary,
         "valid": valid,
-        "hbm_GBs": {"whole_iteration_algorithmic": iter_gbs, "stream_triad": triad_gbs, "spmv_A_plain": spmv_gbs,
+        "hbm_GBs": {"whole_iteration_algorithmic": iter_gbs, "stream_triad": triad_gbs,
+                    "spmv_A_plain_in_loop_cache_state": spmv_gbs,
+                    "spmv_A_plain_back_to_back_cache_flattered": a_info["algorithmic_bytes"] / (spmv_b2b_ms * 1e-3) / 1e9,
                     "spmv_AB_fused_C23": k2_gbs},
         "kernel_ms": {"C1_BT_preA": k1_ms, "C23_A_B": k2_ms, "C4_update": k4_ms, "sum_kernels": sums_ms,
-                      "spmv_A_plain": spmv_ms, "triad_1.6GB": triad_ms},
+                      "spmv_A_plain_in_loop_cache_state": spmv_ms, "spmv_A_plain_back_to_back": spmv_b2b_ms,
+                      "triad_1.6GB": triad_ms},
         "launches_per_iteration": {"sums_folded_into_consumers": folds},
         "bytes_per_iteration": iter_bytes,
         "parity": parity,

@@ -14,6 +14,12 @@ solvers/bramblepasciak_new.py) run over the protocol layer with numpy arithmetic
 
 Each function cites the reference lines it follows.  Operands: scipy CSR ``A``
 (n_u x n_u), ``B`` (n_p x n_u); ``pre_a`` / ``pre_s`` are callables ``x -> P x``.
+
+``mypre_a`` / ``auxiliary_space_term`` (MypreA.Mult, templates/NavierStokesSIMPLE_iterative.py:375-383) and
+``do_time_step`` / ``project`` / ``upwind_convection`` (:424-443) restate the reference's statements over
+the staggered-grid operators; the reference holds no fixture for them and their FE operands (facet blocks,
+h1amg, BDDC, the HDG convection form) are NGSolve's: **parity unpinned** -- they are checked against their own
+algebraic identities in ``tests/test_oracle_golden.py`` and are what the GPU path is compared with.
 """
 
 from math import sqrt
@@ -88,6 +94,103 @@ def symmetric_block_gauss_seidel(A, idx):
         y = block_gauss_seidel_sweep(A, idx, x, np.zeros(A.shape[0]), backward=False)
         return block_gauss_seidel_sweep(A, idx, x, y, backward=True)
     return apply
+
+
+def auxiliary_space_term(transform, laplacians, ranges, component_solve=None):
+    """``transform @ preAh1 @ transform.T`` with ``preAh1 = sum_c emb_c @ pre_c @ emb_c.T``
+    (templates/NavierStokesSIMPLE_iterative.py:334-337,353-357 as used at :380,:383): ``transform`` maps the
+    stacked per-component auxiliary (nodal) spaces to the velocity dofs, ``ranges[c]`` are the dofs of
+    component c inside the stacked space (``Embedding(fesh1.ndof, fesh1.Range(c))``), ``pre_c`` is the
+    component's ``Preconditioner(aH1_c, 'h1amg')``.  Default ``pre_c`` = the exact inverse of the component
+    Laplacian (sparse LU): what an AMG hierarchy that ends on its first level applies, and an operator this file
+    can state without restating NGSolve's upstream hierarchy.  ``component_solve(c)`` may supply another
+    callable per component (e.g. a V-cycle applied as a black box)."""
+    import scipy.sparse.linalg as spl
+    T = sp.csr_matrix(transform)
+    TT = T.T.tocsr()
+    solves = []
+    for c, lap in enumerate(laplacians):
+        solves.append(component_solve(c) if component_solve is not None else spl.splu(sp.csc_matrix(lap)).solve)
+
+    def apply(x):
+        r = TT @ x                                   # transform.T
+        e = np.zeros_like(r)
+        for rng, solve in zip(ranges, solves):       # emb_c @ pre_c @ emb_c.T, summed over the components
+            sl = np.asarray(rng) if not isinstance(rng, (range, slice)) else rng
+            e[sl] = e[sl] + solve(r[sl])
+        return T @ e                                 # transform
+    return apply
+
+
+def mypre_a(A, blocks, aux, gs):
+    """``MypreA.Mult`` (templates/NavierStokesSIMPLE_iterative.py:375-383), statement by statement, with the
+    *sequential* block sweeps of this file: `blocks` (bs, nblocks) in the order the sweep visits them, `aux` =
+    callable for ``transform @ preAh1 @ transform.T`` (None: no auxiliary term).  Returns x -> y."""
+    A = sp.csr_matrix(A)
+    n = A.shape[0]
+    jac = block_jacobi(A, blocks)
+    middle = aux if aux is not None else (lambda r: np.zeros_like(r))
+
+    def apply(x):
+        if gs:
+            y = np.zeros(n)                                                   # :377  y[:] = 0
+            y = block_gauss_seidel_sweep(A, blocks, x, y, backward=False)     # :378  jacobi.Smooth(y, x)
+            temp = x - A @ y                                                  # :379
+            y = y + middle(temp)                                              # :380
+            y = block_gauss_seidel_sweep(A, blocks, x, y, backward=True)      # :381  jacobi.SmoothBack(y, x)
+            return y
+        return middle(x) + jac(x)                                             # :383
+    return apply
+
+
+# --------------------------------------------------------------------------
+# IMEX time step (scope row N4)
+# --------------------------------------------------------------------------
+def upwind_convection(ops, u):
+    """``conv_operator * gfu`` (templates/NavierStokesSIMPLE_iterative.py:106-113,429) on the staggered grid: the
+    weak form of -div(u (x) u) with upwind fluxes = donor-cell fluxes F = adv * avg - |adv| * diff / 2 through the
+    faces of every control volume, conv = -D F.  `ops`: dict of the sparse operators adv, avg, diff, div."""
+    adv, avg, dif = ops["adv"] @ u, ops["avg"] @ u, ops["diff"] @ u
+    return -(ops["div"] @ (adv * avg - 0.5 * np.abs(adv) * dif))
+
+
+def project(B, m_u, vel, solve=None):
+    """``Project(vel)`` (templates/NavierStokesSIMPLE_iterative.py:440-443) on the staggered grid:
+    phi = (B M_u^-1 B^T)^-1 B vel; vel -= M_u^-1 B^T phi.  Direct solve (sparse LU); on an enclosed domain the
+    pressure operator has the constants in its kernel and B vel is orthogonal to them: one pressure is pinned
+    (the correction M_u^-1 B^T phi does not see the constant).  Returns (projected velocity, phi)."""
+    import scipy.sparse.linalg as spl
+    B = sp.csr_matrix(B)
+    bt = (sp.diags(1.0 / m_u) @ B.T).tocsr()
+    L = (B @ bt).tocsc()
+    rhs = B @ vel
+    if solve is not None:
+        phi = solve(rhs)
+    elif np.linalg.norm(L @ np.ones(L.shape[0])) <= 1e-12 * abs(L).sum():
+        keep = np.arange(L.shape[0] - 1)
+        phi = np.zeros(L.shape[0])
+        phi[keep] = spl.splu(sp.csc_matrix(L[keep][:, keep])).solve(rhs[keep])
+    else:
+        phi = spl.splu(L).solve(rhs)
+    return vel - bt @ phi, phi
+
+
+def do_time_step(A, B, m_u, timestep, u, f, conv, solve_mstar=None, solve_proj=None):
+    """``DoTimeStep`` (templates/NavierStokesSIMPLE_iterative.py:424-438), statement by statement:
+    temp = conv(u) + f - A u (:429-431); temp2 = invmstar temp with mstar = M_u + timestep A (:84-85,433);
+    Project(temp2) (:434); u += timestep temp2 (:438).  The reference applies ``invmstar`` and ``invproj`` by
+    inner CG solves (precision 1e-4, :92,130); this restatement solves directly (sparse LU) unless a callable is
+    given.  Returns dict(u=new velocity, temp=..., temp2_unprojected=..., temp2=..., phi=...)."""
+    import scipy.sparse.linalg as spl
+    A = sp.csr_matrix(A)
+    temp = conv(u)                                    # :429
+    temp = temp + f                                   # :430
+    temp = temp + (-(A @ u))                          # :431
+    if solve_mstar is None:
+        solve_mstar = spl.splu((sp.diags(m_u) + timestep * A).tocsc()).solve
+    raw = solve_mstar(temp)                           # :433
+    temp2, phi = project(B, m_u, raw, solve_proj)     # :434
+    return dict(u=u + timestep * temp2, temp=temp, temp2_unprojected=raw, temp2=temp2, phi=phi)   # :438
 
 
 # --------------------------------------------------------------------------

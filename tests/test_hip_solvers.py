@@ -17,6 +17,7 @@ import pytest
 
 from conftest import GOLDEN, golden_path, iteration_tolerance
 from golden_cases import Case
+from oracle import krylov_ref as kr
 from staggered_grid import diffusion_2d, mac_stokes
 
 pytestmark = pytest.mark.gpu
@@ -1129,34 +1130,104 @@ def test_fused_loops_on_unstructured_saddle_systems(hip_engine, seed):
 
 
 def test_time_stepping_on_gpu(hip_engine):
-    """Scope row N4 on the product engine: CGSolver inner solves, Project and DoTimeStep keep the
-    velocity discretely divergence-free and agree with the host computation."""
+    """Scope row N4 on the product engine against the oracle's statement-by-statement `do_time_step`
+    (templates/NavierStokesSIMPLE_iterative.py:424-443; direct sparse solves): with the inner CG solves run to
+    convergence DoTimeStep's right-hand side, its unprojected increment, the projected increment and the new
+    velocity agree to 1e-8; with the reference's inner precision (CGSolver(..., precision=1e-4), :92) the step
+    agrees to that precision; Project leaves a discretely divergence-free field."""
     import hipla
     from templates.NavierStokesSIMPLE_iterative import NavierStokes, SyntheticMesh
-    ns = NavierStokes(SyntheticMesh(0.1, dim=3), nu=0.01, inflow="inlet", outflow="outlet", wall="wall|cyl", uin=None,
-                      timestep=0.05, order=1)
+
+    def fresh():
+        ns = NavierStokes(SyntheticMesh(0.1, dim=3), nu=0.01, inflow="inlet", outflow="outlet", wall="wall|cyl", uin=None,
+                          timestep=0.05, order=1)
+        ns.AddForce(np.random.default_rng(8).standard_normal(ns.system.n_u))
+        return ns
+
+    ns = fresh()
     s = ns.system
+    m_u = np.full(s.n_u, s.h ** s.dim)
     v0 = np.random.default_rng(2).standard_normal(s.n_u)
     vel = hipla.Vector.from_numpy(v0)
     ns.Project(vel)
     assert np.linalg.norm(s.B @ vel.numpy()) < 1e-6 * np.linalg.norm(s.B @ v0)
-    ns.gfu.data = vel
-    u0 = vel.numpy()
+    ref_v, _ = kr.project(s.B, m_u, v0)
+    assert np.linalg.norm(vel.numpy() - ref_v) < 1e-6 * np.linalg.norm(ref_v)      # invproj: CG to 1e-8 (:130)
+    u0 = ref_v
+    cops = s.convection_operators()
+    want = kr.do_time_step(s.A, s.B, m_u, ns.timestep, u0, ns.f.vec.numpy(), lambda u: kr.upwind_convection(cops, u))
+
+    def rel(a, b):
+        return np.linalg.norm(a - b) / np.linalg.norm(b)
+
+    # (i) the reference's inner precision: agreement to that precision
+    ns.gfu.data = hipla.Vector.from_numpy(u0)
     with contextlib.redirect_stdout(io.StringIO()):
         ns.DoTimeStep()
-    import scipy.sparse as sp
-    import scipy.sparse.linalg as spl
-    m_u = np.full(s.n_u, s.h ** s.dim)
-    cops = s.convection_operators()                       # temp = conv(u) + f - A u (:429-431)
-    adv, avg, dif = cops["adv"] @ u0, cops["avg"] @ u0, cops["diff"] @ u0
-    conv = -(cops["div"] @ (adv * avg - 0.5 * np.abs(adv) * dif))
-    t2 = spl.spsolve((sp.diags(m_u) + ns.timestep * s.A).tocsc(), conv + ns.f.vec.numpy() - s.A @ u0)
-    du = (ns.gfu.numpy() - u0) / ns.timestep
+    assert rel(ns.gfu.numpy(), want["u"]) < 1e-4
     assert np.linalg.norm(s.B @ ns.gfu.numpy()) < 1e-5 * np.linalg.norm(ns.gfu.numpy()) * abs(s.B).max()
-    # du is the divergence-free part of t2: their difference is a discrete gradient M_u^-1 B^T phi
-    diff = (t2 - du) * m_u
-    phi = spl.lsqr(s.B.T.tocsr(), diff, atol=1e-12, btol=1e-12)[0]
-    assert np.linalg.norm(s.B.T @ phi - diff) < 5e-3 * np.linalg.norm(diff)
+    # (ii) inner solves run to convergence: every stage of the step against the oracle
+    ns = fresh()
+    ops = ns._time_stepping_operators()
+    ops["invmstar"] = hipla.CGSolver(ops["mstar"], pre=hipla.JacobiPreconditioner(ops["mstar"]), precision=1e-14, maxsteps=5000)
+    ops["invproj"] = hipla.CGSolver(ops["Lp"], pre=hipla.JacobiPreconditioner(ops["Lp"]), precision=1e-14, maxsteps=20000)
+    ns.gfu.data = hipla.Vector.from_numpy(u0)
+    temp = ns.a.mat.CreateColVector()
+    temp.data = ns.conv_operator * ns.gfu                  # :429-431, the statements of DoTimeStep
+    temp.data += ns.f.vec
+    temp.data += -ns.a.mat * ns.gfu
+    assert rel(temp.numpy(), want["temp"]) < 1e-13
+    raw = ns.a.mat.CreateColVector()
+    raw.data = ops["invmstar"] * temp                      # :433
+    assert rel(raw.numpy(), want["temp2_unprojected"]) < 1e-9
+    proj = raw.CreateVector()
+    proj.data = raw
+    ns.Project(proj)                                        # :434
+    assert rel(proj.numpy(), want["temp2"]) < 1e-8
+    with contextlib.redirect_stdout(io.StringIO()):
+        ns.DoTimeStep()
+    assert rel(ns.gfu.numpy(), want["u"]) < 1e-8
+    assert rel((ns.gfu.numpy() - u0) / ns.timestep, want["temp2"]) < 1e-8
+
+
+def test_mypre_a_mult_against_the_oracle(hip_engine):
+    """`MypreA.Mult` on the GPU (multicolour sweeps, native auxiliary-space handle) against the oracle's
+    statement-by-statement `kr.mypre_a` (templates/NavierStokesSIMPLE_iterative.py:375-383; SEQUENTIAL sweeps in
+    the GPU's colour-major block order), 1e-12: (i) with exact component solves the auxiliary term of the oracle
+    is built from sparse LU factorisations of the component Laplacians -- nothing of the product; (ii) with the
+    product's V-cycles the oracle takes the GPU's auxiliary apply as a black box, which pins the order of the five
+    statements of the multiplicative form."""
+    import hipla
+    from templates.NavierStokesSIMPLE_iterative import MypreA, auxiliary_space_preconditioner
+
+    def gpu_apply(op, x, n):
+        y = hipla.Vector(n)
+        op.Mult(hipla.Vector.from_numpy(x), y)
+        return y.numpy()
+
+    for s, blocks in ((mac_stokes(3, 7, 0.01), None), (mac_stokes(2, 10, 0.01).inflate(5), "facet")):
+        blocks = s.line_blocks(3) if blocks is None else s.line_blocks(1)
+        A = hipla.SparseMatrix.from_scipy(s.A)
+        space = s.auxiliary_space()
+        x = np.random.default_rng(12).standard_normal(s.n_u)
+        # (i) exact component solves on both sides
+        transform = hipla.SparseMatrix.from_scipy(space["transform"])
+        comps = [hipla.SmoothedAggregationAMG(hipla.SparseMatrix.from_scipy(lap), coarse_size=10 ** 9)
+                 for lap in space["laplacians"]]
+        assert all(len(c.level_sizes) == 1 for c in comps)
+        aux_gpu = hipla.AuxiliarySpaceAMG(transform, comps)
+        aux_ref = kr.auxiliary_space_term(space["transform"], space["laplacians"], space["ranges"])
+        ya = gpu_apply(aux_gpu, x, s.n_u)
+        assert np.linalg.norm(ya - aux_ref(x)) < 1e-11 * np.linalg.norm(ya)
+        # (ii) the product's V-cycles, applied as a black box inside the oracle's composition
+        _, _, aux_cycles = auxiliary_space_preconditioner(s)
+        for aux, ref_aux, tol in ((aux_gpu, aux_ref, 1e-11), (aux_cycles, lambda r: gpu_apply(aux_cycles, r, s.n_u), 1e-12)):
+            for gs in (True, False):
+                op = MypreA(None, Form(A), blocks, GS=gs, aux=aux)
+                order = op.idx_host if gs else blocks            # the sweep's colour-major block order
+                want = kr.mypre_a(s.A, order, ref_aux, gs)(x)
+                got = gpu_apply(op, x, s.n_u)
+                assert np.linalg.norm(got - want) < tol * np.linalg.norm(want), (s.n_u, gs, tol)
 
 
 def test_fused_cg_solver(hip_engine):

@@ -181,3 +181,78 @@ def test_golden_standin_is_independent_of_the_product():
                 mods = [node.module or ""] if node.level == 0 else []
             for m in mods:
                 assert m.split(".")[0] in allowed, (name, m)
+
+
+def test_oracle_mypre_a_is_the_symmetric_multiplicative_composition():
+    """`kr.mypre_a` (MypreA.Mult, templates/NavierStokesSIMPLE_iterative.py:375-383) against the closed form of
+    what its five statements compose.  GS=True: with the block lower / upper triangles (D + L), (D + U) of A in the
+    block order of the sweep, y = P x has the error propagation I - P A = (I - (D+U)^-1 A)(I - M A)(I - (D+L)^-1 A)
+    (forward sweep, auxiliary correction, backward sweep) and P is symmetric positive definite; GS=False:
+    P = M + J.  M = T (sum_c E_c L_c^-1 E_c^T) T^T built densely here, independently of `kr.auxiliary_space_term`."""
+    s = mac_stokes(2, 7, 0.01)
+    A = s.A.toarray()
+    n = s.n_u
+    blocks = s.line_blocks(3)
+    space = s.auxiliary_space()
+    T = space["transform"].toarray()
+    inner = np.zeros((T.shape[1], T.shape[1]))
+    for lap, rng in zip(space["laplacians"], space["ranges"]):
+        idx = np.arange(rng.start, rng.stop)
+        inner[np.ix_(idx, idx)] = np.linalg.inv(lap.toarray())
+    M = T @ inner @ T.T
+    aux = kr.auxiliary_space_term(space["transform"], space["laplacians"], space["ranges"])
+    x = np.random.default_rng(4).standard_normal(n)
+    np.testing.assert_allclose(aux(x), M @ x, rtol=1e-11, atol=1e-13)
+    # block triangles in the order of the sweep
+    order = [blocks[:, b][blocks[:, b] >= 0] for b in range(blocks.shape[1])]
+    covered = np.concatenate(order)
+    assert np.array_equal(np.sort(covered), np.arange(n))              # the line blocks tile the velocity dofs
+    rank = np.empty(n, dtype=np.int64)
+    for b, dofs in enumerate(order):
+        rank[dofs] = b
+    lower = np.where(rank[:, None] >= rank[None, :], A, 0.0)           # D + L (block lower triangle)
+    upper = np.where(rank[:, None] <= rank[None, :], A, 0.0)           # D + U
+    eye = np.eye(n)
+    E = (eye - np.linalg.solve(upper, A)) @ (eye - M @ A) @ (eye - np.linalg.solve(lower, A))
+    P = (eye - E) @ np.linalg.inv(A)
+    gs = kr.mypre_a(s.A, blocks, aux, True)
+    got = np.column_stack([gs(eye[:, j]) for j in range(n)])
+    np.testing.assert_allclose(got, P, rtol=0, atol=1e-10 * np.abs(P).max())
+    assert np.abs(got - got.T).max() < 1e-10 * np.abs(got).max() and np.linalg.eigvalsh(0.5 * (got + got.T)).min() > 0
+    add = kr.mypre_a(s.A, blocks, aux, False)
+    J = np.column_stack([kr.block_jacobi(s.A, blocks)(eye[:, j]) for j in range(n)])
+    np.testing.assert_allclose(add(x), (M + J) @ x, rtol=1e-11, atol=1e-13)
+    # no auxiliary term: the symmetric sweep of this file
+    np.testing.assert_allclose(kr.mypre_a(s.A, blocks, None, True)(x), kr.symmetric_block_gauss_seidel(s.A, blocks)(x),
+                               rtol=1e-13, atol=1e-15)
+
+
+def test_oracle_time_step_is_the_kkt_solution():
+    """`kr.do_time_step` / `kr.project` (DoTimeStep, Project: templates/NavierStokesSIMPLE_iterative.py:424-443)
+    against one dense solve of what the statements amount to: temp2 is the M_u-orthogonal projection of
+    mstar^-1 (conv(u) + f - A u) onto the discretely divergence-free fields, i.e. the first component of
+    [[M_u, B^T], [B, 0]] [t; phi] = [M_u raw; 0]; the donor-cell convection term against direct loops over
+    the grid is covered in test_drivers_cpu.py."""
+    s = mac_stokes(2, 9, 0.01)
+    rng = np.random.default_rng(6)
+    u0, f = rng.standard_normal(s.n_u), rng.standard_normal(s.n_u)
+    m_u = np.full(s.n_u, s.h ** s.dim)
+    dt = 0.05
+    cops = s.convection_operators()
+    out = kr.do_time_step(s.A, s.B, m_u, dt, u0, f, lambda u: kr.upwind_convection(cops, u))
+    A, B = s.A.toarray(), s.B.toarray()
+    adv, avg, dif = cops["adv"] @ u0, cops["avg"] @ u0, cops["diff"] @ u0
+    rhs = -(cops["div"] @ (adv * avg - 0.5 * np.abs(adv) * dif)) + f - A @ u0
+    np.testing.assert_allclose(out["temp"], rhs, rtol=1e-13, atol=1e-13)
+    raw = np.linalg.solve(np.diag(m_u) + dt * A, rhs)
+    np.testing.assert_allclose(out["temp2_unprojected"], raw, rtol=1e-10, atol=1e-12)
+    # KKT system, pressure determined up to a constant: least-squares solve of the consistent system
+    K = np.block([[np.diag(m_u), B.T], [B, np.zeros((s.n_p, s.n_p))]])
+    sol = np.linalg.lstsq(K, np.concatenate([m_u * raw, np.zeros(s.n_p)]), rcond=None)[0]
+    np.testing.assert_allclose(out["temp2"], sol[:s.n_u], rtol=0, atol=1e-9 * np.abs(raw).max())
+    assert np.linalg.norm(B @ out["temp2"]) < 1e-10 * np.linalg.norm(B @ raw)
+    np.testing.assert_allclose(out["u"], u0 + dt * out["temp2"], rtol=0, atol=1e-15)
+    # Project alone, idempotent
+    v1, _ = kr.project(s.B, m_u, u0)
+    v2, _ = kr.project(s.B, m_u, v1)
+    assert np.linalg.norm(B @ v1) < 1e-10 * np.linalg.norm(B @ u0) and np.linalg.norm(v2 - v1) < 1e-10 * np.linalg.norm(v1)
