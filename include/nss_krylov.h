@@ -143,6 +143,18 @@ NSS_API int nss_csr_index_group(nss_csr_t a, int32_t* entries_per_index);
  * use form 1 of the same matrix); 3 = fixed-width copy of a large matrix with at most two entries per row
  * (B^T of the staggered grid), multiplied by the row-per-lane kernel. */
 NSS_API int nss_csr_operand_form(nss_csr_t a, int32_t* form);
+/* Kernels whose SpMV operand is an expression of TWO stored vectors (the rows of B multiply t1 - s0, the rows of B^T
+ * beta s1 + w1: solvers/bramblepasciak_new.py:212-213, :206 with :240-241 folded in) can take both from LDS copies
+ * ("pair-staged") when the operand runs of every row block hold at most half the LDS buffer.  This re-plans `a` in
+ * place with shorter row blocks (1024 products) when that gets it there -- per-row sums keep their bits, the
+ * dot-product partials are regrouped -- and reports whether the matrix is pair-stageable now.  Set-up only
+ * (synchronises the device); a no-op for matrices that are not staged at all or already qualify. */
+NSS_API int nss_csr_plan_for_pairs(nss_csr_t a, int32_t* pair_staged);
+/* the same question without re-planning */
+NSS_API int nss_csr_pair_staged(nss_csr_t a, int32_t* pair_staged);
+/* process-wide override (tests, measurements): 0 = kernels never take the pair-staged form (they gather through the
+ * window form of the same matrix: same bits), -1 / 1 = wherever a matrix admits it */
+NSS_API int nss_csr_pair_mode(int32_t mode);
 /* matrices created from now on take form 3 from `min_rows` rows on (default 2^21: below, the iteration is
  * launch-bound and the launch a pair of matrices shares is worth more); -1 restores the default.  Same bits
  * either way. */

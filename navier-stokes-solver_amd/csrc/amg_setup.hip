@@ -525,6 +525,7 @@ nss_csr_s* adopt_csr(int32_t m, int32_t n, int64_t nnz, Dev<int32_t>& rowptr, De
   A->nnz = nnz;
   A->rg = rg;
   A->chunk = chunk;
+  if (cuts && ncuts > 0) A->cuts.assign(cuts, cuts + ncuts);
   A->nblk = int32_t(blk.size()) - 1;
   A->rowptr = rowptr.take();
   A->col = col.take();

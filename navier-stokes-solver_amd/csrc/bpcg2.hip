@@ -503,7 +503,11 @@ struct EpiK1c {
     const double* __restrict__ w1;
     double beta;
     bool first;
-    static constexpr bool kStageable = false;   // an expression of two vectors: gathered
+    static constexpr bool kStageable = false;   // an expression of two vectors: gathered, or pair-staged
+    static constexpr bool kStageablePair = true;
+    __device__ const double* ptr() const { return s1; }
+    __device__ const double* ptr2() const { return w1; }
+    __device__ double pair(double s, double w) const { return first ? s : fma(beta, s, w); }
     __device__ double operator()(int c) const { return first ? s1[c] : fma(beta, s1[c], w1[c]); }   // :240-241
   };
   __device__ X xop(const double*) const { return X{s1, w1, beta, it == 0}; }
@@ -595,7 +599,11 @@ struct EpiK3c {
   struct X {
     const double* __restrict__ t1;
     const double* __restrict__ s0;
-    static constexpr bool kStageable = false;   // an expression of two vectors: gathered
+    static constexpr bool kStageable = false;   // an expression of two vectors: gathered, or pair-staged
+    static constexpr bool kStageablePair = true;
+    __device__ const double* ptr() const { return t1; }
+    __device__ const double* ptr2() const { return s0; }
+    __device__ double pair(double a, double b) const { return a - b; }
     __device__ double operator()(int c) const { return t1[c] - s0[c]; }
   };
   __device__ X xop(const double*) const { return X{t1, s0}; }

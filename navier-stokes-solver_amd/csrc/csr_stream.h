@@ -70,6 +70,8 @@ constexpr int kSegMax = 13;
 constexpr int kSegWords = 32;        // descriptor: r0, r1, p0, cnt, nseg, total, pre[1..12], off[0..12], spare
 constexpr int kSegPre = 6, kSegOff = 18;
 
+bool pair_staging_enabled();     // nss_csr_pair_mode (tests, measurements)
+
 struct CsrView {
   const int32_t* __restrict__ rowblk;
   const int32_t* __restrict__ rowptr;
@@ -85,7 +87,8 @@ struct CsrView {
   int32_t nblk;     // row blocks in this launch
   int32_t per_xcd;  // ceil(nblk / 8)
   int32_t mode;     // how the operand is reached: 0 = 4-byte columns, gather; 1 = 16-bit window-relative columns,
-                    // gather; 2 = staged (LDS copy of the row block's operand segments, 16-bit positions)
+                    // gather; 2 = staged (LDS copy of the row block's operand segments, 16-bit positions);
+                    // 3 = pair-staged (the segments of TWO vectors, each in one half of the LDS buffer)
 };
 
 }  // namespace nss
@@ -99,7 +102,9 @@ struct nss_csr_s {
   int32_t* rowblk = nullptr;
   int32_t nblk = 0;
   int32_t rg = 1;
-  int32_t chunk = nss::kChunk;   // products per row block
+  int32_t chunk = nss::kChunk;   // products the kernels' LDS buffer holds (the template parameter CH)
+  int32_t blk_products = nss::kChunk;   // products per row block the launch plan aims at (<= chunk; nss_csr_plan_for_pairs)
+  std::vector<int32_t> cuts;     // row positions no row block spans (kept for re-planning)
   // Compressed column stream: when the columns of every row block fall into at most 16 aligned
   // windows of 4096 columns (grid operators: a row block touches its own grid plane and the two
   // neighbouring ones -- a few narrow clusters far apart) the kernel streams 2 bytes per entry,
@@ -123,6 +128,11 @@ struct nss_csr_s {
   // kernels whose operand is an expression of two vectors (they gather).
   uint16_t* pos16 = nullptr;
   int32_t* blkseg = nullptr;
+  // Pair-staged operand: kernels whose operand is an expression of TWO stored vectors (t1 - s0 in the rows of B,
+  // beta s1 + w1 in the rows of B^T) copy the segments of both -- the first to the lower half of the LDS buffer, the
+  // second to the upper half -- and combine what they read back.  Possible when the segments of every row block hold
+  // at most chunk / 2 columns (`pair_ok`); nss_csr_plan_for_pairs re-plans a matrix with shorter row blocks to get there.
+  bool pair_ok = false;
   // Grouped column stream (block-structured operators: the facet blocks of the HDG-like spaces, ~84
   // non-zeros per row in runs of 12 consecutive columns): when every row length is a multiple of `gb`
   // and every aligned group of `gb` consecutive entries has consecutive columns, col16 / pos16 hold ONE 16-bit
@@ -137,12 +147,17 @@ struct nss_csr_s {
   // passes, the epilogue's loads of each pass behind the previous one's stores).
   int32_t* ell_col = nullptr;
   double* ell_val = nullptr;
-  // `stageable`: the kernel's operand functor can be copied to LDS (XOp::kStageable)
-  int idx_mode(bool stageable = true) const { return (blkseg && stageable) ? 2 : (col16 ? 1 : 0); }
+  // `stageable`: the kernel's operand functor is one stored vector that can be copied to LDS (XOp::kStageable);
+  // `pairable`: it is an expression of two (XOp::kStageablePair)
+  int idx_mode(bool stageable = true, bool pairable = false) const {
+    if (blkseg && stageable) return 2;
+    if (blkseg && pairable && pair_ok && nss::pair_staging_enabled()) return 3;
+    return col16 ? 1 : 0;
+  }
   // launch view of the row blocks [b0, b1)
   nss::CsrView view(int b0, int b1, int mode) const {
     const uint64_t magic = gb > 1 ? ~uint64_t(0) / uint64_t(gb) + 1 : 0;    // ceil(2^64 / gb)
-    return nss::CsrView{rowblk, rowptr, col, mode == 2 ? pos16 : (mode == 1 ? col16 : nullptr), blkbase, blkseg, val,
+    return nss::CsrView{rowblk, rowptr, col, mode >= 2 ? pos16 : (mode == 1 ? col16 : nullptr), blkbase, blkseg, val,
                         uint32_t(gb), uint32_t(nss::kBlock / gb), uint32_t(nss::kBlock % gb), magic, b0, b1 - b0,
                         (b1 - b0 + nss::kXcds - 1) / nss::kXcds, mode};
   }
@@ -158,8 +173,10 @@ void compress_columns(nss_csr_s& A, hipStream_t st);
 bool direct_rows_candidate(int32_t m, const int32_t* rowptr);
 
 // Launch plan of a CSR matrix: lanes per row (*rg_out) and the row-block boundaries (spmv.hip).
+// `products`: products per row block to aim at (<= kChunk; the lanes-per-row choice does not depend on it, so the
+// per-row sums of a re-planned matrix keep their bits)
 void plan_row_blocks(int32_t m, int64_t nnz, const int32_t* rowptr, int32_t* rg_out, int32_t* chunk_out,
-                     std::vector<int32_t>& blk, const int32_t* cuts = nullptr, int ncuts = 0);
+                     std::vector<int32_t>& blk, const int32_t* cuts = nullptr, int ncuts = 0, int products = kChunk);
 
 // Epi interface:
 //   __device__ void row(int r, double ax);          // called once per row by one lane
@@ -212,6 +229,13 @@ struct XPlain {
   __device__ double operator()(int c) const { return x[c]; }
 #endif
 };
+// An operand that is an expression of TWO stored vectors can be pair-staged: ptr() / ptr2() are copied to the two
+// halves of the LDS buffer and pair(a, b) is applied to what is read back (X::kStageablePair, X::ptr2, X::pair).
+template <class X, class = void>
+struct XPairable : std::false_type {};
+template <class X>
+struct XPairable<X, std::enable_if_t<X::kStageablePair>> : std::true_type {};
+
 template <class E, class = void>
 struct EpiX {
   using type = XPlain;
@@ -304,7 +328,16 @@ __device__ __forceinline__ bool csr_phase1(const CsrView& a, const double* __res
   if (!EpiPrologue<Epi>::run(epi, red)) return false;    // uniform over the workgroup
   const XOp xop = EpiX<Epi>::get(epi, x);
   double xv[kPer];
-  if constexpr (IDX == 2) {
+  if constexpr (IDX == 3) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (see IDX == 2)
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      const int p = int(c16[k]) + (GRP ? c[k] : 0);
+      xv[k] = (tid + k * kBlock < cnt) ? xop.pair(prod[p], prod[CH / 2 + p]) : 0.0;
+    }
+    __syncthreads();
+  } else if constexpr (IDX == 2) {
     // LDS-DMA is tracked by vmcnt and gfx950 does not drain it at s_barrier: every wave waits for its own copies
     // before the barrier that publishes them to the other waves.  (hipcc already placed this wait here -- the
     // matrix stream is consumed right behind the barrier -- the statement pins it against code motion.)
@@ -349,6 +382,7 @@ __device__ __forceinline__ void csr_stream_body(const CsrView& a, const double* 
                                                 double* prod, double* red, int32_t* window) {
   using XOp = typename EpiX<Epi>::type;
   static_assert(IDX != 2 || XOp::kStageable, "staged form with an operand that cannot be copied to LDS");
+  static_assert(IDX != 3 || XPairable<XOp>::value, "pair-staged form with an operand that is not a pair of vectors");
   const int tid = threadIdx.x;
   // XCD-aware map: workgroups with equal (index & 7) share an XCD; XCD i owns the i-th
   // contiguous eighth of the row blocks.  One row block per workgroup: a striding
@@ -358,7 +392,7 @@ __device__ __forceinline__ void csr_stream_body(const CsrView& a, const double* 
   const int b = lb < a.nblk ? a.blk0 + lb : -1;
   if (b >= 0) {
     int r0 = 0, r1 = 0, p0 = 0, cnt = 0;
-    if constexpr (IDX == 2) {
+    if constexpr (IDX >= 2) {
       // One descriptor per row block instead of the rowblk -> rowptr chain.  It must arrive through SCALAR loads
       // (the run table then sits in SGPRs); the constant address space makes the loads invariant, and a uniform
       // invariant load is an s_load -- as vector loads (what the compiler emitted in the two-matrix kernel) every
@@ -380,16 +414,35 @@ __device__ __forceinline__ void csr_stream_body(const CsrView& a, const double* 
       for (int s = 0; s < kSegMax - 1; ++s) seg_pre[s] = d[kSegPre + s];
 #pragma unroll
       for (int s = 0; s < kSegMax; ++s) seg_off[s] = d[kSegOff + s];
-      const double* __restrict__ src = EpiX<Epi>::get(epi, x).ptr();
       const int wave = tid / kWave, lane = tid % kWave;
+      if constexpr (IDX == 2) {
+        const double* __restrict__ src = EpiX<Epi>::get(epi, x).ptr();
 #pragma unroll
-      for (int j = 0; j < CH / (2 * kBlock); ++j) {
-        const int base = j * 2 * kBlock + wave * 2 * kWave;
-        const int pos = base + 2 * lane;
-        int o = seg_off[0];
+        for (int j = 0; j < CH / (2 * kBlock); ++j) {
+          const int base = j * 2 * kBlock + wave * 2 * kWave;
+          const int pos = base + 2 * lane;
+          int o = seg_off[0];
 #pragma unroll
-        for (int s = 1; s < kSegMax; ++s) o = pos >= seg_pre[s - 1] ? seg_off[s] : o;
-        if (pos < total) __builtin_amdgcn_global_load_lds((GlobalSrc)(src + pos + o), (LdsDst)(prod + base), 16, 0, 0);
+          for (int s = 1; s < kSegMax; ++s) o = pos >= seg_pre[s - 1] ? seg_off[s] : o;
+          if (pos < total) __builtin_amdgcn_global_load_lds((GlobalSrc)(src + pos + o), (LdsDst)(prod + base), 16, 0, 0);
+        }
+      } else {
+        // pair: total <= CH / 2; the first vector's segments -> prod[0, CH/2), the second's -> prod[CH/2, CH)
+        const XOp x0 = EpiX<Epi>::get(epi, x);
+        const double* __restrict__ src1 = x0.ptr();
+        const double* __restrict__ src2 = x0.ptr2();
+#pragma unroll
+        for (int j = 0; j < CH / (4 * kBlock); ++j) {
+          const int base = j * 2 * kBlock + wave * 2 * kWave;
+          const int pos = base + 2 * lane;
+          int o = seg_off[0];
+#pragma unroll
+          for (int s = 1; s < kSegMax; ++s) o = pos >= seg_pre[s - 1] ? seg_off[s] : o;
+          if (pos < total) {
+            __builtin_amdgcn_global_load_lds((GlobalSrc)(src1 + pos + o), (LdsDst)(prod + base), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((GlobalSrc)(src2 + pos + o), (LdsDst)(prod + CH / 2 + base), 16, 0, 0);
+          }
+        }
       }
     } else {
       r0 = a.rowblk[b];
@@ -598,7 +651,8 @@ inline void launch_csr_stream(const nss_csr_s& A, const double* x, const Epi& ep
     return;
   }
   constexpr bool kCanStage = EpiX<Epi>::type::kStageable;
-  const int mode = A.idx_mode(kCanStage);
+  constexpr bool kCanPair = XPairable<typename EpiX<Epi>::type>::value;
+  const int mode = A.idx_mode(kCanStage, kCanPair);
   const bool grp = mode != 0 && A.gb > 1;
   const CsrView v = A.view(b0, b1, mode);
   const dim3 grid(nss_csr_s::grid(b1 - b0)), block(kBlock);
@@ -607,6 +661,11 @@ inline void launch_csr_stream(const nss_csr_s& A, const double* x, const Epi& ep
     if constexpr (kCanStage) {                                                                                   \
       if (grp) hipLaunchKernelGGL((csr_stream_kernel<N, Epi, 2, CHK, true>), grid, block, 0, st, v, x, epi);     \
       else hipLaunchKernelGGL((csr_stream_kernel<N, Epi, 2, CHK, false>), grid, block, 0, st, v, x, epi);        \
+    }                                                                                                            \
+  } else if (mode == 3) {                                                                                        \
+    if constexpr (kCanPair) {                                                                                    \
+      if (grp) hipLaunchKernelGGL((csr_stream_kernel<N, Epi, 3, CHK, true>), grid, block, 0, st, v, x, epi);     \
+      else hipLaunchKernelGGL((csr_stream_kernel<N, Epi, 3, CHK, false>), grid, block, 0, st, v, x, epi);        \
     }                                                                                                            \
   } else if (mode == 1) {                                                                                        \
     if (grp) hipLaunchKernelGGL((csr_stream_kernel<N, Epi, 1, CHK, true>), grid, block, 0, st, v, x, epi);       \
@@ -631,7 +690,10 @@ inline bool launch_csr_stream_dual(const nss_csr_s& A, const double* xa, const E
   if (A.ell_col || B.ell_col) return false;               // row-per-lane kernel: a launch of its own
   if (A.rg != B.rg || A.chunk != B.chunk) return false;
   constexpr bool kStageA = EpiX<EpiA>::type::kStageable, kStageB = EpiX<EpiB>::type::kStageable;
-  const int ma = A.idx_mode(kStageA), mb = B.idx_mode(kStageB);
+  constexpr bool kPairB = XPairable<typename EpiX<EpiB>::type>::value;
+  const int ma = A.idx_mode(kStageA);
+  int mb = B.idx_mode(kStageB, kPairB);
+  if (mb == 3 && ma != 2) mb = B.col16 ? 1 : 0;           // the pair-staged half is only instantiated beside a staged one
   if ((ma == 0) != (mb == 0)) return false;               // a 4-byte stream only pairs with a 4-byte stream
   const bool grp = ma != 0 && (A.gb > 1 || B.gb > 1);     // the grouped decode also reads a one-per-entry stream (gb == 1)
   const CsrView va = A.view(0, A.nblk, ma), vb = B.view(0, B.nblk, mb);
@@ -646,6 +708,8 @@ inline bool launch_csr_stream_dual(const nss_csr_s& A, const double* xa, const E
     NSS_DUAL_GO(N, CHK, 0, 0, false);                                                       \
   } else if (ma == 2 && mb == 2) {                                                          \
     if constexpr (kStageA && kStageB) { NSS_DUAL_PAIR(N, CHK, 2, 2) }                       \
+  } else if (ma == 2 && mb == 3) {                                                          \
+    if constexpr (kStageA && kPairB) { NSS_DUAL_PAIR(N, CHK, 2, 3) }                        \
   } else if (ma == 2) {                                                                     \
     if constexpr (kStageA) { NSS_DUAL_PAIR(N, CHK, 2, 1) }                                  \
   } else if (mb == 2) {                                                                     \

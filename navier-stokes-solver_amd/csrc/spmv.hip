@@ -21,6 +21,9 @@ constexpr int kMinRowBlocks = 2048;   // 256 CUs x 8 resident workgroups
 // is launch-bound and the one launch a pair of matrices shares (csr_stream_dual_kernel) is worth more.
 static int64_t g_direct_min_rows = NSS_DIRECT_MIN_ROWS;   // nss_csr_direct_rows_threshold() (tests, measurements)
 
+static int g_pair_mode = -1;
+bool pair_staging_enabled() { return g_pair_mode != 0; }
+
 bool direct_rows_candidate(int32_t m, const int32_t* rowptr) {
 #if NSS_DIRECT_ROWS
   if (m < g_direct_min_rows) return false;
@@ -35,10 +38,11 @@ bool direct_rows_candidate(int32_t m, const int32_t* rowptr) {
 }
 
 void plan_row_blocks(int32_t m, int64_t nnz, const int32_t* rowptr, int32_t* rg_out, int32_t* chunk_out,
-                     std::vector<int32_t>& blk, const int32_t* cuts, int ncuts) {
+                     std::vector<int32_t>& blk, const int32_t* cuts, int ncuts, int products) {
   const double mean = m > 0 ? double(nnz) / double(m) : 0.0;
   const int chunk = kChunk;
   *chunk_out = chunk;
+  products = std::max(kBlock, std::min(products, chunk));
   // Lanes per row: the largest power of two for which one reduce pass (kBlock / rg rows) still
   // covers a full chunk of products, i.e. rg ~ mean / 8.  Long rows then fill the LDS chunk
   // (all 8 loads per lane in flight) and every row's bounds and epilogue operands are
@@ -49,7 +53,7 @@ void plan_row_blocks(int32_t m, int64_t nnz, const int32_t* rowptr, int32_t* rg_
   const int rows_per_pass = kBlock / rg;
   int passes = 1;
   if (rg == 1) {
-    passes = mean > 0.0 ? int(double(chunk) / (mean * rows_per_pass)) : kMaxRowsPerBlock / rows_per_pass;
+    passes = mean > 0.0 ? int(double(products) / (mean * rows_per_pass)) : kMaxRowsPerBlock / rows_per_pass;
     passes = std::max(1, passes);
 #if NSS_PLAN_FILL_CHIP
     // small matrices (a slab of a partitioned system, the small configs): rather more, shorter row
@@ -70,7 +74,7 @@ void plan_row_blocks(int32_t m, int64_t nnz, const int32_t* rowptr, int32_t* rg_
     const int32_t limit = ci < ncuts ? std::min<int32_t>(m, cuts[ci]) : m;
     while (r < limit && r - start < row_cap) {
       const int64_t len = int64_t(rowptr[r + 1]) - rowptr[r];
-      if (acc + len > chunk) break;
+      if (acc + len > products) break;
       acc += len;
       ++r;
     }
@@ -152,7 +156,8 @@ __global__ __launch_bounds__(kBlock) void seg_build_kernel(int32_t nblk, const i
                                                             const int32_t* __restrict__ rowptr,
                                                             const int32_t* __restrict__ col, int32_t chunk,
                                                             int32_t ncols, int32_t* __restrict__ desc,
-                                                            uint16_t* __restrict__ pos16, int32_t* __restrict__ nbad) {
+                                                            uint16_t* __restrict__ pos16, int32_t* __restrict__ nbad,
+                                                            int32_t* __restrict__ maxtotal) {
   __shared__ int32_t cols[kChunk];
   __shared__ int32_t hidx[kSegMax];
   __shared__ int32_t sstart[kSegMax], spre[kSegMax];
@@ -235,6 +240,7 @@ __global__ __launch_bounds__(kBlock) void seg_build_kernel(int32_t nblk, const i
     }
     if (fits && acc <= chunk) {
       ok = 1;
+      atomicMax(maxtotal, acc);
       d[4] = nseg;
       d[5] = acc;
       for (int s2 = 1; s2 < nseg; ++s2) d[kSegPre + s2 - 1] = spre[s2];
@@ -360,23 +366,25 @@ static void stage_columns(nss_csr_s& A, hipStream_t st) {
 #if NSS_STAGE_X
   if (A.nnz < int64_t(NSS_STAGE_MIN_MEAN) * A.m) return;
   int32_t* desc = nullptr;
-  int32_t* nbad = nullptr;
+  int32_t* nbad = nullptr;            // [0] row blocks that do not fit, [1] largest number of staged columns of a block
   uint16_t* p16 = nullptr;
+  A.pair_ok = false;
   try {
     NSS_HIP(hipMalloc(&desc, sizeof(int32_t) * size_t(A.nblk) * kSegWords));
-    NSS_HIP(hipMalloc(&nbad, sizeof(int32_t)));
+    NSS_HIP(hipMalloc(&nbad, 2 * sizeof(int32_t)));
     NSS_HIP(hipMalloc(&p16, sizeof(uint16_t) * (size_t(A.nnz) + 8)));
-    NSS_HIP(hipMemsetAsync(nbad, 0, sizeof(int32_t), st));
+    NSS_HIP(hipMemsetAsync(nbad, 0, 2 * sizeof(int32_t), st));
     NSS_HIP(hipMemsetAsync(p16, 0, sizeof(uint16_t) * (size_t(A.nnz) + 8), st));
     hipLaunchKernelGGL(seg_build_kernel, dim3(A.nblk), dim3(kBlock), 0, st, A.nblk, A.rowblk, A.rowptr, A.col, A.chunk,
-                       A.n, desc, p16, nbad);
+                       A.n, desc, p16, nbad, nbad + 1);
     NSS_CHECK_LAUNCH();
-    int32_t h_bad = 0;
-    NSS_HIP(hipMemcpyAsync(&h_bad, nbad, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    int32_t h_bad[2] = {0, 0};
+    NSS_HIP(hipMemcpyAsync(h_bad, nbad, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     NSS_HIP(hipStreamSynchronize(st));
-    if (h_bad == 0) {                 // every row block fits (the staged kernels have no per-block fallback)
+    if (h_bad[0] == 0) {              // every row block fits (the staged kernels have no per-block fallback)
       A.pos16 = p16;
       A.blkseg = desc;
+      A.pair_ok = h_bad[1] <= A.chunk / 2;
       p16 = nullptr;
       desc = nullptr;
     }
@@ -548,6 +556,7 @@ int nss_csr_create_cuts(int32_t nrows, int32_t ncols, int64_t nnz, const int32_t
       A->nnz = nnz;
       std::vector<int32_t> blk;
       plan_row_blocks(nrows, nnz, h_rowptr, &A->rg, &A->chunk, blk, h_cuts, ncuts);
+      A->cuts.assign(h_cuts, h_cuts + ncuts);
       A->nblk = int32_t(blk.size()) - 1;
       NSS_HIP(hipMalloc(&A->rowptr, sizeof(int32_t) * (size_t(nrows) + 1)));
       NSS_HIP(hipMalloc(&A->col, sizeof(int32_t) * (nnz + 4)));   // +4: paired loads may touch one entry past the end
@@ -584,6 +593,62 @@ int nss_csr_destroy(nss_csr_t a) {
     (void)hipFree(a->ell_col);
     (void)hipFree(a->ell_val);
     delete a;
+  });
+}
+
+// new launch plan with at most `products` products per row block; every derived column stream is rebuilt
+static void replan(nss_csr_s& A, int products) {
+  NSS_HIP(hipDeviceSynchronize());                       // no kernel may still read the arrays that go away
+  std::vector<int32_t> h_rowptr(size_t(A.m) + 1);
+  NSS_HIP(hipMemcpy(h_rowptr.data(), A.rowptr, sizeof(int32_t) * h_rowptr.size(), hipMemcpyDeviceToHost));
+  std::vector<int32_t> blk;
+  int32_t rg = 1, chunk = kChunk;
+  plan_row_blocks(A.m, A.nnz, h_rowptr.data(), &rg, &chunk, blk, A.cuts.data(), int(A.cuts.size()), products);
+  int32_t* rowblk = nullptr;
+  NSS_HIP(hipMalloc(&rowblk, sizeof(int32_t) * blk.size()));
+  NSS_HIP(hipMemcpy(rowblk, blk.data(), sizeof(int32_t) * blk.size(), hipMemcpyHostToDevice));
+  for (void* p : {(void*)A.rowblk, (void*)A.col16, (void*)A.blkbase, (void*)A.blkseg, (void*)A.pos16, (void*)A.ell_col,
+                  (void*)A.ell_val})
+    (void)hipFree(p);
+  A.rowblk = rowblk;
+  A.col16 = nullptr;
+  A.blkbase = nullptr;
+  A.blkseg = nullptr;
+  A.pos16 = nullptr;
+  A.ell_col = nullptr;
+  A.ell_val = nullptr;
+  A.gb = 1;
+  A.pair_ok = false;
+  A.rg = rg;                                             // (unchanged: the lanes-per-row rule does not see `products`)
+  A.nblk = int32_t(blk.size()) - 1;
+  A.blk_products = products;
+  compress_columns(A, nullptr);
+}
+
+int nss_csr_plan_for_pairs(nss_csr_t a, int32_t* pair_staged) {
+  return guarded([&] {
+    NSS_REQUIRE(a != nullptr, "csr_plan_for_pairs: NULL matrix");
+    // only matrices the single-operand kernels stage, and not the two-entry-per-row ones of the row-per-lane kernel
+    if (a->blkseg && !a->pair_ok && !a->ell_col && a->blk_products > kChunk / 2) {
+      const int before = a->blk_products;
+      replan(*a, kChunk / 2);
+      if (!a->pair_ok) replan(*a, before);               // wide operators: shorter blocks do not help; back to the full plan
+    }
+    if (pair_staged) *pair_staged = (a->blkseg && a->pair_ok) ? 1 : 0;
+  });
+}
+
+int nss_csr_pair_mode(int32_t mode) {
+  return guarded([&] {
+    NSS_REQUIRE(mode >= -1 && mode <= 1, "csr_pair_mode: -1 (automatic), 0 (never) or 1");
+    g_pair_mode = mode;
+  });
+}
+
+int nss_csr_pair_staged(nss_csr_t a, int32_t* pair_staged) {
+  return guarded([&] {
+    NSS_REQUIRE(a != nullptr && pair_staged != nullptr, "csr_pair_staged: NULL argument");
+    *pair_staged = (a->blkseg && a->pair_ok) ? 1 : 0;
   });
 }
 

@@ -197,6 +197,9 @@ class Bpcg2Loop:
             self.cond_f = eng.zeros(matA.height)
             st.cond_HT, st.cond_H = condensed["HT"].handle.ptr, condensed["H"].handle.ptr
             st.cond_inner, st.cond_f = condensed["inner"].handle.ptr, self.cond_f.data_ptr()
+        # the rows of B multiply t1 - s0 (:212-213): with row blocks short enough both vectors are read from LDS copies
+        self.pair_staged_b = (os.environ.get("NSS_PAIR_STAGE", "1") == "1" and hasattr(matB.handle, "plan_for_pairs")
+                              and matB.handle.plan_for_pairs())
         st.A, st.B, st.BT = matA.handle.ptr, matB.handle.ptr, matBT.handle.ptr
         st.pre_diag = pa["diag"].d.data_ptr() if pa["diag"] is not None else None
         st.pre_bjac = pa["bjac"].handle.ptr if pa["bjac"] is not None else None

@@ -48,6 +48,9 @@ def _signatures():
         "nss_csr_index_width": (C.c_int, [vp, c_i32_p]),
         "nss_csr_index_group": (C.c_int, [vp, c_i32_p]),
         "nss_csr_operand_form": (C.c_int, [vp, c_i32_p]),
+        "nss_csr_plan_for_pairs": (C.c_int, [vp, c_i32_p]),
+        "nss_csr_pair_staged": (C.c_int, [vp, c_i32_p]),
+        "nss_csr_pair_mode": (C.c_int, [i32]),
         "nss_csr_direct_rows_threshold": (C.c_int, [i64]),
         "nss_scratch_trim": (C.c_int, []),
         "nss_stream_loads_mode": (C.c_int, [i32]),
@@ -154,6 +157,18 @@ class _CsrHandle:
         self.engine._check(self.engine.lib.nss_csr_row_blocks(self.ptr, out.ctypes.data, out.size))
         return out
 
+    def plan_for_pairs(self, replan=True):
+        """Re-plan (in place, set-up only) so that kernels whose operand is an expression of two vectors can take both
+        from LDS copies (nss_csr_plan_for_pairs); returns whether the matrix is pair-stageable now.  `replan=False`
+        only asks."""
+        out = C.c_int32()
+        lib = self.engine.lib
+        if not hasattr(lib, "nss_csr_plan_for_pairs"):
+            return False
+        self.engine._check(lib.nss_csr_plan_for_pairs(self.ptr, C.byref(out)) if replan
+                           else lib.nss_csr_pair_staged(self.ptr, C.byref(out)))
+        return bool(out.value)
+
     def info(self):
         lib = self.engine.lib
         m, n, nb, rg = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
@@ -165,7 +180,7 @@ class _CsrHandle:
         form = C.c_int32(width.value == 2)
         if hasattr(lib, "nss_csr_operand_form"):                     # (absent in older A/B builds)
             self.engine._check(lib.nss_csr_operand_form(self.ptr, form))
-        return {"operand_form": ("gather32", "gather16", "staged", "rows")[form.value],
+        return {"operand_form": ("gather32", "gather16", "staged", "rows")[form.value], "pair_staged": self.plan_for_pairs(False),
                 "rows": m.value, "cols": n.value, "nnz": nnz.value, "row_blocks": nb.value,
                 "lanes_per_row": rg.value, "algorithmic_bytes": nbytes.value, "index_bytes": width.value,
                 "index_group": group.value}

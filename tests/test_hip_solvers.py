@@ -559,6 +559,62 @@ def test_compact_plan_equals_eight_phase_form_bit_for_bit(hip_engine, case):
         lib.nss_bpcg2_fold_mode(-1)
 
 
+@pytest.mark.parametrize("dim,n,inflate", [(3, 16, 1), (2, 40, 1), (3, 6, 12)])
+def test_pair_staged_operands_give_identical_bits(hip_engine, dim, n, inflate):
+    """Kernels whose SpMV operand is an expression of two stored vectors -- the rows of B multiply t1 - s0, the rows
+    of B^T beta s1 + w1 (solvers/bramblepasciak_new.py:212-213, :206 + :240-241) -- read both vectors from LDS copies
+    filled by LDS-DMA when the operand runs of every row block fit twice into the LDS buffer
+    (nss_csr_plan_for_pairs re-plans B with 1024-product row blocks to get there).  Same products in the same
+    order: (i) the re-planned matrix multiplies to the same bits as before, (ii) the fused loop with the pair-staged
+    form gives the bits of the same loop gathering through the window form of the same matrices."""
+    import hipla
+    from solvers.bramblepasciak_new import BpcgSession
+    s = mac_stokes(dim, n, 0.01)
+    if inflate > 1:
+        s = s.inflate(inflate)
+    f, g = s.rhs(0)
+    lib = hip_engine.lib
+    x = hipla.Vector.from_numpy(np.random.default_rng(1).standard_normal(s.n_u))
+    B0 = hipla.SparseMatrix.from_scipy(s.B)
+    y0 = hipla.Vector(s.n_p)
+    y0.data = B0 * x
+    blocks_before = B0.handle.info()["row_blocks"]
+
+    def run(nit=30):
+        A, B = hipla.SparseMatrix.from_scipy(s.A), hipla.SparseMatrix.from_scipy(s.B)
+        preA = hipla.BlockJacobi(A, s.line_blocks(3 if inflate == 1 else 1))
+        sol = hipla.BlockVector([hipla.Vector(s.n_u), hipla.Vector(s.n_p)])
+        with contextlib.redirect_stdout(io.StringIO()):
+            ses = BpcgSession(Form(A), Form(B), None, hipla.Vector.from_numpy(f), hipla.Vector.from_numpy(g), preA,
+                              hipla.DiagonalMatrix(1.0 / s.mass), sol=sol)
+        loop = ses.fused
+        ses.first_direction()
+        loop.start(ses.wdn, ses.err0, 0.0, True, nit)
+        loop.enqueue(0, nit)
+        loop.poll()
+        y = hipla.Vector(s.n_p)
+        y.data = B * x                                  # the re-planned B, plain SpMV
+        return loop.history(nit - 1).copy(), sol.numpy(), B.handle.info(), ses.matBT.handle.info(), y.numpy(), loop
+
+    try:
+        assert lib.nss_csr_pair_mode(0) == 0
+        gathered = run()
+        assert lib.nss_csr_pair_mode(-1) == 0
+        paired = run()
+    finally:
+        lib.nss_csr_pair_mode(-1)
+    np.testing.assert_array_equal(paired[4], y0.numpy())                 # (i)
+    np.testing.assert_array_equal(gathered[4], y0.numpy())
+    np.testing.assert_array_equal(paired[0], gathered[0])                # (ii) history
+    np.testing.assert_array_equal(paired[1], gathered[1])                #      solution
+    assert np.all(np.isfinite(paired[0]))
+    b_info, bt_info = paired[2], paired[3]
+    if inflate == 1:                                                      # grid operators: B re-planned and pair-staged
+        assert b_info["operand_form"] == "staged" and b_info["pair_staged"] and paired[5].pair_staged_b
+        assert b_info["row_blocks"] >= blocks_before          # (small systems already have short row blocks)
+        assert bt_info["pair_staged"] or bt_info["operand_form"] == "rows"
+
+
 @pytest.mark.parametrize("case", ["stokes3d_n10_bjac_minres", "stokes2d_n24_jacobi_minres",
                                   "stokes3d_n5_facet_x12_minres"])
 def test_minres_sum_placement_gives_identical_bits(hip_engine, case):
