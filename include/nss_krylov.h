@@ -119,6 +119,17 @@ NSS_API int nss_graph_color(nss_csr_t g, nss_csr_t g_transposed, const int64_t* 
                             int32_t* ncolors_out, nss_stream_t stream);
 NSS_API int nss_csr_select_rows(nss_csr_t a, int32_t nrows, const int32_t* d_rows, int32_t ncuts,
                                 const int32_t* h_cuts, nss_csr_t* out, nss_stream_t stream);
+/* nss_csr_permute: as nss_csr_select_rows, and every column c becomes d_colmap[c] (DEVICE int32[columns of a]; the
+ *   result has ncols_out columns; the entries of a row keep their order); the launch plan additionally keeps at most
+ *   `max_rows` rows per row block (0: no limit) and starts row blocks only at rows with h_row_pos[r] == 0 (HOST
+ *   uint8[nrows] or NULL): rows of one Gauss-Seidel block stay in one workgroup.
+ * nss_graph_color_greedy: first-fit colouring in node order on the HOST (sequential; h_colors: HOST int32[n] out).
+ *   On grid-like block graphs it finds the parity colouring (2 - 4 balanced colours) where the Luby rounds of
+ *   nss_graph_color give 5 - 6 with a tail of tiny ones -- each colour is a launch of the sweep. */
+NSS_API int nss_csr_permute(nss_csr_t a, int32_t nrows, const int32_t* d_rows, const int32_t* d_colmap, int32_t ncols_out,
+                            int32_t ncuts, const int32_t* h_cuts, int32_t max_rows, const uint8_t* h_row_pos,
+                            nss_csr_t* out, nss_stream_t stream);
+NSS_API int nss_graph_color_greedy(nss_csr_t g, nss_csr_t g_transposed, int32_t* h_colors, int32_t* ncolors_out);
 /* the set-up entry points (nss_csr_spgemm, nss_csr_transpose, nss_amg_*) keep their multi-GB
  * temporaries in a pool between calls; this returns the unused ones to the driver */
 NSS_API int nss_scratch_trim(void);
@@ -155,6 +166,18 @@ NSS_API int nss_csr_pair_staged(nss_csr_t a, int32_t* pair_staged);
 /* process-wide override (tests, measurements): 0 = kernels never take the pair-staged form (they gather through the
  * window form of the same matrix: same bits), -1 / 1 = wherever a matrix admits it */
 NSS_API int nss_csr_pair_mode(int32_t mode);
+/* Reuse-aware dispatch order of the staged kernels (grid operators beyond ~1e7 rows; csrc/csr_stream.h: blkdisp): a
+ * matrix whose row blocks re-read operand runs `period` blocks further down the natural order (the next grid plane)
+ * gets a second descriptor table that visits the blocks b, b + P, ..., b + (T - 1) P of T planes back to back.
+ * Only the workgroup -> row block map changes; all bits stay.  nss_csr_dispatch_mode applies to matrices created
+ * afterwards: planes = -2 library default (OFF: measured at 5e7 DoF the tiled walk cuts the bytes fetched through the
+ * L2s from 1.18 x to 1.05 x of the algorithmic reads and is not faster, profiles/r03_ab_dispatch_cfg5.txt), -1
+ * automatic (T = 8 from a period of `min_period` row blocks on; min_period <= 0: 256), 0 never, 1 .. 64 = always with
+ * T = planes; `run` (<= 0: library default) = consecutive row blocks
+ * of one plane before the walk moves on to the next plane.  nss_csr_dispatch_info reports what a matrix got
+ * (period 0: natural order). */
+NSS_API int nss_csr_dispatch_mode(int32_t planes, int32_t min_period, int32_t run);
+NSS_API int nss_csr_dispatch_info(nss_csr_t a, double* period, int32_t* planes);
 /* matrices created from now on take form 3 from `min_rows` rows on (default 2^21: below, the iteration is
  * launch-bound and the launch a pair of matrices shares is worth more); -1 restores the default.  Same bits
  * either way. */
@@ -200,6 +223,15 @@ NSS_API int nss_bjac_info(nss_bjac_t j, int32_t* bs, int32_t* nblocks, int64_t* 
  * h_ridx: int32[bs][nblocks] = permuted row of each block entry (-1 = padding). */
 NSS_API int nss_bjac_set_colors(nss_bjac_t j, nss_csr_t a_perm, int32_t ncolors, const int32_t* h_color_ptr,
                                 const int32_t* h_color_rowptr, const int32_t* h_rowdof, const int32_t* h_ridx);
+/* The same sweeps with the colour-major numbering used INSIDE the sweep as well: `a_perm` = P A P^T from
+ * nss_csr_permute (rows AND columns in the colour-major block order; n_perm rows = the dofs of the blocks, n_perm + 1
+ * columns, the last standing for the dofs outside every block; every row block of its launch plan holds whole
+ * Gauss-Seidel blocks and at most 256 rows).  A sweep call gathers x and y into that numbering once, runs ONE launch
+ * per colour (rows of the colour with the block solve in the epilogue: the residuals of a row block pass through LDS)
+ * and scatters y back once; the symmetric operator gathers / scatters once for both sweeps.  Same products in the
+ * same order as the two-launch form: same bits. */
+NSS_API int nss_bjac_set_colors_permuted(nss_bjac_t j, nss_csr_t a_perm, int32_t ncolors, const int32_t* h_color_ptr,
+                                         const int32_t* h_color_rowptr, const int32_t* h_rowdof, const int32_t* h_ridx);
 /* one sweep: colours ascending (backward == 0) or descending */
 NSS_API int nss_bjac_smooth_f64(nss_bjac_t j, double xscale, const double* x, double* y, int32_t backward,
                                 nss_stream_t stream);

@@ -69,6 +69,7 @@ constexpr int kDirectRows = NSS_DIRECT_ROWS_PER_LANE * 256;   // rows per row bl
 constexpr int kSegMax = 13;
 constexpr int kSegWords = 32;        // descriptor: r0, r1, p0, cnt, nseg, total, pre[1..12], off[0..12], spare
 constexpr int kSegPre = 6, kSegOff = 18;
+constexpr int kSegBlock = 31;        // dispatch-ordered copy of the table: the row block this slot stands for
 
 bool pair_staging_enabled();     // nss_csr_pair_mode (tests, measurements)
 
@@ -79,6 +80,8 @@ struct CsrView {
   const uint16_t* __restrict__ col16;   // the 16-bit stream of `mode` (window-relative columns or staged positions), or NULL
   const int32_t* __restrict__ blkbase;  // kWindows window bases per row block (mode 1)
   const int32_t* __restrict__ blkseg;   // kSegWords per row block (mode 2)
+  const int32_t* __restrict__ blkdisp;  // the same descriptors in DISPATCH order (8 x per_xcd slots, word kSegBlock = the
+                                        // row block, -1 in padding slots), or NULL: slot lb is row block blk0 + lb
   const double* __restrict__ val;
   uint32_t gb;      // entries per column group of the 16-bit stream (1: one index per entry)
   uint32_t gstep, sstep;   // kBlock / gb, kBlock % gb: a lane's next entry is kBlock further down the stream
@@ -128,6 +131,18 @@ struct nss_csr_s {
   // kernels whose operand is an expression of two vectors (they gather).
   uint16_t* pos16 = nullptr;
   int32_t* blkseg = nullptr;
+  // Reuse-aware dispatch order (grid operators beyond ~1e7 rows).  XCD i walks its contiguous eighth of the row
+  // blocks; the operand runs a block stages besides its own neighbourhood -- the grid planes above and below --
+  // are staged again by the blocks P positions further down the walk (P = row blocks per plane).  Up to ~200
+  // positions the XCD's 4-MiB L2 still holds them; beyond (5e7 DoF: P ~ 550) every such run comes from HBM a
+  // second and a third time (PMC: the dominant launch drew 1.17 x its algorithmic bytes).  `blkdisp` is a copy of
+  // the descriptor table in an order that visits the blocks b, b + P, b + 2P, ... of T consecutive planes back to
+  // back, then b + 1, b + 1 + P, ...: the re-reads are adjacent in time.  Only the workgroup -> row block map
+  // changes: per-row sums and the per-block dot-partial slots, hence all bits, stay.  Built at upload from the run
+  // starts (spmv.hip: build_dispatch); full-range launches of the staged forms use it.
+  int32_t* blkdisp = nullptr;
+  double disp_period = 0.0;      // P (row blocks), 0: natural order
+  int32_t disp_planes = 0;       // T
   // Pair-staged operand: kernels whose operand is an expression of TWO stored vectors (t1 - s0 in the rows of B,
   // beta s1 + w1 in the rows of B^T) copy the segments of both -- the first to the lower half of the LDS buffer, the
   // second to the upper half -- and combine what they read back.  Possible when the segments of every row block hold
@@ -157,7 +172,9 @@ struct nss_csr_s {
   // launch view of the row blocks [b0, b1)
   nss::CsrView view(int b0, int b1, int mode) const {
     const uint64_t magic = gb > 1 ? ~uint64_t(0) / uint64_t(gb) + 1 : 0;    // ceil(2^64 / gb)
-    return nss::CsrView{rowblk, rowptr, col, mode >= 2 ? pos16 : (mode == 1 ? col16 : nullptr), blkbase, blkseg, val,
+    const bool full = b0 == 0 && b1 == nblk;
+    return nss::CsrView{rowblk, rowptr, col, mode >= 2 ? pos16 : (mode == 1 ? col16 : nullptr), blkbase, blkseg,
+                        (mode >= 2 && full) ? blkdisp : nullptr, val,
                         uint32_t(gb), uint32_t(nss::kBlock / gb), uint32_t(nss::kBlock % gb), magic, b0, b1 - b0,
                         (b1 - b0 + nss::kXcds - 1) / nss::kXcds, mode};
   }
@@ -175,8 +192,12 @@ bool direct_rows_candidate(int32_t m, const int32_t* rowptr);
 // Launch plan of a CSR matrix: lanes per row (*rg_out) and the row-block boundaries (spmv.hip).
 // `products`: products per row block to aim at (<= kChunk; the lanes-per-row choice does not depend on it, so the
 // per-row sums of a re-planned matrix keep their bits)
+// `max_rows` > 0: at most that many rows per row block; `row_pos` (one byte per row, host): a row block may only
+// start at a row with row_pos == 0 (rows that belong together -- the dofs of one Gauss-Seidel block -- stay in one
+// workgroup)
 void plan_row_blocks(int32_t m, int64_t nnz, const int32_t* rowptr, int32_t* rg_out, int32_t* chunk_out,
-                     std::vector<int32_t>& blk, const int32_t* cuts = nullptr, int ncuts = 0, int products = kChunk);
+                     std::vector<int32_t>& blk, const int32_t* cuts = nullptr, int ncuts = 0, int products = kChunk,
+                     int max_rows = 0, const uint8_t* row_pos = nullptr);
 
 // Epi interface:
 //   __device__ void row(int r, double ax);          // called once per row by one lane
@@ -389,7 +410,12 @@ __device__ __forceinline__ void csr_stream_body(const CsrView& a, const double* 
   // (persistent) loop around this body measured 9 % slower on the A SpMV (extra barrier, and
   // the hardware dispatcher balances the tail better).
   const int lb = (wg & (kXcds - 1)) * a.per_xcd + (wg >> 3);
-  const int b = lb < a.nblk ? a.blk0 + lb : -1;
+  int b = lb < a.nblk ? a.blk0 + lb : -1;
+  typedef const int32_t __attribute__((address_space(4))) * ConstI32;
+  if constexpr (IDX >= 2) {
+    // reuse-aware dispatch order: slot lb of the dispatch-ordered table names its row block (uniform scalar load)
+    if (a.blkdisp != nullptr) b = ((ConstI32)(a.blkdisp + size_t(lb) * kSegWords))[kSegBlock];
+  }
   if (b >= 0) {
     int r0 = 0, r1 = 0, p0 = 0, cnt = 0;
     if constexpr (IDX >= 2) {
@@ -397,8 +423,8 @@ __device__ __forceinline__ void csr_stream_body(const CsrView& a, const double* 
       // (the run table then sits in SGPRs); the constant address space makes the loads invariant, and a uniform
       // invariant load is an s_load -- as vector loads (what the compiler emitted in the two-matrix kernel) every
       // use below would wait for vmcnt(0).
-      typedef const int32_t __attribute__((address_space(4))) * ConstI32;
-      const ConstI32 d = (ConstI32)(a.blkseg + size_t(b) * kSegWords);
+      const ConstI32 d = a.blkdisp != nullptr ? (ConstI32)(a.blkdisp + size_t(lb) * kSegWords)
+                                              : (ConstI32)(a.blkseg + size_t(b) * kSegWords);
       r0 = d[0];
       r1 = d[1];
       p0 = d[2];
@@ -643,7 +669,7 @@ inline void launch_csr_direct(const nss_csr_s& A, const double* x, const Epi& ep
 // rows of the row blocks [b0, b1) (default: all)
 template <class Epi>
 inline void launch_csr_stream(const nss_csr_s& A, const double* x, const Epi& epi, hipStream_t st, int b0 = 0,
-                              int b1 = -1) {
+                              int b1 = -1, size_t dyn_lds = 0) {
   if (b1 < 0) b1 = A.nblk;
   if (A.m == 0 || b1 <= b0) return;
   if (A.ell_col) {
@@ -659,19 +685,19 @@ inline void launch_csr_stream(const nss_csr_s& A, const double* x, const Epi& ep
 #define NSS_LAUNCH_ONE(N, CHK)                                                                                  \
   if (mode == 2) {                                                                                               \
     if constexpr (kCanStage) {                                                                                   \
-      if (grp) hipLaunchKernelGGL((csr_stream_kernel<N, Epi, 2, CHK, true>), grid, block, 0, st, v, x, epi);     \
-      else hipLaunchKernelGGL((csr_stream_kernel<N, Epi, 2, CHK, false>), grid, block, 0, st, v, x, epi);        \
+      if (grp) hipLaunchKernelGGL((csr_stream_kernel<N, Epi, 2, CHK, true>), grid, block, dyn_lds, st, v, x, epi);     \
+      else hipLaunchKernelGGL((csr_stream_kernel<N, Epi, 2, CHK, false>), grid, block, dyn_lds, st, v, x, epi);        \
     }                                                                                                            \
   } else if (mode == 3) {                                                                                        \
     if constexpr (kCanPair) {                                                                                    \
-      if (grp) hipLaunchKernelGGL((csr_stream_kernel<N, Epi, 3, CHK, true>), grid, block, 0, st, v, x, epi);     \
-      else hipLaunchKernelGGL((csr_stream_kernel<N, Epi, 3, CHK, false>), grid, block, 0, st, v, x, epi);        \
+      if (grp) hipLaunchKernelGGL((csr_stream_kernel<N, Epi, 3, CHK, true>), grid, block, dyn_lds, st, v, x, epi);     \
+      else hipLaunchKernelGGL((csr_stream_kernel<N, Epi, 3, CHK, false>), grid, block, dyn_lds, st, v, x, epi);        \
     }                                                                                                            \
   } else if (mode == 1) {                                                                                        \
-    if (grp) hipLaunchKernelGGL((csr_stream_kernel<N, Epi, 1, CHK, true>), grid, block, 0, st, v, x, epi);       \
-    else hipLaunchKernelGGL((csr_stream_kernel<N, Epi, 1, CHK, false>), grid, block, 0, st, v, x, epi);          \
+    if (grp) hipLaunchKernelGGL((csr_stream_kernel<N, Epi, 1, CHK, true>), grid, block, dyn_lds, st, v, x, epi);       \
+    else hipLaunchKernelGGL((csr_stream_kernel<N, Epi, 1, CHK, false>), grid, block, dyn_lds, st, v, x, epi);          \
   } else {                                                                                                       \
-    hipLaunchKernelGGL((csr_stream_kernel<N, Epi, 0, CHK, false>), grid, block, 0, st, v, x, epi);               \
+    hipLaunchKernelGGL((csr_stream_kernel<N, Epi, 0, CHK, false>), grid, block, dyn_lds, st, v, x, epi);               \
   }
   NSS_FOR_PLAN(A, NSS_LAUNCH_ONE)
 #undef NSS_LAUNCH_ONE

@@ -23,11 +23,24 @@ struct nss_bjac_s {
   int32_t* rowdof = nullptr;              // device: original dof of permuted row r
   int32_t* ridx = nullptr;                // device [bs][nblocks]: permuted row of a block entry, -1 = padding
   double* res = nullptr;                  // device: residual of the colour being swept (permuted rows)
+  // Colour-major layout INSIDE the sweep (nss_bjac_set_colors_permuted): gs_mat is P A P^T -- rows and columns in the
+  // colour-major block order, dofs that belong to no block map to the extra column n_perm (always 0) -- the iterate
+  // and the right-hand side are gathered into that numbering once on entry (yt, xt) and the iterate is scattered back
+  // once on exit; a colour is then ONE launch: the rows of the colour with the block solve in the epilogue (every
+  // row block of gs_mat holds whole Gauss-Seidel blocks and at most kGsRows rows; the residuals of a row block pass
+  // through LDS).  Everything a colour touches of its own is contiguous.
+  bool gs_permuted = false;
+  int32_t n_perm = 0;
+  uint8_t* gpos = nullptr;                // [n_perm] position of the row inside its block
+  uint8_t* glen = nullptr;                // [n_perm] rows of its block
+  double* ginv = nullptr;                 // [bs][n_perm]: ginv[k][r] = (A_bb^-1)(row r, k-th row of the block)
+  double *xt = nullptr, *yt = nullptr;    // [n_perm + 1]
 };
 
 namespace nss {
 
 constexpr int kMaxBs = 16;
+constexpr int kGsRows = 256;     // rows per row block of the permuted Gauss-Seidel matrix (their residuals: 2 KiB of LDS)
 
 // y[dofs] = alpha * J x + beta * y[dofs]; returns immediately on the device when
 // `done` (device int, may be NULL) is non-zero.

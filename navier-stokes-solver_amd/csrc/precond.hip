@@ -242,6 +242,107 @@ __global__ __launch_bounds__(kBlock) void bgs_solve_kernel(int32_t b0, int32_t b
   }
 }
 
+// ---- colour-major layout inside the sweep (nss_bjac_s::gs_permuted) ------------------------------------------
+// One launch per colour: rows of the colour of P A P^T times the permuted iterate, residual of every row into LDS
+// (a row block holds at most kGsRows consecutive rows: slot r mod kGsRows), then -- all rows of the row block done --
+// every lane applies its row of the inverse block to the residuals of its block: yt[r] += sum_k ginv[k][r] res[first + k].
+// Same products in the same order as the two-launch form (EpiGsResidual + bgs_solve_kernel): same bits.
+struct EpiGsFused {
+  const int32_t* __restrict__ done;
+  const int32_t* __restrict__ rowblk;
+  const double* __restrict__ xt;
+  double* __restrict__ yt;
+  const double* __restrict__ ginv;
+  const uint8_t* __restrict__ gpos;
+  const uint8_t* __restrict__ glen;
+  int32_t n_perm;
+  double xscale;
+  __device__ bool skip() const { return done && done[0] != 0; }
+  struct Pre { double x = 0.0; };
+  __device__ Pre fetch(int r) const { return Pre{xt[r]}; }
+  __device__ void row(int r, double ay, const Pre& p) const {
+    extern __shared__ double gs_res[];
+    gs_res[r & (kGsRows - 1)] = fma(xscale, p.x, -ay);
+  }
+  __device__ void finish(int b, double*) const {
+    extern __shared__ double gs_res[];
+    if (b < 0) return;                                    // (uniform over the workgroup)
+    __syncthreads();
+    const int r0 = rowblk[b], r1 = rowblk[b + 1];
+    for (int r = r0 + int(threadIdx.x); r < r1; r += kBlock) {
+      const int first = r - int(gpos[r]), len = int(glen[r]);
+      double s = 0.0;
+      for (int k = 0; k < len; ++k) s = fma(ginv[size_t(k) * n_perm + r], gs_res[(first + k) & (kGsRows - 1)], s);
+      yt[r] += s;
+    }
+  }
+};
+
+// entry: xt = x[rowdof], yt = y[rowdof] (or 0), the extra slot behind them 0
+__global__ __launch_bounds__(kBlock) void gs_enter_kernel(int32_t n_perm, const int32_t* __restrict__ rowdof,
+                                                           const double* __restrict__ x, const double* __restrict__ y,
+                                                           double* __restrict__ xt, double* __restrict__ yt,
+                                                           const int32_t* __restrict__ done) {
+  if (done && done[0] != 0) return;
+  const int stride = gridDim.x * kBlock;
+  for (int r = blockIdx.x * kBlock + threadIdx.x; r <= n_perm; r += stride) {
+    const bool live = r < n_perm;
+    const int d = live ? rowdof[r] : 0;
+    xt[r] = live ? x[d] : 0.0;
+    yt[r] = (live && y) ? y[d] : 0.0;
+  }
+}
+
+// exit: y[rowdof] = yt
+__global__ __launch_bounds__(kBlock) void gs_leave_kernel(int32_t n_perm, const int32_t* __restrict__ rowdof,
+                                                           const double* __restrict__ yt, double* __restrict__ y,
+                                                           const int32_t* __restrict__ done) {
+  if (done && done[0] != 0) return;
+  const int stride = gridDim.x * kBlock;
+  for (int r = blockIdx.x * kBlock + threadIdx.x; r < n_perm; r += stride) y[rowdof[r]] = yt[r];
+}
+
+// ginv[k][r] for the rows of one block: (A_bb^-1)(position of r, k-th live position of the block)
+__global__ __launch_bounds__(kBlock) void gs_pack_inverse_kernel(int32_t bs, int32_t nb, int32_t n_perm,
+                                                                  const int32_t* __restrict__ ridx,
+                                                                  const double* __restrict__ inv,
+                                                                  double* __restrict__ ginv, uint8_t* __restrict__ gpos,
+                                                                  uint8_t* __restrict__ glen) {
+  const int b = blockIdx.x * kBlock + threadIdx.x;
+  if (b >= nb) return;
+  int live[kMaxBs], len = 0;
+  for (int c = 0; c < bs; ++c)
+    if (ridx[size_t(c) * nb + b] >= 0) live[len++] = c;
+  for (int i = 0; i < len; ++i) {
+    const int r = ridx[size_t(live[i]) * nb + b];
+    gpos[r] = uint8_t(i);
+    glen[r] = uint8_t(len);
+    for (int k = 0; k < bs; ++k)
+      ginv[size_t(k) * n_perm + r] = k < len ? inv[(size_t(live[i]) * bs + live[k]) * nb + b] : 0.0;
+  }
+}
+
+static void gs_sweep_permuted(const nss_bjac_s& j, double xscale, bool backward, const int32_t* done, hipStream_t st) {
+  const int nc = int(j.color_ptr.size()) - 1;
+  const EpiGsFused epi{done, j.gs_mat->rowblk, j.xt, j.yt, j.ginv, j.gpos, j.glen, j.n_perm, xscale};
+  for (int k = 0; k < nc; ++k) {
+    const int c = backward ? nc - 1 - k : k;
+    launch_csr_stream(*j.gs_mat, j.yt, epi, st, j.color_rowblk[c], j.color_rowblk[c + 1], sizeof(double) * kGsRows);
+  }
+}
+
+static void gs_enter(const nss_bjac_s& j, const double* x, const double* y, const int32_t* done, hipStream_t st) {
+  hipLaunchKernelGGL(gs_enter_kernel, dim3(stream_grid(int64_t(j.n_perm) + 1, kBlock)), dim3(kBlock), 0, st, j.n_perm,
+                     j.rowdof, x, y, j.xt, j.yt, done);
+  NSS_CHECK_LAUNCH();
+}
+
+static void gs_leave(const nss_bjac_s& j, double* y, const int32_t* done, hipStream_t st) {
+  hipLaunchKernelGGL(gs_leave_kernel, dim3(stream_grid(j.n_perm, kBlock)), dim3(kBlock), 0, st, j.n_perm, j.rowdof, j.yt,
+                     y, done);
+  NSS_CHECK_LAUNCH();
+}
+
 template <int BS>
 static void launch_bgs_solve(const nss_bjac_s& j, int c, double* y, const int32_t* done, hipStream_t st) {
   const int b0 = j.color_ptr[c], b1 = j.color_ptr[c + 1];
@@ -253,6 +354,12 @@ static void launch_bgs_solve(const nss_bjac_s& j, int c, double* y, const int32_
 void bjac_smooth(const nss_bjac_s& j, double xscale, const double* x, double* y, bool backward, const int32_t* done,
                  hipStream_t st) {
   if (!j.gs_mat) throw Error("bjac_smooth: colours not set (nss_bjac_set_colors)");
+  if (j.gs_permuted) {             // gather x and y into the colour-major numbering, sweep, scatter y back
+    gs_enter(j, x, y, done, st);
+    gs_sweep_permuted(j, xscale, backward, done, st);
+    gs_leave(j, y, done, st);
+    return;
+  }
   const int nc = int(j.color_ptr.size()) - 1;
   for (int k = 0; k < nc; ++k) {
     const int c = backward ? nc - 1 - k : k;
@@ -271,6 +378,18 @@ void bjac_smooth(const nss_bjac_s& j, double xscale, const double* x, double* y,
 
 void bjac_symgs_apply(const nss_bjac_s& j, double xscale, const double* x, double* y, const int32_t* done,
                       hipStream_t st) {
+  if (j.gs_permuted) {             // both sweeps inside the colour-major numbering: one gather, one scatter
+    if (j.n_uncovered > 0) {       // dofs in no block stay 0 (guarded: a frozen solver keeps its y)
+      hipLaunchKernelGGL(bjac_uncovered_kernel, dim3((j.n_uncovered + kBlock - 1) / kBlock), dim3(kBlock), 0, st,
+                         j.n_uncovered, j.covered, 0.0, y, done);
+      NSS_CHECK_LAUNCH();
+    }
+    gs_enter(j, x, nullptr, done, st);                               // y[:] = 0 (:377)
+    gs_sweep_permuted(j, xscale, false, done, st);                   // jacobi.Smooth(y, x)      (:378)
+    gs_sweep_permuted(j, xscale, true, done, st);                    // jacobi.SmoothBack(y, x)  (:381)
+    gs_leave(j, y, done, st);
+    return;
+  }
   NSS_HIP(hipMemsetAsync(y, 0, sizeof(double) * size_t(j.n), st));   // y[:] = 0 (:377)
   bjac_smooth(j, xscale, x, y, false, done, st);                     // jacobi.Smooth(y, x)      (:378)
   bjac_smooth(j, xscale, x, y, true, done, st);                      // jacobi.SmoothBack(y, x)  (:381)
@@ -437,6 +556,11 @@ int nss_bjac_destroy(nss_bjac_t j) {
     (void)hipFree(j->rowdof);
     (void)hipFree(j->ridx);
     (void)hipFree(j->res);
+    (void)hipFree(j->gpos);
+    (void)hipFree(j->glen);
+    (void)hipFree(j->ginv);
+    (void)hipFree(j->xt);
+    (void)hipFree(j->yt);
     delete j;
   });
 }
@@ -449,11 +573,12 @@ int nss_bjac_apply_f64(nss_bjac_t j, double alpha, const double* x, double beta,
   });
 }
 
-int nss_bjac_set_colors(nss_bjac_t j, nss_csr_t a_perm, int32_t ncolors, const int32_t* h_color_ptr,
-                        const int32_t* h_color_rowptr, const int32_t* h_rowdof, const int32_t* h_ridx) {
-  return guarded([&] {
+static void set_colors_common(nss_bjac_t j, nss_csr_t a_perm, int32_t ncolors, const int32_t* h_color_ptr,
+                              const int32_t* h_color_rowptr, const int32_t* h_rowdof, const int32_t* h_ridx,
+                              bool permuted_columns) {
+  {
     NSS_REQUIRE(j && a_perm && h_color_ptr && h_color_rowptr && h_rowdof && h_ridx, "bjac_set_colors: NULL argument");
-    NSS_REQUIRE(a_perm->n == j->n, "bjac_set_colors: permuted matrix has the wrong column count");
+    NSS_REQUIRE(permuted_columns || a_perm->n == j->n, "bjac_set_colors: permuted matrix has the wrong column count");
     NSS_REQUIRE(ncolors >= 1, "bjac_set_colors: need at least one colour");
     NSS_REQUIRE(h_color_ptr[0] == 0 && h_color_ptr[ncolors] == j->nblocks, "bjac_set_colors: colour offsets must span the blocks");
     NSS_REQUIRE(h_color_rowptr[0] == 0 && h_color_rowptr[ncolors] == a_perm->m, "bjac_set_colors: colour row offsets must span the permuted rows");
@@ -486,8 +611,63 @@ int nss_bjac_set_colors(nss_bjac_t j, nss_csr_t a_perm, int32_t ncolors, const i
     NSS_HIP(hipMemcpy(j->rowdof, h_rowdof, sizeof(int32_t) * a_perm->m, hipMemcpyHostToDevice));
     NSS_HIP(hipMemcpy(j->ridx, h_ridx, sizeof(int32_t) * size_t(j->bs) * j->nblocks, hipMemcpyHostToDevice));
     j->gs_mat = a_perm;
+    j->gs_permuted = false;
     j->color_ptr.assign(h_color_ptr, h_color_ptr + ncolors + 1);
     j->color_rowblk = crb;
+  }
+}
+
+int nss_bjac_set_colors(nss_bjac_t j, nss_csr_t a_perm, int32_t ncolors, const int32_t* h_color_ptr,
+                        const int32_t* h_color_rowptr, const int32_t* h_rowdof, const int32_t* h_ridx) {
+  return guarded([&] { set_colors_common(j, a_perm, ncolors, h_color_ptr, h_color_rowptr, h_rowdof, h_ridx, false); });
+}
+
+int nss_bjac_set_colors_permuted(nss_bjac_t j, nss_csr_t a_perm, int32_t ncolors, const int32_t* h_color_ptr,
+                                 const int32_t* h_color_rowptr, const int32_t* h_rowdof, const int32_t* h_ridx) {
+  return guarded([&] {
+    NSS_REQUIRE(j && a_perm && h_color_ptr && h_color_rowptr && h_rowdof && h_ridx, "bjac_set_colors_permuted: NULL argument");
+    const int32_t n_perm = a_perm->m;
+    NSS_REQUIRE(a_perm->n == n_perm + 1, "bjac_set_colors_permuted: the permuted matrix must have n_perm + 1 columns (the "
+                                         "last one stands for the dofs outside every block)");
+    NSS_REQUIRE(int64_t(n_perm) + j->n_uncovered == j->n, "bjac_set_colors_permuted: the permuted rows must be exactly the dofs of the blocks");
+    // the common part (offsets, rowdof, ridx, the residual buffer of the two-launch form)
+    set_colors_common(j, a_perm, ncolors, h_color_ptr, h_color_rowptr, h_rowdof, h_ridx, true);
+    // the launch plan must keep the blocks whole and the row blocks short
+    std::vector<int32_t> rb(size_t(a_perm->nblk) + 1);
+    NSS_HIP(hipMemcpy(rb.data(), a_perm->rowblk, sizeof(int32_t) * rb.size(), hipMemcpyDeviceToHost));
+    std::vector<uint8_t> starts(size_t(n_perm) + 1, 0);
+    {   // first row of every block
+      std::vector<int32_t> first(size_t(j->nblocks), INT32_MAX);
+      for (int c = 0; c < j->bs; ++c)
+        for (int32_t b = 0; b < j->nblocks; ++b) {
+          const int32_t r = h_ridx[size_t(c) * j->nblocks + b];
+          if (r >= 0) first[size_t(b)] = std::min(first[size_t(b)], r);
+        }
+      for (int32_t b = 0; b < j->nblocks; ++b)
+        if (first[size_t(b)] != INT32_MAX) starts[size_t(first[size_t(b)])] = 1;
+      starts[size_t(n_perm)] = 1;
+    }
+    for (size_t k = 0; k + 1 < rb.size(); ++k) {
+      NSS_REQUIRE(rb[k + 1] - rb[k] <= kGsRows, "bjac_set_colors_permuted: a row block of the permuted matrix has more than 256 rows");
+      NSS_REQUIRE(starts[size_t(rb[k])] == 1, "bjac_set_colors_permuted: a row block of the permuted matrix splits a Gauss-Seidel block");
+    }
+    for (void* p : {(void*)j->gpos, (void*)j->glen, (void*)j->ginv, (void*)j->xt, (void*)j->yt}) (void)hipFree(p);
+    j->gpos = j->glen = nullptr;
+    j->ginv = j->xt = j->yt = nullptr;
+    j->gs_permuted = false;
+    NSS_HIP(hipMalloc(&j->gpos, std::max<size_t>(1, n_perm)));
+    NSS_HIP(hipMalloc(&j->glen, std::max<size_t>(1, n_perm)));
+    NSS_HIP(hipMalloc(&j->ginv, sizeof(double) * size_t(j->bs) * std::max<size_t>(1, n_perm)));
+    NSS_HIP(hipMalloc(&j->xt, sizeof(double) * (size_t(n_perm) + 1)));
+    NSS_HIP(hipMalloc(&j->yt, sizeof(double) * (size_t(n_perm) + 1)));
+    NSS_HIP(hipMemset(j->xt, 0, sizeof(double) * (size_t(n_perm) + 1)));
+    NSS_HIP(hipMemset(j->yt, 0, sizeof(double) * (size_t(n_perm) + 1)));
+    hipLaunchKernelGGL(gs_pack_inverse_kernel, dim3((j->nblocks + kBlock - 1) / kBlock), dim3(kBlock), 0, nullptr, j->bs,
+                       j->nblocks, n_perm, j->ridx, j->inv, j->ginv, j->gpos, j->glen);
+    NSS_CHECK_LAUNCH();
+    NSS_HIP(hipDeviceSynchronize());
+    j->n_perm = n_perm;
+    j->gs_permuted = true;
   });
 }
 

@@ -38,7 +38,8 @@ bool direct_rows_candidate(int32_t m, const int32_t* rowptr) {
 }
 
 void plan_row_blocks(int32_t m, int64_t nnz, const int32_t* rowptr, int32_t* rg_out, int32_t* chunk_out,
-                     std::vector<int32_t>& blk, const int32_t* cuts, int ncuts, int products) {
+                     std::vector<int32_t>& blk, const int32_t* cuts, int ncuts, int products, int max_rows,
+                     const uint8_t* row_pos) {
   const double mean = m > 0 ? double(nnz) / double(m) : 0.0;
   const int chunk = kChunk;
   *chunk_out = chunk;
@@ -62,6 +63,7 @@ void plan_row_blocks(int32_t m, int64_t nnz, const int32_t* rowptr, int32_t* rg_
 #endif
   }
   int row_cap = std::min(kMaxRowsPerBlock, passes * rows_per_pass);
+  if (max_rows > 0) row_cap = std::min(row_cap, max_rows);
   if (direct_rows_candidate(m, rowptr)) row_cap = std::min(row_cap, kDirectRows);   // see csr_direct_kernel
   blk.clear();
   blk.push_back(0);
@@ -79,6 +81,15 @@ void plan_row_blocks(int32_t m, int64_t nnz, const int32_t* rowptr, int32_t* rg_
       ++r;
     }
     if (r == start) ++r;  // a single row longer than the chunk gets a block of its own
+    if (row_pos) {        // rows that belong together stay together: end where a group starts (or take the whole group)
+      int32_t e = r;
+      while (e > start && e < limit && row_pos[e] != 0) --e;
+      if (e == start) {
+        e = r;
+        while (e < limit && row_pos[e] != 0) ++e;
+      }
+      r = e;
+    }
     blk.push_back(r);
   }
 }
@@ -403,6 +414,146 @@ static void stage_columns(nss_csr_s& A, hipStream_t st) {
 #endif
 }
 
+// ---- reuse-aware dispatch order (nss_csr_s::blkdisp) ----------------------------------------------------
+// -1: automatic; 0: never; > 0: tile whenever a period is found, with this many planes per tile.
+// DEFAULT OFF -- measured at 5e7 DoF (profiles/r03_ab_dispatch_cfg5.txt): the tiled walk does what it was built for --
+// the dominant launch fetches 5.54 GB instead of 6.20 GB through the L2s (1.05 x instead of 1.18 x its algorithmic
+// reads), the plain A SpMV 3.25 instead of 3.78 GB -- and is not faster: 8 planes x 1 block per visit -8 %, with
+// 192-block visits (a CU's resident workgroups then stay in one plane) 0 ... -1 % against the natural order.  The
+// re-reads it removes were evidently served by the 256-MB memory-side cache (the natural order's reuse distance is
+// ~200 MB of streamed data across the 8 XCDs), not by HBM; the launch is held elsewhere.
+#ifndef NSS_DISPATCH_DEFAULT
+#define NSS_DISPATCH_DEFAULT 0
+#endif
+static int g_dispatch_planes = NSS_DISPATCH_DEFAULT;
+#ifndef NSS_DISPATCH_MIN_PERIOD
+#define NSS_DISPATCH_MIN_PERIOD 256   // row blocks between a block and the one that re-reads its far runs: below, the XCD's L2 still holds them
+#endif
+#ifndef NSS_DISPATCH_PLANES
+#define NSS_DISPATCH_PLANES 8
+#endif
+static int g_dispatch_min_period = NSS_DISPATCH_MIN_PERIOD;
+#ifndef NSS_DISPATCH_RUN
+#define NSS_DISPATCH_RUN 1            // consecutive row blocks of one plane before the walk moves to the next plane
+#endif
+static int g_dispatch_run = NSS_DISPATCH_RUN;
+
+namespace {
+struct Runs {
+  int n = 0;
+  int32_t lo[kSegMax], hi[kSegMax];
+};
+
+Runs runs_of(const int32_t* d) {
+  Runs r;
+  const int nseg = d[4], total = d[5];
+  for (int s = 0; s < nseg && s < kSegMax; ++s) {
+    const int32_t pre = s == 0 ? 0 : d[kSegPre + s - 1];
+    const int32_t nxt = s + 1 < nseg ? d[kSegPre + s] : total;
+    r.lo[r.n] = d[kSegOff + s] + pre;
+    r.hi[r.n] = r.lo[r.n] + (nxt - pre);
+    ++r.n;
+  }
+  return r;
+}
+
+bool share_columns(const Runs& a, const Runs& b) {
+  for (int i = 0; i < a.n; ++i)
+    for (int j = 0; j < b.n; ++j)
+      if (a.lo[i] < b.hi[j] && b.lo[j] < a.hi[i]) return true;
+  return false;
+}
+}  // namespace
+
+// The period P of a matrix: how many positions further down the natural order the row blocks sit that stage the far
+// runs of a block again.  For a sample of blocks b: the blocks b + p that share columns with b form a cluster right
+// behind b (its neighbours in the same grid plane), a gap, and a cluster around p = P (the next plane); P = the
+// centre of that second cluster, the median over the sample.  0 when there is no second cluster within reach.
+static double dispatch_period(const std::vector<int32_t>& desc, int nblk) {
+  const int reach = std::min(nblk - 1, 8192);
+  if (nblk < 64 || reach < 16) return 0.0;
+  std::vector<double> found;
+  const int samples = 24;
+  for (int q = 0; q < samples; ++q) {
+    const int b = int((int64_t(nblk - 1 - reach) * (2 * q + 1)) / (2 * samples));
+    const Runs rb = runs_of(&desc[size_t(b) * kSegWords]);
+    if (rb.n == 0) continue;
+    int p = 1;
+    while (p <= reach && share_columns(rb, runs_of(&desc[size_t(b + p) * kSegWords]))) ++p;    // near cluster
+    const int gap0 = p;
+    while (p <= reach && !share_columns(rb, runs_of(&desc[size_t(b + p) * kSegWords]))) ++p;   // gap
+    if (p > reach) continue;
+    const int first = p;
+    while (p <= reach && share_columns(rb, runs_of(&desc[size_t(b + p) * kSegWords]))) ++p;    // second cluster
+    if (first - gap0 < 8) continue;                       // no real gap: not a plane structure
+    found.push_back(0.5 * double(first + p - 1));
+  }
+  if (found.size() < size_t(samples) / 2) return 0.0;
+  std::sort(found.begin(), found.end());
+  const double med = found[found.size() / 2];
+  // a consistent structure: most samples agree with the median
+  size_t agree = 0;
+  for (double v : found) agree += std::abs(v - med) <= 0.02 * med + 2.0 ? 1 : 0;
+  return agree * 4 >= found.size() * 3 ? med : 0.0;
+}
+
+// dispatch order of the row blocks [lo, hi) of one XCD: tiles of `planes` periods, inside a tile the blocks at equal
+// offset of every period back to back
+static void tile_order(int lo, int hi, double period, int planes, int run, std::vector<int32_t>& out) {
+  int base = lo;
+  run = std::max(1, run);
+  while (base < hi) {
+    int start[64 + 1];
+    for (int k = 0; k <= planes; ++k) start[k] = std::min(hi, base + int(std::llround(double(k) * period)));
+    int longest = 0;
+    for (int k = 0; k < planes; ++k) longest = std::max(longest, start[k + 1] - start[k]);
+    for (int j0 = 0; j0 < longest; j0 += run)
+      for (int k = 0; k < planes; ++k)
+        for (int j = j0; j < j0 + run && start[k] + j < start[k + 1]; ++j) out.push_back(start[k] + j);
+    base = start[planes];
+  }
+}
+
+static void build_dispatch(nss_csr_s& A, hipStream_t st) {
+  if (!A.blkseg || g_dispatch_planes == 0 || A.nblk < 8 * kXcds) return;
+  std::vector<int32_t> desc(size_t(A.nblk) * kSegWords);
+  NSS_HIP(hipMemcpyAsync(desc.data(), A.blkseg, sizeof(int32_t) * desc.size(), hipMemcpyDeviceToHost, st));
+  NSS_HIP(hipStreamSynchronize(st));
+  const double period = dispatch_period(desc, A.nblk);
+  const int planes = std::min(64, g_dispatch_planes > 0 ? g_dispatch_planes : NSS_DISPATCH_PLANES);
+  if (period <= 0.0 || (g_dispatch_planes < 0 && period < double(g_dispatch_min_period))) return;
+  const int per_xcd = (A.nblk + kXcds - 1) / kXcds;
+  if (period * 2.0 > double(per_xcd)) return;              // fewer than two planes per XCD: nothing to tile
+  std::vector<int32_t> table(size_t(kXcds) * per_xcd * kSegWords, 0);
+  std::vector<int32_t> order;
+  for (int x = 0; x < kXcds; ++x) {
+    const int lo = std::min(A.nblk, x * per_xcd), hi = std::min(A.nblk, (x + 1) * per_xcd);
+    order.clear();
+    tile_order(lo, hi, period, planes, g_dispatch_run, order);
+    if (int(order.size()) != hi - lo) throw Error("dispatch order does not cover the XCD's row blocks");
+    for (int q = 0; q < per_xcd; ++q) {
+      int32_t* slot = &table[(size_t(x) * per_xcd + q) * kSegWords];
+      if (q < int(order.size())) {
+        std::copy_n(&desc[size_t(order[q]) * kSegWords], kSegWords, slot);
+        slot[kSegBlock] = order[q];
+      } else {
+        slot[kSegBlock] = -1;                              // padding slot
+      }
+    }
+  }
+  int32_t* dev = nullptr;
+  NSS_HIP(hipMalloc(&dev, sizeof(int32_t) * table.size()));
+  try {
+    NSS_HIP(hipMemcpy(dev, table.data(), sizeof(int32_t) * table.size(), hipMemcpyHostToDevice));
+  } catch (...) {
+    (void)hipFree(dev);
+    throw;
+  }
+  A.blkdisp = dev;
+  A.disp_period = period;
+  A.disp_planes = planes;
+}
+
 // 16-bit window form: A.col16 / A.blkbase when every row block fits kWindows windows.
 static void window_columns(nss_csr_s& A, hipStream_t st) {
   int32_t* base = nullptr;
@@ -505,6 +656,7 @@ void compress_columns(nss_csr_s& A, hipStream_t st) {
   window_columns(A, st);
   group_columns(A, st);
   direct_rows(A, st);
+  if (!A.ell_col) build_dispatch(A, st);
 #else
   (void)A;
   (void)st;
@@ -589,6 +741,7 @@ int nss_csr_destroy(nss_csr_t a) {
     (void)hipFree(a->col16);
     (void)hipFree(a->blkbase);
     (void)hipFree(a->blkseg);
+    (void)hipFree(a->blkdisp);
     (void)hipFree(a->pos16);
     (void)hipFree(a->ell_col);
     (void)hipFree(a->ell_val);
@@ -608,8 +761,11 @@ static void replan(nss_csr_s& A, int products) {
   NSS_HIP(hipMalloc(&rowblk, sizeof(int32_t) * blk.size()));
   NSS_HIP(hipMemcpy(rowblk, blk.data(), sizeof(int32_t) * blk.size(), hipMemcpyHostToDevice));
   for (void* p : {(void*)A.rowblk, (void*)A.col16, (void*)A.blkbase, (void*)A.blkseg, (void*)A.pos16, (void*)A.ell_col,
-                  (void*)A.ell_val})
+                  (void*)A.ell_val, (void*)A.blkdisp})
     (void)hipFree(p);
+  A.blkdisp = nullptr;
+  A.disp_period = 0.0;
+  A.disp_planes = 0;
   A.rowblk = rowblk;
   A.col16 = nullptr;
   A.blkbase = nullptr;
@@ -635,6 +791,23 @@ int nss_csr_plan_for_pairs(nss_csr_t a, int32_t* pair_staged) {
       if (!a->pair_ok) replan(*a, before);               // wide operators: shorter blocks do not help; back to the full plan
     }
     if (pair_staged) *pair_staged = (a->blkseg && a->pair_ok) ? 1 : 0;
+  });
+}
+
+int nss_csr_dispatch_mode(int32_t planes, int32_t min_period, int32_t run) {
+  return guarded([&] {
+    NSS_REQUIRE(planes >= -2 && planes <= 64, "csr_dispatch_mode: planes must be -2 (library default), -1 (automatic), 0 (natural order) or 1 .. 64");
+    g_dispatch_planes = planes == -2 ? NSS_DISPATCH_DEFAULT : planes;
+    g_dispatch_min_period = min_period > 0 ? min_period : NSS_DISPATCH_MIN_PERIOD;
+    g_dispatch_run = run > 0 ? run : NSS_DISPATCH_RUN;
+  });
+}
+
+int nss_csr_dispatch_info(nss_csr_t a, double* period, int32_t* planes) {
+  return guarded([&] {
+    NSS_REQUIRE(a != nullptr, "csr_dispatch_info: NULL matrix");
+    if (period) *period = a->blkdisp ? a->disp_period : 0.0;
+    if (planes) *planes = a->blkdisp ? a->disp_planes : 0;
   });
 }
 

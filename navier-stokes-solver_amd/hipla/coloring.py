@@ -61,6 +61,23 @@ def color_blocks(g, seed=0):
     return colors
 
 
+def color_blocks_greedy(g):
+    """First-fit colours in block order: block i takes the smallest colour none of its already coloured
+    neighbours (j < i) has -- on grid-like block graphs the parity colouring (2 - 4 balanced colours).  The host
+    twin of `nss_graph_color_greedy` (same colours); a plain loop: set-up of small systems and tests only."""
+    nb = g.shape[0]
+    indptr, indices = g.indptr, g.indices
+    colors = -np.ones(nb, dtype=np.int32)
+    for i in range(nb):
+        nbr = indices[indptr[i]:indptr[i + 1]]
+        taken = set(int(c) for c in colors[nbr[nbr < i]])
+        c = 0
+        while c in taken:
+            c += 1
+        colors[i] = c
+    return colors
+
+
 def colour_major_order(colors):
     """Permutation that sorts blocks by colour (stable) and the colour offsets."""
     order = np.argsort(colors, kind="stable")

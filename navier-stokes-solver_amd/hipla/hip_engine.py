@@ -51,11 +51,15 @@ def _signatures():
         "nss_csr_plan_for_pairs": (C.c_int, [vp, c_i32_p]),
         "nss_csr_pair_staged": (C.c_int, [vp, c_i32_p]),
         "nss_csr_pair_mode": (C.c_int, [i32]),
+        "nss_csr_dispatch_mode": (C.c_int, [i32, i32, i32]),
+        "nss_csr_dispatch_info": (C.c_int, [vp, C.POINTER(dbl), c_i32_p]),
         "nss_csr_direct_rows_threshold": (C.c_int, [i64]),
         "nss_scratch_trim": (C.c_int, []),
         "nss_stream_loads_mode": (C.c_int, [i32]),
         "nss_csr_ones_like": (C.c_int, [vp, C.POINTER(vp), vp]),
         "nss_graph_color": (C.c_int, [vp, vp, vp, vp, c_i32_p, vp]),
+        "nss_graph_color_greedy": (C.c_int, [vp, vp, vp, c_i32_p]),
+        "nss_csr_permute": (C.c_int, [vp, i32, vp, vp, i32, i32, vp, i32, vp, C.POINTER(vp), vp]),
         "nss_csr_select_rows": (C.c_int, [vp, i32, vp, i32, vp, C.POINTER(vp), vp]),
         "nss_reciprocal_f64": (C.c_int, [i64, vp, vp, vp]),
         "nss_amg_aggregate": (C.c_int, [vp, dbl, vp, vp, c_i64_p, vp]),
@@ -79,6 +83,7 @@ def _signatures():
         "nss_bjac_apply_f64": (C.c_int, [vp, dbl, vp, dbl, vp, vp]),
         "nss_bjac_info": (C.c_int, [vp, c_i32_p, c_i32_p, c_i64_p, c_i64_p]),
         "nss_bjac_set_colors": (C.c_int, [vp, vp, i32, vp, vp, vp, vp]),
+        "nss_bjac_set_colors_permuted": (C.c_int, [vp, vp, i32, vp, vp, vp, vp]),
         "nss_csr_create_cuts": (C.c_int, [i32, i32, i64, vp, vp, vp, i32, vp, C.POINTER(vp)]),
         "nss_bjac_smooth_f64": (C.c_int, [vp, dbl, vp, vp, i32, vp]),
         "nss_bjac_symgs_apply_f64": (C.c_int, [vp, dbl, vp, vp, vp]),
@@ -135,6 +140,9 @@ def load_library(path=None):
         fn.argtypes = args
     if os.environ.get("NSS_STREAM_LOADS") and hasattr(lib, "nss_stream_loads_mode"):     # measurements: -1 / 0 / 1
         lib.nss_stream_loads_mode(int(os.environ["NSS_STREAM_LOADS"]))
+    if os.environ.get("NSS_DISPATCH_PLANES") and hasattr(lib, "nss_csr_dispatch_mode"):   # measurements: -1 / 0 / T
+        lib.nss_csr_dispatch_mode(int(os.environ["NSS_DISPATCH_PLANES"]), int(os.environ.get("NSS_DISPATCH_MIN_PERIOD", "0")),
+                                  int(os.environ.get("NSS_DISPATCH_RUN", "0")))
     if os.environ.get("NSS_FOLD_SUMS"):                                                   # measurements: -1 / 0 / 1
         for name in ("nss_bpcg2_fold_mode", "nss_minres_fold_mode"):
             if hasattr(lib, name):
@@ -180,7 +188,11 @@ class _CsrHandle:
         form = C.c_int32(width.value == 2)
         if hasattr(lib, "nss_csr_operand_form"):                     # (absent in older A/B builds)
             self.engine._check(lib.nss_csr_operand_form(self.ptr, form))
+        period, planes = C.c_double(0.0), C.c_int32(0)
+        if hasattr(lib, "nss_csr_dispatch_info"):
+            self.engine._check(lib.nss_csr_dispatch_info(self.ptr, C.byref(period), C.byref(planes)))
         return {"operand_form": ("gather32", "gather16", "staged", "rows")[form.value], "pair_staged": self.plan_for_pairs(False),
+                "dispatch_period": period.value, "dispatch_planes": planes.value,
                 "rows": m.value, "cols": n.value, "nnz": nnz.value, "row_blocks": nb.value,
                 "lanes_per_row": rg.value, "algorithmic_bytes": nbytes.value, "index_bytes": width.value,
                 "index_group": group.value}
@@ -430,6 +442,36 @@ class HipEngine:
                                              pri.data_ptr(), colors.data_ptr(), C.byref(ncolors), self.stream))
         return colors.cpu().numpy(), int(ncolors.value)
 
+    def graph_color_greedy(self, g, g_transposed):
+        """First-fit colours in node order (host int32 array), `nss_graph_color_greedy`."""
+        colors = np.zeros(g.m, dtype=np.int32)
+        ncolors = C.c_int32()
+        self._check(self.lib.nss_graph_color_greedy(g.ptr, g_transposed.ptr if g_transposed is not None else None,
+                                                    colors.ctypes.data, C.byref(ncolors)))
+        return colors, int(ncolors.value)
+
+    def csr_permute(self, h, rows, colmap, ncols_out, cuts=None, max_rows=0, row_pos=None):
+        """New matrix whose row r is row rows[r] of `h` with every column c renamed to colmap[c] (`nss_csr_permute`);
+        the launch plan respects `cuts`, `max_rows` rows per row block and the group starts `row_pos == 0`."""
+        rows = np.ascontiguousarray(rows, dtype=np.int32)
+        colmap = np.ascontiguousarray(colmap, dtype=np.int32)
+        if rows.size and (rows.min() < 0 or rows.max() >= h.m):
+            raise ValueError("row index out of range")
+        if colmap.shape != (h.n,) or (colmap.size and (colmap.min() < 0 or colmap.max() >= ncols_out)):
+            raise ValueError("column map out of range")
+        cuts = np.zeros(0, dtype=np.int32) if cuts is None else np.ascontiguousarray(cuts, dtype=np.int32)
+        pos = None if row_pos is None else np.ascontiguousarray(row_pos, dtype=np.uint8)
+        if pos is not None and pos.shape != (rows.size,):
+            raise ValueError("one row_pos byte per row expected")
+        drows = self.torch.from_numpy(rows).to(self.device)
+        dmap = self.torch.from_numpy(colmap).to(self.device)
+        out = C.c_void_p()
+        self._check(self.lib.nss_csr_permute(h.ptr, rows.size, drows.data_ptr() if rows.size else None, dmap.data_ptr(),
+                                             int(ncols_out), cuts.size, cuts.ctypes.data if cuts.size else None,
+                                             int(max_rows), pos.ctypes.data if pos is not None else None, C.byref(out),
+                                             self.stream))
+        return self._wrap_csr(out)
+
     def csr_select_rows(self, h, rows, cuts=None):
         """New matrix whose row r is row rows[r] of `h`; the launch plan respects `cuts`."""
         rows = np.ascontiguousarray(rows, dtype=np.int32)
@@ -496,6 +538,12 @@ class HipEngine:
         self._check(self.lib.nss_bjac_set_colors(h.ptr, perm_handle.ptr, arrs[0].size - 1,
                                                  *[a.ctypes.data for a in arrs]))
         h.keep_matrix = perm_handle         # the sweeps stream the permuted rows: keep them alive
+
+    def bjac_set_colors_permuted(self, h, perm_handle, color_ptr, color_rowptr, rowdof, ridx):
+        arrs = [np.ascontiguousarray(a, dtype=np.int32) for a in (color_ptr, color_rowptr, rowdof, ridx)]
+        self._check(self.lib.nss_bjac_set_colors_permuted(h.ptr, perm_handle.ptr, arrs[0].size - 1,
+                                                          *[a.ctypes.data for a in arrs]))
+        h.keep_matrix = perm_handle
 
     def bjac_smooth(self, h, xscale, x, y, backward):
         if x.shape[0] != h.n or y.shape[0] != h.n:

@@ -622,10 +622,19 @@ class BlockGaussSeidel(BaseMatrix):
     (``nss_bjac_smooth_f64``); the ordering differs from NGSolve's mesh-facet order (upstream,
     not visible), so iteration counts are pinned against the build's own CPU oracle only."""
 
-    def __init__(self, mat, blocks, seed=0, colors=None, middle=None):
+    def __init__(self, mat, blocks, seed=0, colors=None, middle=None, layout=None, coloring_method=None):
         """`colors` (one int per block) may be supplied when the system has already been
         re-ordered colour-major on the host (`coloring.colour_permutation`): the sweep then
         touches x, y and the inverse blocks contiguously.
+
+        `layout`: "colour-major" (default on the HIP engine; NSS_GS_LAYOUT overrides) -- inside the sweep the
+        iterate, the right-hand side and the matrix (P A P^T) live in the colour-major block numbering: x and y are
+        gathered once on entry and y scattered once on exit, every colour is one launch (block solve in the SpMV's
+        epilogue) over contiguous data; "rows" -- round 1's form: rows of A permuted, columns and vectors in the
+        original numbering, two launches per colour.  Same bits for the same colours.
+        `coloring_method`: "greedy" (default; first fit in block order on the host: the parity colouring of grid-like
+        block graphs, 2 - 4 balanced colours) or "luby" (maximal independent sets on the device: 5 - 6 colours with a
+        tail of tiny ones).  NSS_GS_COLORING overrides.
 
         `middle` (an operator M, e.g. the auxiliary-space term ``T @ AMG @ T.T``) reproduces the
         full ``MypreA.Mult`` of the reference with ``GS=True`` (:376-381):
@@ -636,18 +645,29 @@ class BlockGaussSeidel(BaseMatrix):
         self.mat = mat
         self.middle = middle
         self.n = mat.height
+        import os
         base = BlockJacobi._as_table(blocks)
         on_device = colors is None and hasattr(self.engine, "graph_color")
+        layout = layout or os.environ.get("NSS_GS_LAYOUT", "colour-major")
+        method = coloring_method or os.environ.get("NSS_GS_COLORING", "greedy")
+        if layout not in ("colour-major", "rows") or method not in ("greedy", "luby"):
+            raise ValueError("layout: 'colour-major' | 'rows'; coloring_method: 'greedy' | 'luby'")
+        if not hasattr(self.engine, "csr_permute"):
+            layout = "rows"
+        self.layout, self.coloring_method = layout, (method if colors is None else "given")
         if on_device:
-            # block graph (two sparse products of patterns) and Luby colouring on the GPU: a proper
-            # colouring by construction (of two adjacent candidates only the higher priority wins)
-            colors = self._device_colors(mat, base, seed)
+            # block graph (two sparse products of patterns) on the GPU, then first-fit colours in block order (host) or
+            # Luby rounds (device): proper colourings by construction
+            colors = self._device_colors(mat, base, seed, method)
         else:
             graph = coloring.block_graph(mat.to_scipy(), base)
-            colors = coloring.color_blocks(graph, seed) if colors is None else np.asarray(colors, dtype=np.int32)
+            if colors is None:
+                colors = coloring.color_blocks_greedy(graph) if method == "greedy" else coloring.color_blocks(graph, seed)
+            colors = np.asarray(colors, dtype=np.int32)
             if colors.shape != (base.shape[1],) or not coloring.check_coloring(graph, colors):
                 raise RuntimeError("block colouring is not proper")
         order, ptr = coloring.colour_major_order(colors)
+        self.colors = np.asarray(colors, dtype=np.int32)            # per block, in the caller's block order
         self.idx_host = np.ascontiguousarray(base[:, order])
         self.color_ptr = ptr
         self.ncolors = int(ptr.size - 1)
@@ -662,6 +682,18 @@ class BlockGaussSeidel(BaseMatrix):
         rows_per_block = live.sum(axis=1)
         block_row0 = np.concatenate([[0], np.cumsum(rows_per_block)])
         color_rowptr = block_row0[ptr]
+        if layout == "colour-major":
+            # P A P^T: columns renamed too (dofs outside every block -> the extra column n_perm, which stays 0); row
+            # blocks of at most 256 rows that hold whole Gauss-Seidel blocks
+            n_perm = int(rowdof.size)
+            colmap = np.full(self.n, n_perm, dtype=np.int32)
+            colmap[rowdof] = np.arange(n_perm, dtype=np.int32)
+            pos = (np.arange(n_perm, dtype=np.int64) - np.repeat(block_row0[:-1], rows_per_block)).astype(np.uint8)
+            self.perm_handle = self.engine.csr_permute(mat.handle, rowdof, colmap, n_perm + 1, cuts=color_rowptr,
+                                                       max_rows=256, row_pos=pos)
+            self.engine.bjac_set_colors_permuted(self.handle, self.perm_handle, ptr, color_rowptr, rowdof,
+                                                 np.ascontiguousarray(ridx.T))
+            return
         if hasattr(self.engine, "csr_select_rows"):
             self.perm_handle = self.engine.csr_select_rows(mat.handle, rowdof, cuts=color_rowptr)
         else:
@@ -673,7 +705,7 @@ class BlockGaussSeidel(BaseMatrix):
                                     np.ascontiguousarray(ridx.T))
 
     @staticmethod
-    def _device_colors(mat, base, seed):
+    def _device_colors(mat, base, seed, method="luby"):
         """Colours of the blocks `base` (bs x nblocks table): adjacency M^T |A| M of the blocks by two
         device SpGEMMs over 0/1 patterns (no cancellation), then `nss_graph_color` with the priorities
         `coloring.color_blocks` would use -- the result equals the host colouring."""
@@ -687,8 +719,11 @@ class BlockGaussSeidel(BaseMatrix):
         pattern = eng.csr_ones_like(mat.handle)
         graph = SparseMatrix.from_handle(
             eng.csr_spgemm(member.CreateTranspose().handle, eng.csr_spgemm(pattern, member.handle)), eng)
-        priority = np.random.default_rng(seed).permutation(nb).astype(np.int64) + 1
-        colors, _ = eng.graph_color(graph.handle, graph.CreateTranspose().handle, priority)
+        if method == "greedy" and hasattr(eng, "graph_color_greedy"):
+            colors, _ = eng.graph_color_greedy(graph.handle, graph.CreateTranspose().handle)
+        else:
+            priority = np.random.default_rng(seed).permutation(nb).astype(np.int64) + 1
+            colors, _ = eng.graph_color(graph.handle, graph.CreateTranspose().handle, priority)
         if hasattr(eng, "scratch_trim"):
             eng.scratch_trim()
         return colors

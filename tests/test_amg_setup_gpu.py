@@ -140,11 +140,16 @@ def test_device_colouring_and_row_selection(hip_engine):
         A.sort_indices()
         idx = s.line_blocks(bs)
         Ad = hipla.SparseMatrix.from_scipy(A)
-        dev = hipla.BlockGaussSeidel._device_colors(Ad, idx, 0)
+        dev = hipla.BlockGaussSeidel._device_colors(Ad, idx, 0, "luby")
         graph = coloring.block_graph(A, idx)
         host = coloring.color_blocks(graph, 0)
         np.testing.assert_array_equal(dev, host)
         assert coloring.check_coloring(graph, dev)
+        # the default: first fit in block order on the host (nss_graph_color_greedy) == its Python twin; on these
+        # grid-like block graphs the parity colouring, fewer colours than the maximal independent sets
+        greedy = hipla.BlockGaussSeidel._device_colors(Ad, idx, 0, "greedy")
+        np.testing.assert_array_equal(greedy, coloring.color_blocks_greedy(graph))
+        assert coloring.check_coloring(graph, greedy) and greedy.max() < dev.max() and greedy.max() <= 3
         rng = np.random.default_rng(dim)
         rows = rng.permutation(A.shape[0])[: A.shape[0] * 2 // 3].astype(np.int32)
         cuts = np.array([0, rows.size // 3, rows.size], dtype=np.int32)

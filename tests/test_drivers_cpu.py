@@ -113,8 +113,11 @@ def test_multicolour_block_gauss_seidel_against_sequential_oracle(numpy_engine):
         idx = s.line_blocks(3) if blocks == "line" else s.facet_blocks()
         A = hipla.SparseMatrix.from_scipy(s.A)
         g = coloring.block_graph(s.A, idx)
-        colors = coloring.color_blocks(g)
-        assert coloring.check_coloring(g, colors) and colors.min() == 0
+        luby = coloring.color_blocks(g)
+        colors = coloring.color_blocks_greedy(g)          # the default: first fit in block order
+        assert coloring.check_coloring(g, luby) and luby.min() == 0
+        assert coloring.check_coloring(g, colors) and colors.min() == 0 and colors.max() <= luby.max()
+        assert hipla.BlockGaussSeidel(A, idx, coloring_method="luby").ncolors == luby.max() + 1
         G = hipla.BlockGaussSeidel(A, idx)
         assert G.ncolors == colors.max() + 1 and sorted(G.idx_host[G.idx_host >= 0]) == list(range(s.n_u))
         rng = np.random.default_rng(0)

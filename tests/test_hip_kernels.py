@@ -462,6 +462,27 @@ def test_multicolour_block_gauss_seidel_sweeps(hip_engine, case):
     assert abs(np.dot(out.numpy(), z) - np.dot(x, gz.numpy())) < 1e-10 * np.linalg.norm(x) * np.linalg.norm(gz.numpy())
     out.data = 2.5 * G * X                       # scaled operator (preA = k * preA_unscaled)
     assert relerr(out.numpy(), 2.5 * kr.symmetric_block_gauss_seidel(s.A, G.idx_host)(x)) < 1e-12
+    # the default is the colour-major layout inside the sweep (P A P^T, x / y gathered once, one launch per colour with
+    # the block solve in the epilogue) over first-fit colours; round 1's form (rows of A permuted only, two launches
+    # per colour) with the same colours gives the same bits, and so does every other proper colouring against ITS
+    # sequential order
+    assert G.layout == "colour-major" and G.coloring_method == "greedy"
+    R = hipla.BlockGaussSeidel(A, blocks, colors=G.colors, layout="rows")
+    assert R.layout == "rows" and np.array_equal(R.idx_host, G.idx_host)
+    for op in ("Smooth", "SmoothBack", "Mult"):
+        ya, yb = hipla.Vector.from_numpy(y0), hipla.Vector.from_numpy(y0)
+        if op == "Mult":
+            G.Mult(X, ya), R.Mult(X, yb)
+        else:
+            getattr(G, op)(ya, X), getattr(R, op)(yb, X)
+        np.testing.assert_array_equal(ya.numpy(), yb.numpy())
+    L = hipla.BlockGaussSeidel(A, blocks, coloring_method="luby")
+    assert L.coloring_method == "luby" and L.ncolors >= G.ncolors
+    yl = hipla.Vector.from_numpy(y0)
+    L.Smooth(yl, X)
+    assert relerr(yl.numpy(), kr.block_gauss_seidel_sweep(s.A, L.idx_host, x, y0)) < 1e-12
+    if case == "line3_2d":
+        assert G.ncolors <= 3 and L.ncolors >= 4     # parity colouring of the grid-like block graph vs Luby's MIS tail
 
 
 def test_csr_transpose_native(hip_engine):

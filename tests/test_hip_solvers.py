@@ -615,6 +615,62 @@ def test_pair_staged_operands_give_identical_bits(hip_engine, dim, n, inflate):
         assert bt_info["pair_staged"] or bt_info["operand_form"] == "rows"
 
 
+def test_reuse_aware_dispatch_order_changes_no_bit(hip_engine):
+    """Grid operators beyond ~1e7 rows get a second, dispatch-ordered copy of their row-block descriptors
+    (csrc/csr_stream.h: blkdisp): inside every XCD's share the blocks b, b + P, ..., b + (T - 1) P of T grid planes
+    run back to back, so that the operand runs of the neighbouring planes are re-read while they are still in the
+    XCD's L2.  Only the workgroup -> row block map changes -- forced on here for a small system (T = 3 and 8): the
+    period found is the number of row blocks per grid slab, every row block is still visited exactly once (SpMV
+    and its dot partials complete), and the fused loops give the bits of the natural order."""
+    import hipla
+    from minres import MinRes
+    from solvers.bramblepasciak_new import BpcgSession
+    s = mac_stokes(3, 40, 0.01)
+    f, g = s.rhs(0)
+    lib = hip_engine.lib
+    x = np.random.default_rng(1).standard_normal(s.n_u)
+
+    def run(planes, nit=25):
+        assert lib.nss_csr_dispatch_mode(planes, 0, 5 if planes == 8 else 0) == 0
+        A, B = hipla.SparseMatrix.from_scipy(s.A), hipla.SparseMatrix.from_scipy(s.B)
+        ya, yb = hipla.Vector(s.n_u), hipla.Vector(s.n_p)
+        xv = hipla.Vector.from_numpy(x)
+        ya.data = A * xv
+        yb.data = B * xv
+        preA = hipla.BlockJacobi(A, s.line_blocks(3))
+        preS = hipla.DiagonalMatrix(1.0 / s.mass)
+        sol = hipla.BlockVector([hipla.Vector(s.n_u), hipla.Vector(s.n_p)])
+        with contextlib.redirect_stdout(io.StringIO()):
+            ses = BpcgSession(Form(A), Form(B), None, hipla.Vector.from_numpy(f), hipla.Vector.from_numpy(g), preA, preS,
+                              sol=sol)
+            ses.first_direction()
+            ses.fused.start(ses.wdn, ses.err0, 0.0, True, nit)
+            ses.fused.enqueue(0, nit)
+            ses.fused.poll()
+            K = hipla.BlockMatrix([[A, B.T], [B, None]])
+            Cm = hipla.BlockMatrix([[preA, None], [None, preS]])
+            u, errors = MinRes(mat=K, pre=Cm, rhs=hipla.BlockVector([hipla.Vector.from_numpy(f), hipla.Vector.from_numpy(g)]),
+                               maxsteps=nit, tol=0.0, printrates=False)
+        return dict(ya=ya.numpy(), yb=yb.numpy(), hist=ses.fused.history(nit - 1).copy(), sol=sol.numpy(),
+                    minres=np.array(errors), a=A.handle.info(), b=B.handle.info())
+
+    try:
+        ref = run(0)
+        assert ref["a"]["dispatch_period"] == 0.0 and ref["a"]["operand_form"] == "staged"
+        np.testing.assert_allclose(ref["ya"], s.A @ x, rtol=1e-13, atol=1e-13)
+        for planes in (3, 8):
+            got = run(planes)
+            rows_per_block = s.n_u / got["a"]["row_blocks"]
+            slab = s.velocity_slab_offsets[1] - s.velocity_slab_offsets[0]
+            assert got["a"]["dispatch_planes"] == planes
+            assert abs(got["a"]["dispatch_period"] - slab / rows_per_block) < 0.05 * slab / rows_per_block + 2
+            for key in ("ya", "yb", "hist", "sol", "minres"):
+                np.testing.assert_array_equal(got[key], ref[key])
+        assert np.all(np.isfinite(ref["hist"]))
+    finally:
+        lib.nss_csr_dispatch_mode(-2, 0, 0)
+
+
 @pytest.mark.parametrize("case", ["stokes3d_n10_bjac_minres", "stokes2d_n24_jacobi_minres",
                                   "stokes3d_n5_facet_x12_minres"])
 def test_minres_sum_placement_gives_identical_bits(hip_engine, case):
