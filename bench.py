@@ -63,6 +63,9 @@ def parse_args():
     ap.add_argument("--windows", type=int, default=5,
                     help="consecutive timed windows of --steps iterations each; `value` is their median "
                          "(a single ~0.1-s window cannot separate a 3 %% change from noise), all reported as window_values")
+    ap.add_argument("--mypre-a", dest="mypre_a", type=int, default=1,
+                    help="1: also run the reference's default preconditioner MypreA(GS=True) with the auxiliary-space term on "
+                         "the headline system (`roofline_mypre_a_gs`); 0 skips it")
     ap.add_argument("--secondary", type=int, default=1,
                     help="1: also time the other BASELINE configurations (cfg2 MINRES, cfg3 BPCG v2) and MINRES / BPCG v1 "
                          "at the headline size through their entry points (`secondary_configs`); 0 skips them")
@@ -178,6 +181,113 @@ def entry_point_rates(torch, hipla, sysm, A, B, preA, solvers, k1, k2):
         out[name] = {"entry_point": entry, "iters_per_s": 1.0 / per, "us_per_iteration": 1e6 * per,
                      "spmv_per_iteration": spmv, "iterations_timed": [k1, k2]}
     return out
+
+
+def mypre_a_gs_roofline(torch, eng, hipla, sysm, A, B, its=60, warm=10):
+    """The reference's DEFAULT velocity preconditioner on the headline system (what `SolveInitial(iterative=True)`
+    runs: templates/NavierStokesSIMPLE_iterative.py:168,360-391,397): MypreA(GS=True) = forward multicolour block
+    Gauss-Seidel sweep over the facet-like blocks, residual, auxiliary-space correction `transform @ preAh1 @
+    transform.T` (one V-cycle per velocity component on the nodal Laplacians), backward sweep -- natively inside the
+    fused BPCG v2 loop.  Iteration rate, and the device time / algorithmic bytes / fraction of the HBM peak of its two
+    kernels groups: one sweep call (gather into the colour-major numbering, one launch per colour with the block solve
+    in the epilogue, scatter) and the auxiliary-space term (two SpMVs with the transform around the component V-cycles),
+    each timed with HIP events between cache-sweeping launches."""
+    import contextlib
+    import io
+    from solvers.bramblepasciak_new import BpcgSession
+    from templates.NavierStokesSIMPLE_iterative import MypreA, auxiliary_space_preconditioner
+    t0 = time.perf_counter()
+    _, _, aux = auxiliary_space_preconditioner(sysm)
+    preA = MypreA(None, Form(A), sysm.line_blocks(3), GS=True, aux=aux)
+    torch.cuda.synchronize()
+    t_pre = time.perf_counter() - t0
+    f, g = sysm.rhs(0)
+    sol = hipla.BlockVector([hipla.Vector(sysm.n_u), hipla.Vector(sysm.n_p)])
+    t0 = time.perf_counter()
+    with contextlib.redirect_stdout(io.StringIO()):
+        ses = BpcgSession(Form(A), Form(B), None, hipla.Vector.from_numpy(f), hipla.Vector.from_numpy(g), preA,
+                          hipla.DiagonalMatrix(1.0 / sysm.mass), sol=sol)
+    loop = ses.fused
+    if loop is None:
+        raise RuntimeError("fused loop declined MypreA(GS=True) with the auxiliary-space term")
+    ses.first_direction()
+    loop.start(ses.wdn, ses.err0, 0.0, True, warm + 3 * its + 40)
+    loop.enqueue(0, warm)
+    torch.cuda.synchronize()
+    t_setup = time.perf_counter() - t0
+    wins = []
+    for w in range(3):
+        t0 = time.perf_counter()
+        loop.enqueue(warm + w * its, warm + (w + 1) * its)
+        torch.cuda.synchronize()
+        wins.append((time.perf_counter() - t0) / its)
+    per_it = sorted(wins)[1]
+    marks = []
+    for it in range(warm + 3 * its, warm + 3 * its + 32):       # C1 + the whole preconditioner apply, inside the loop
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        loop.cphases("C1", "C1", it)
+        e1.record()
+        loop.cphases("C23", "SUMW", it)
+        marks.append((e0, e1))
+    torch.cuda.synchronize()
+    c1_ms = sum(a.elapsed_time(b) for a, b in marks[8:]) / (len(marks) - 8)
+    done, _, last = loop.poll()
+    valid = bool((not done) and np_isfinite(loop.history(last)))
+    # the two kernel groups on their own, between launches that sweep the caches
+    n = sysm.n_u
+    x, y = hipla.Vector.from_numpy(f), hipla.Vector(n)
+    big = [eng.zeros(1 << 25) for _ in range(3)]
+
+    def timed(fn, reps=12):
+        ev = []
+        for _ in range(reps + 2):
+            eng.stream_triad(0.5, big[0], big[1], big[2])
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            fn()
+            b.record()
+            ev.append((a, b))
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in ev[2:]) / reps
+
+    sweep_ms = timed(lambda: preA.Smooth(y, x))
+    aux_ms = timed(lambda: aux.Mult(x, y))
+    p = preA.perm_handle.info()
+    bs = preA.bs
+    sweep_bytes = (8 * p["nnz"] + p["index_bytes"] * (p["nnz"] // p["index_group"]) + 4 * (p["rows"] + 1)   # P A P^T as stored
+                   + 8 * bs * n + 8 * n + 16 * n                                                            # inverse blocks, x, y in / out
+                   + 2 * 16 * n + 16 * n)                                                                   # gathers of x, y; scatter of y
+    spmv_bytes = lambda i: i["algorithmic_bytes"]
+    aux_bytes = spmv_bytes(aux.transform.handle.info()) + spmv_bytes(aux.transform_t.handle.info())
+    for comp in aux.components:
+        for lv in comp.levels:
+            aux_bytes += spmv_bytes(lv["inv"].handle.info()) if "inv" in lv else (
+                2 * spmv_bytes(lv["A"].handle.info()) + spmv_bytes(lv["P"].handle.info()) + spmv_bytes(lv["R"].handle.info())
+                + 8 * 6 * lv["n"])
+
+    def roof(nbytes, ms):
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        return {"avg_ms": ms, "algorithmic_bytes": int(nbytes), "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": gbs / HBM_PEAK_GBS}
+
+    return {"workload": "headline system (%d DoF), BPCG v2, preA = MypreA(GS=True): multicolour block Gauss-Seidel sweeps "
+                        "(bs=%d, %d colours, %s layout) around the auxiliary-space term (%d component V-cycles, levels %s)"
+                        % (sysm.ndof, bs, preA.ncolors, preA.layout, len(aux.components), aux.level_sizes[0]),
+            "reference": "templates/NavierStokesSIMPLE_iterative.py:168,376-381,397",
+            "iters_per_s": 1.0 / per_it, "ms_per_iteration": 1e3 * per_it, "window_values": [1.0 / w for w in wins],
+            "scale_factor_k": ses.k, "C1_with_whole_preA_ms_in_loop": c1_ms,
+            "sweep_call": dict(roof(sweep_bytes, sweep_ms), kernel="gs_enter + csr_stream_kernel<EpiGsFused> x %d colours + "
+                               "gs_leave (one Smooth / SmoothBack call)" % preA.ncolors, calls_per_iteration=2),
+            "auxiliary_space_term": dict(roof(aux_bytes, aux_ms), kernel="T^T SpMV, %d smoothed-aggregation V(1,1)-cycles, "
+                                         "T SpMV (nss_amg_create_auxiliary)" % len(aux.components), calls_per_iteration=1),
+            "setup_s": {"amg_hierarchies_colouring_permutation": t_pre, "scale_factor_initial_residual": t_setup},
+            "valid": valid}
+
+
+def np_isfinite(a):
+    import numpy as np
+    return bool(np.all(np.isfinite(a)))
 
 
 def secondary_configs(torch, hipla, headline=None):
@@ -658,6 +768,13 @@ def main():
 
     hdg = None
     scale_k, folds = ses.k, loop.folds_sums()
+    mypre = None
+    if args.mypre_a and args.inflate == 1 and args.pre == "bjac3" and args.dim == 3:
+        try:                                                # (never at the cost of the headline line)
+            mypre = mypre_a_gs_roofline(torch, eng, hipla, sysm, A, B)
+        except Exception as exc:
+            mypre = {"error": repr(exc)}
+        torch.cuda.empty_cache()
     secondary = None
     if args.secondary and args.inflate == 1 and args.pre == "bjac3":
         try:                                                # secondary measurements must never cost the headline line
@@ -713,6 +830,7 @@ def main():
                      "timing": "HIP events around the kernel inside %d iterations of the running loop" % (probe_its - 8)},
         "cpu_baseline": cpu,
         "roofline_hdg_like": hdg,
+        "roofline_mypre_a_gs": mypre,
         "secondary_configs": secondary,
         "valid": valid,
         "hbm_GBs": {"whole_iteration_algorithmic": iter_gbs, "stream_triad": triad_gbs,

@@ -501,6 +501,40 @@ NSS_API int nss_cg_iterate(const nss_cg_t* s, int32_t it_begin, int32_t it_end, 
 NSS_API int nss_cg_poll(const nss_cg_t* s, int32_t* done, int32_t* it_final, int32_t* last_it,
                         nss_stream_t stream);
 
+/* ---- device-resident preconditioned Lanczos: the scale factor k -------------------------------
+ * Replaces the n-sized work AND the scalar recurrences of `EigenValues_Preconditioner(mat=A, pre=preA, tol=1e-3)`
+ * (call sites bramble_pasciak_cg.py:68-74, solvers/bramblepasciak_new.py:111-122; the reference times it inside
+ * its solver time, run.py:34-38; NGSolve's implementation is upstream: parity unpinned against it, pinned against
+ * the identical recurrence of oracle/krylov_ref.py::lanczos_ritz).  v[0] holds the start vector on entry; the
+ * library keeps the Lanczos vectors un-normalised and carries the factors in `scal` (csrc/lanczos.hip).  Step j
+ * appends hist[2j] = delta_j, hist[2j+1] = gamma_{j+1}: T = tridiag(gamma_1.., delta_0.., gamma_1..); the host
+ * reads them once per batch of steps and solves the small eigenproblem.
+ * preA = pre_scale * (pre_amg + (pre_diag | pre_bjac)) as in nss_bpcg2_t (additive MypreA, :383), or -- pre_bjac in
+ * Gauss-Seidel mode together with pre_amg -- the multiplicative MypreA (:376-381) with this A in its residual.
+ * scal: double[8]; ctrl: int32[4] = { stop, j_stop (-1: gamma_0 == 0), last_j, - }: stop is set by the breakdown
+ * test gamma_{j+1} <= 1e-14 max(|delta_0|, |delta_j|), after which every kernel returns at once. */
+typedef struct nss_lanczos_s {
+  nss_csr_t A;
+  const double* pre_diag;
+  nss_bjac_t pre_bjac;
+  nss_amg_t pre_amg;
+  double pre_scale;
+  double* v[3];                /* ring: step j reads v[j % 3] (and v[(j + 2) % 3]), writes v[(j + 1) % 3] */
+  double* z[2];                /* ring: step j reads z[j % 2], writes z[(j + 1) % 2]                      */
+  double* p;
+  double* scal;
+  int32_t* ctrl;
+  double* hist;                /* double[2 * maxsteps]                                                     */
+  double *partials_a, *partials_b;  /* sizes: nss_lanczos_workspace()                                      */
+  int32_t n;
+} nss_lanczos_t;
+NSS_API int nss_lanczos_workspace(const nss_lanczos_t* s, int64_t* partials_a, int64_t* partials_b);
+/* z[0] = preA v[0], gamma_0 = sqrt|<z[0], v[0]>|; clears scal / ctrl */
+NSS_API int nss_lanczos_start(const nss_lanczos_t* s, nss_stream_t stream);
+/* enqueue steps j_begin .. j_end - 1: no host synchronisation */
+NSS_API int nss_lanczos_iterate(const nss_lanczos_t* s, int32_t j_begin, int32_t j_end, nss_stream_t stream);
+NSS_API int nss_lanczos_poll(const nss_lanczos_t* s, int32_t* stop, int32_t* j_stop, int32_t* last_j, nss_stream_t stream);
+
 /* ---- fused preconditioned MINRES ----------------------------------------------------------
  * Replaces the loop body of minres.py:96-144 for K = [[A, B^T], [B, 0]], C = diag(preA, preS)
  * (the operands run.py:45-46 builds).  Vectors are given per block component ([0] velocity, n_u;

@@ -30,6 +30,89 @@ def _tridiag_eigs(diag, off):
     return eigvalsh_tridiagonal(np.asarray(diag), np.asarray(off[: len(diag) - 1]))
 
 
+class _LanczosState:
+    """ctypes mirror of ``nss_lanczos_t`` (include/nss_krylov.h), built lazily (no ctypes at import)."""
+    _cls = None
+
+    @classmethod
+    def get(cls):
+        if cls._cls is None:
+            import ctypes as C
+
+            class LanczosState(C.Structure):
+                _fields_ = ([(n, C.c_void_p) for n in ("A", "pre_diag", "pre_bjac", "pre_amg")]
+                            + [("pre_scale", C.c_double), ("v", C.c_void_p * 3), ("z", C.c_void_p * 2), ("p", C.c_void_p),
+                               ("scal", C.c_void_p), ("ctrl", C.c_void_p), ("hist", C.c_void_p),
+                               ("partials_a", C.c_void_p), ("partials_b", C.c_void_p), ("n", C.c_int32)])
+            cls._cls = LanczosState
+        return cls._cls
+
+
+NATIVE = True          # tests flip this to force the protocol recurrence on native operands
+
+
+def _native_lanczos(mat, pre, start, tol, maxsteps, check_every):
+    """The same recurrence resident on the device (csrc/lanczos.hip: nss_lanczos_*): per step an SpMV with the dot in
+    its epilogue, one element-wise kernel, the preconditioner (+ dot) and two single-workgroup sums that also advance
+    the scalars; the host reads the new (delta, gamma) pairs once per `check_every` steps.  Returns None when an
+    operand is not native to the HIP engine (the caller then runs the protocol recurrence)."""
+    import ctypes as C
+    from . import fused
+    from .matrix import SparseMatrix
+    from .vector import Vector
+    if not (NATIVE and fused.ENABLED and isinstance(mat, SparseMatrix) and isinstance(start, Vector)):
+        return None
+    eng = mat.engine
+    if getattr(eng, "name", "") != "hip-gfx950" or not hasattr(eng.lib, "nss_lanczos_iterate") or mat.height != mat.width:
+        return None
+    pa = fused.native_velocity_pre(pre)
+    if pa is None or (pa["multiplicative"] and pa["bjac"].mat is not mat):
+        return None
+    n = mat.height
+    st = _LanczosState.get()()
+    st.A = mat.handle.ptr
+    st.pre_diag = pa["diag"].d.data_ptr() if pa["diag"] is not None else None
+    st.pre_bjac = pa["bjac"].handle.ptr if pa["bjac"] is not None else None
+    st.pre_amg = pa["amg"].handle.ptr if pa["amg"] is not None else None
+    st.pre_scale = float(pa["scale"])
+    vecs = [eng.zeros(n) for _ in range(6)]
+    eng.copy(start.buf, vecs[0])
+    for i in range(3):
+        st.v[i] = vecs[i].data_ptr()
+    st.z[0], st.z[1], st.p = vecs[3].data_ptr(), vecs[4].data_ptr(), vecs[5].data_ptr()
+    st.n = n
+    na, nb = C.c_int64(), C.c_int64()
+    eng._check(eng.lib.nss_lanczos_workspace(C.byref(st), C.byref(na), C.byref(nb)))
+    partials = [eng.zeros(max(1, na.value)), eng.zeros(max(1, nb.value))]
+    st.partials_a, st.partials_b = partials[0].data_ptr(), partials[1].data_ptr()
+    scal = eng.zeros(8)
+    ctrl = eng.torch.zeros(4, dtype=eng.torch.int32, device=eng.device)
+    hist = eng.zeros(2 * maxsteps)
+    st.scal, st.ctrl, st.hist = scal.data_ptr(), ctrl.data_ptr(), hist.data_ptr()
+    eng._check(eng.lib.nss_lanczos_start(C.byref(st), eng.stream))
+    stop, j_stop, last = C.c_int32(), C.c_int32(), C.c_int32()
+    ritz = np.zeros(0)
+    lo_prev = hi_prev = None
+    j = 0
+    while j < maxsteps:
+        end = min(maxsteps, j + check_every)
+        eng._check(eng.lib.nss_lanczos_iterate(C.byref(st), j, end, eng.stream))
+        eng._check(eng.lib.nss_lanczos_poll(C.byref(st), C.byref(stop), C.byref(j_stop), C.byref(last), eng.stream))
+        if stop.value and j_stop.value < 0:
+            return np.zeros(0)                           # gamma_0 == 0
+        j_last = j_stop.value if stop.value else end - 1
+        h = eng.to_host(hist[: 2 * (j_last + 1)])
+        ritz = _tridiag_eigs(list(h[0::2][: j_last + 1]), list(h[1::2][: j_last]))
+        lo, hi = float(ritz[0]), float(ritz[-1])
+        if stop.value:
+            break
+        if lo_prev is not None and abs(lo - lo_prev) <= tol * abs(lo) and abs(hi - hi_prev) <= tol * abs(hi):
+            break
+        lo_prev, hi_prev = lo, hi
+        j = end
+    return ritz
+
+
 def lanczos_ritz(mat, pre, start, tol=1e-10, maxsteps=2000, check_every=5, dot=InnerProduct):
     """Preconditioned Lanczos on ``mat`` with SPD (possibly range-restricted) ``pre``.
 
@@ -38,6 +121,10 @@ def lanczos_ritz(mat, pre, start, tol=1e-10, maxsteps=2000, check_every=5, dot=I
     z_{j+1} = pre r_{j+1}; gamma_{j+1} = sqrt<z_{j+1}, r_{j+1}>.
     T = tridiag(gamma, delta, gamma); Ritz values = eig(T).  Stops when both
     extreme Ritz values moved by < tol (relative) between two checks."""
+    if dot is InnerProduct and getattr(start, "comm", None) is None:
+        native = _native_lanczos(mat, pre, start, tol, maxsteps, check_every)
+        if native is not None:
+            return native
     v = start.CreateVector()
     v.data = start
     v_old = start.CreateVector()

@@ -51,6 +51,10 @@ def _signatures():
         "nss_csr_plan_for_pairs": (C.c_int, [vp, c_i32_p]),
         "nss_csr_pair_staged": (C.c_int, [vp, c_i32_p]),
         "nss_csr_pair_mode": (C.c_int, [i32]),
+        "nss_lanczos_workspace": (C.c_int, [vp, c_i64_p, c_i64_p]),
+        "nss_lanczos_start": (C.c_int, [vp, vp]),
+        "nss_lanczos_iterate": (C.c_int, [vp, i32, i32, vp]),
+        "nss_lanczos_poll": (C.c_int, [vp, c_i32_p, c_i32_p, c_i32_p, vp]),
         "nss_csr_dispatch_mode": (C.c_int, [i32, i32, i32]),
         "nss_csr_dispatch_info": (C.c_int, [vp, C.POINTER(dbl), c_i32_p]),
         "nss_csr_direct_rows_threshold": (C.c_int, [i64]),

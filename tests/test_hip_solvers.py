@@ -615,6 +615,61 @@ def test_pair_staged_operands_give_identical_bits(hip_engine, dim, n, inflate):
         assert bt_info["pair_staged"] or bt_info["operand_form"] == "rows"
 
 
+def test_device_resident_lanczos_matches_the_protocol_recurrence(hip_engine):
+    """`EigenValues_Preconditioner` (scale factor k: bramble_pasciak_cg.py:68-74, solvers/bramblepasciak_new.py:111-122)
+    on native operands runs the Lanczos recurrence resident on the device (csrc/lanczos.hip: un-normalised vectors, the
+    dots in the epilogues of the SpMV / block-Jacobi kernels, scalars advanced by the sum kernels; the host reads the
+    tridiagonal once per 5 steps).  Same recurrence, same start vector as the statement-by-statement protocol form
+    (two host-synchronising dots per step) and as the oracle: Ritz values to 1e-12 / 1e-10, same number of steps --
+    for point / block Jacobi, the symmetric Gauss-Seidel sweep, a V-cycle and both forms of MypreA."""
+    import hipla
+    from hipla import eigen
+    from templates.NavierStokesSIMPLE_iterative import MypreA, auxiliary_space_preconditioner
+    s = mac_stokes(3, 12, 0.01)
+    A = hipla.SparseMatrix.from_scipy(s.A)
+    blocks = s.line_blocks(3)
+    _, _, aux = auxiliary_space_preconditioner(s)
+    G = hipla.BlockGaussSeidel(A, blocks)
+    pres = {"jacobi": hipla.JacobiPreconditioner(A), "bjac": hipla.BlockJacobi(A, blocks), "bgs": G,
+            "amg": hipla.SmoothedAggregationAMG(A, coarse_size=300), "scaled_bjac": 2.5 * hipla.BlockJacobi(A, blocks),
+            "mypre_additive": MypreA(None, Form(A), blocks, GS=False, aux=aux),
+            "mypre_multiplicative": MypreA(None, Form(A), blocks, GS=True, aux=aux)}
+    calls = []
+    orig = eigen._native_lanczos
+
+    def spy(*a, **k):
+        out = orig(*a, **k)
+        calls.append(out is not None)
+        return out
+
+    eigen._native_lanczos = spy
+    try:
+        for name, pre in pres.items():
+            for tol in (1e-3, 1e-10):
+                del calls[:]
+                native = eigen.EigenValues_Preconditioner(mat=A, pre=pre, tol=tol)
+                assert calls == [True], name
+                eigen.NATIVE = False
+                try:
+                    del calls[:]
+                    proto = eigen.EigenValues_Preconditioner(mat=A, pre=pre, tol=tol)
+                    assert calls == [False]
+                finally:
+                    eigen.NATIVE = True
+                assert len(native) == len(proto), (name, tol, len(native), len(proto))
+                np.testing.assert_allclose(native, proto, rtol=1e-10, atol=1e-12 * abs(proto).max())
+                assert abs(native.min() - proto.min()) <= 1e-12 * proto.max() + 1e-10 * proto.min()
+        # ... and the oracle's recurrence on the host
+        ref = kr.lanczos_ritz(s.A, kr.block_jacobi(s.A, blocks), tol=1e-3)
+        got = eigen.EigenValues_Preconditioner(mat=A, pre=pres["bjac"], tol=1e-3)
+        assert len(got) == len(ref) and abs(got.min() - ref.min()) <= 1e-9 * ref.min()
+        # an operator that annihilates the start vector: gamma_0 == 0 -> no Ritz values (as the protocol form)
+        Z = hipla.DiagonalMatrix(np.zeros(s.n_u))
+        assert len(eigen.EigenValues_Preconditioner(mat=A, pre=Z, tol=1e-3)) == 0
+    finally:
+        eigen._native_lanczos = orig
+
+
 def test_reuse_aware_dispatch_order_changes_no_bit(hip_engine):
     """Grid operators beyond ~1e7 rows get a second, dispatch-ordered copy of their row-block descriptors
     (csrc/csr_stream.h: blkdisp): inside every XCD's share the blocks b, b + P, ..., b + (T - 1) P of T grid planes

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Interleaved same-box A/B of run-time variants (environment switches): tools/ab_env.sh "A:VAR=0 B:VAR=1" [rounds] [bench args]
-VARS=${1}; ROUNDS=${2:-3}; ARGS=${3:-"--cpu-iters 0 --hdg 0 --secondary 0 --steps 200 --warmup 20"}
+VARS=${1}; ROUNDS=${2:-3}; ARGS=${3:-"--cpu-iters 0 --hdg 0 --secondary 0 --mypre-a 0 --steps 200 --warmup 20"}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 for r in $(seq 1 $ROUNDS); do
   for v in $VARS; do

@@ -6,7 +6,7 @@ set -o pipefail
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof
 TAG=${1:-pmc}
-ARGS=${2:-"--steps 20 --warmup 5 --windows 1 --cpu-iters 0 --hdg 0 --secondary 0"}
+ARGS=${2:-"--steps 20 --warmup 5 --windows 1 --cpu-iters 0 --hdg 0 --secondary 0 --mypre-a 0"}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_fetch -o ${TAG} -- python3 $REPO/bench.py $ARGS > $OUT/${TAG}_fetch.json 2> $OUT/${TAG}_fetch.err || { tail -5 $OUT/${TAG}_fetch.err; exit 1; }
