@@ -30,6 +30,19 @@ def _tridiag_eigs(diag, off):
     return eigvalsh_tridiagonal(np.asarray(diag), np.asarray(off[: len(diag) - 1]))
 
 
+def _tridiag_extremes(diag, off):
+    """Smallest and largest eigenvalue only (bisection, O(j) each): what the convergence check of a batch needs --
+    the full spectrum (O(j^2)) is computed once, at the end."""
+    from scipy.linalg import eigvalsh_tridiagonal
+    n = len(diag)
+    if n == 1:
+        return float(diag[0]), float(diag[0])
+    d, e = np.asarray(diag), np.asarray(off[: n - 1])
+    lo = eigvalsh_tridiagonal(d, e, select="i", select_range=(0, 0))[0]
+    hi = eigvalsh_tridiagonal(d, e, select="i", select_range=(n - 1, n - 1))[0]
+    return float(lo), float(hi)
+
+
 class _LanczosState:
     """ctypes mirror of ``nss_lanczos_t`` (include/nss_krylov.h), built lazily (no ctypes at import)."""
     _cls = None
@@ -90,27 +103,49 @@ def _native_lanczos(mat, pre, start, tol, maxsteps, check_every):
     hist = eng.zeros(2 * maxsteps)
     st.scal, st.ctrl, st.hist = scal.data_ptr(), ctrl.data_ptr(), hist.data_ptr()
     eng._check(eng.lib.nss_lanczos_start(C.byref(st), eng.stream))
-    stop, j_stop, last = C.c_int32(), C.c_int32(), C.c_int32()
-    ritz = np.zeros(0)
+    torch = eng.torch
+    # The host looks at a batch while the device already runs the next one: after every batch the control words and
+    # the new (delta, gamma) pairs go to pinned host memory (stream-ordered copies, an event behind them); the host
+    # waits for the event of batch b only after batch b + 1 is enqueued.  When batch b ends the run, the steps of
+    # batch b + 1 were wasted work -- the result does not see them.
+    h_ctrl = [torch.empty(4, dtype=torch.int32).pin_memory() for _ in range(2)]
+    h_hist = torch.empty(2 * maxsteps, dtype=torch.float64).pin_memory()
+    pending = []                                          # (end, event, slot)
+
+    def enqueue(j0):
+        end = min(maxsteps, j0 + check_every)
+        eng._check(eng.lib.nss_lanczos_iterate(C.byref(st), j0, end, eng.stream))
+        slot = (j0 // check_every) & 1
+        h_ctrl[slot].copy_(ctrl, non_blocking=True)
+        h_hist[2 * j0: 2 * end].copy_(hist[2 * j0: 2 * end], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        pending.append((end, ev, slot))
+        return end
+
     lo_prev = hi_prev = None
-    j = 0
-    while j < maxsteps:
-        end = min(maxsteps, j + check_every)
-        eng._check(eng.lib.nss_lanczos_iterate(C.byref(st), j, end, eng.stream))
-        eng._check(eng.lib.nss_lanczos_poll(C.byref(st), C.byref(stop), C.byref(j_stop), C.byref(last), eng.stream))
-        if stop.value and j_stop.value < 0:
-            return np.zeros(0)                           # gamma_0 == 0
-        j_last = j_stop.value if stop.value else end - 1
-        h = eng.to_host(hist[: 2 * (j_last + 1)])
-        ritz = _tridiag_eigs(list(h[0::2][: j_last + 1]), list(h[1::2][: j_last]))
-        lo, hi = float(ritz[0]), float(ritz[-1])
-        if stop.value:
+    diag = off = np.zeros(0)
+    j = enqueue(0)
+    while pending:
+        if j < maxsteps:
+            j = enqueue(j)                                # the next batch runs while this one is looked at
+        end, ev, slot = pending.pop(0)
+        ev.synchronize()
+        stop, j_stop = int(h_ctrl[slot][0]), int(h_ctrl[slot][1])
+        if stop and j_stop < 0:
+            torch.cuda.synchronize()
+            return np.zeros(0)                            # gamma_0 == 0
+        j_last = j_stop if stop else end - 1
+        h = h_hist[: 2 * (j_last + 1)].numpy()
+        diag, off = h[0::2][: j_last + 1].copy(), h[1::2][: j_last].copy()
+        lo, hi = _tridiag_extremes(diag, off)
+        if stop:
             break
         if lo_prev is not None and abs(lo - lo_prev) <= tol * abs(lo) and abs(hi - hi_prev) <= tol * abs(hi):
             break
         lo_prev, hi_prev = lo, hi
-        j = end
-    return ritz
+    torch.cuda.synchronize()                              # (the speculative batch, before its buffers go away)
+    return _tridiag_eigs(list(diag), list(off))
 
 
 def lanczos_ritz(mat, pre, start, tol=1e-10, maxsteps=2000, check_every=5, dot=InnerProduct):

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Wall time of the scale-factor estimate `EigenValues_Preconditioner(mat=A, pre=preA, tol=1e-3)` (block-Jacobi preA):
+device-resident recurrence (csrc/lanczos.hip) vs the protocol recurrence (two host-synchronising dots per step), at
+the BASELINE sizes.   python tools/lanczos_time.py [cfg2 cfg3 cfg4]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "navier-stokes-solver_amd")):
+    sys.path.insert(0, p)
+import torch
+
+import hipla
+from hipla import eigen
+from staggered_grid import mac_stokes
+
+CASES = {"cfg2": (2, 183), "cfg3": (2, 577), "cfg4": (3, 136)}
+for name in (sys.argv[1:] or ["cfg2", "cfg3", "cfg4"]):
+    dim, n = CASES[name]
+    s = mac_stokes(dim, n, 0.01)
+    A = hipla.SparseMatrix.from_scipy(s.A)
+    pre = hipla.BlockJacobi(A, s.line_blocks(3))
+    out = {}
+    for mode in ("native", "protocol"):
+        eigen.NATIVE = mode == "native"
+        eigen.EigenValues_Preconditioner(mat=A, pre=pre, tol=1e-3)        # warm-up (workspaces, kernels)
+        best = 1e9
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            lams = eigen.EigenValues_Preconditioner(mat=A, pre=pre, tol=1e-3)
+            torch.cuda.synchronize()
+            best = min(best, time.perf_counter() - t0)
+        out[mode] = (best, len(lams), float(lams.min()), float(lams.max()))
+    eigen.NATIVE = True
+    (tn, kn, lo_n, hi_n), (tp, kp, lo_p, hi_p) = out["native"], out["protocol"]
+    print("%s (%d rows): device-resident %.1f ms (%d steps, %.1f us/step) | protocol %.1f ms (%d steps) | x %.2f | "
+          "lambda_min rel. diff %.1e" % (name, s.n_u, 1e3 * tn, kn, 1e6 * tn / kn, 1e3 * tp, kp, tp / tn, abs(lo_n - lo_p) / lo_p))
