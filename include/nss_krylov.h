@@ -356,6 +356,11 @@ typedef struct nss_bpcg2_s {
    * w1_g and t3_g with the rows of B in C23 (ghost rows add nothing to the dot partials), w0_g and w1_g in C4.
    * 0: the eight-phase layout described above. */
   int32_t dist_compact;
+  /* row-partitioned runs: the auxiliary-space term of MypreA on slabs (nss_dist_aux_create), alone, added to a (block)
+   * Jacobi part (additive MypreA, :383) or -- pre_bjac in Gauss-Seidel mode -- inside the multiplicative MypreA
+   * (:376-381) whose sweeps run inside the slab (additive across slabs) and whose residual uses the partitioned A;
+   * NULL otherwise */
+  struct nss_dist_aux_s* pre_dist_aux;
 } nss_bpcg2_t;
 
 enum {
@@ -463,6 +468,18 @@ NSS_API int nss_dist_amg_create(nss_dist_t d, nss_csr_t a_loc, const nss_halo_t*
                                 nss_csr_t p_loc, const double* wdinv, nss_amg_t coarse, nss_dist_amg_t* out);
 NSS_API int nss_dist_amg_destroy(nss_dist_amg_t h);
 NSS_API int nss_dist_amg_apply_f64(nss_dist_amg_t h, double scale, const double* b, double* y, nss_stream_t stream);
+
+/* The auxiliary-space term `transform @ preAh1 @ transform.T` of MypreA (templates/NavierStokesSIMPLE_iterative.py:336-337,
+ * 357,380,383) on slabs, applied natively inside the partitioned loops (the reference is single-process): tt_loc = the
+ * nodal slab's rows of transform.T (columns: velocity dofs [owned | ghosts], halo_x), t_loc = the velocity slab's rows of
+ * transform (columns: stacked nodal dofs [owned | ghosts], halo_e), amg = the V-cycle on the stacked block-diagonal nodal
+ * Laplacian with replicated coarse levels.  halo_y (may be NULL) = the halo of the loop's t1 as A's operand: needed by
+ * the multiplicative form, whose residual x - A y runs between the two sweeps.  y = scale * T V(L) T^T b. */
+typedef struct nss_dist_aux_s* nss_dist_aux_t;
+NSS_API int nss_dist_aux_create(nss_dist_t d, nss_csr_t tt_loc, const nss_halo_t* halo_x, nss_csr_t t_loc,
+                                const nss_halo_t* halo_e, nss_dist_amg_t amg, const nss_halo_t* halo_y, nss_dist_aux_t* out);
+NSS_API int nss_dist_aux_destroy(nss_dist_aux_t h);
+NSS_API int nss_dist_aux_apply_f64(nss_dist_aux_t h, double scale, const double* b, double* y, nss_stream_t stream);
 
 /* Per-phase device times of the native partitioned loop: between _begin and _end every iteration issued by
  * nss_bpcg2_iterate_dist (up to max_iterations) records 9 HIP events on the compute stream; _end waits for them

@@ -687,7 +687,12 @@ void bpcg2_check_state(const nss_bpcg2_t* s) {
     NSS_REQUIRE(s->B->m == s->n_p, "bpcg2: matrix row counts do not match n_p");
   }
   NSS_REQUIRE(!(s->pre_diag && s->pre_bjac), "bpcg2: pre_diag and pre_bjac are exclusive");
-  NSS_REQUIRE(s->pre_diag || s->pre_bjac || s->pre_amg || s->pre_dist_amg, "bpcg2: no preconditioner for the velocity block");
+  NSS_REQUIRE(s->pre_diag || s->pre_bjac || s->pre_amg || s->pre_dist_amg || s->pre_dist_aux, "bpcg2: no preconditioner for the velocity block");
+  NSS_REQUIRE(!s->pre_dist_aux || (!s->pre_amg && !s->pre_dist_amg && !s->cond_HT && s->pre_dist_aux->n_u == s->n_u),
+              "bpcg2: the row-partitioned auxiliary-space term replaces pre_amg / pre_dist_amg, takes no condensed form, and must match n_u");
+  NSS_REQUIRE(!s->pre_dist_aux || !(s->pre_bjac && s->pre_bjac->gs_mat) ||
+                  (s->pre_dist_aux->has_halo_y && s->pre_dist_aux->halo_y.ext == s->t1),
+              "bpcg2: the multiplicative partitioned MypreA needs the halo of t1 (nss_dist_aux_create: halo_y)");
   NSS_REQUIRE(!s->pre_dist_amg || (!s->pre_amg && !s->cond_HT && s->pre_dist_amg->n == s->n_u),
               "bpcg2: the row-partitioned AMG replaces pre_amg, takes no condensed form, and must match n_u");
   NSS_REQUIRE(!s->pre_amg || s->pre_amg->levels[0].n == s->n_u, "bpcg2: AMG size mismatch");
@@ -725,7 +730,7 @@ void bpcg2_spmv_phase(const nss_bpcg2_t& s, int which, int it, hipStream_t st, i
     case NSS_BPCG2_K1: {
       // the point-Jacobi apply rides in the epilogue unless an AMG term comes first
       EpiK1 e{s.ctrl, s.scal, s.u0, s.q, s.z0, s.t2, s.s0, s.w0, s.t0, s.t1,
-              (s.pre_amg || s.cond_HT) ? nullptr : s.pre_diag, s.k, it};
+              (s.pre_amg || s.pre_dist_amg || s.pre_dist_aux || s.cond_HT) ? nullptr : s.pre_diag, s.k, it};
       launch_csr_stream(*s.BT, s.s1, e, st, b0, b1);
       break;
     }
@@ -754,7 +759,22 @@ void bpcg2_k1_finish(const nss_bpcg2_t& s, hipStream_t st) {
     src = s.cond_f;
   }
   auto diag = [&](double beta) { diag_apply(s.n_u, s.pre_diag, s.k, src, beta, s.t1, s.ctrl, st); };
-  if (s.pre_dist_amg) {                              // row-partitioned V-cycle (+ additive Jacobi part)
+  if (s.pre_dist_aux && s.pre_bjac && s.pre_bjac->gs_mat) {
+    // multiplicative MypreA on slabs (GS=True, :376-381): the sweeps run inside the slab (additive across slabs), the
+    // residual between them with the partitioned A (halo exchange of the iterate), the auxiliary-space term on slabs
+    const nss_dist_aux_s& aux = *s.pre_dist_aux;
+    hipLaunchKernelGGL(bpcg2_zero_kernel, dim3((s.n_u + kBlock - 1) / kBlock), dim3(kBlock), 0, st, s.ctrl, s.n_u, s.t1);
+    NSS_CHECK_LAUNCH();
+    bjac_smooth(*s.pre_bjac, s.k, src, s.t1, false, s.ctrl, st);
+    exchange(*aux.d, aux.halo_y, st);
+    launch_csr_stream(*s.A, s.t1, EpiScaledResidual{s.ctrl, s.k, src, s.t2}, st);
+    dist_aux_apply(aux, 1.0, s.t2, s.t1, true, st, s.ctrl);
+    bjac_smooth(*s.pre_bjac, s.k, src, s.t1, true, s.ctrl, st);
+  } else if (s.pre_dist_aux) {                        // additive MypreA on slabs (:383)
+    dist_aux_apply(*s.pre_dist_aux, s.k, src, s.t1, false, st, s.ctrl);
+    if (s.pre_bjac) bjac_apply(*s.pre_bjac, s.k, src, 1.0, s.t1, s.ctrl, st);
+    if (s.pre_diag) diag(1.0);
+  } else if (s.pre_dist_amg) {                              // row-partitioned V-cycle (+ additive Jacobi part)
     dist_amg_apply(*s.pre_dist_amg, s.k, src, s.t1, st, s.ctrl);
     if (s.pre_bjac) bjac_apply(*s.pre_bjac, s.k, src, 1.0, s.t1, s.ctrl, st);
     if (s.pre_diag) diag(1.0);
@@ -834,7 +854,7 @@ void bpcg2_cphase(const nss_bpcg2_t& s, int which, int it, hipStream_t st) {
   const bool fold = fold_sums(s);
   switch (which) {
     case NSS_BPCG2C_C1: {
-      const double* dinv = (s.pre_amg || s.pre_dist_amg || s.cond_HT) ? nullptr : s.pre_diag;
+      const double* dinv = (s.pre_amg || s.pre_dist_amg || s.pre_dist_aux || s.cond_HT) ? nullptr : s.pre_diag;
       // (streaming operand loads only where B^T takes the row-per-lane kernel: that is the large-system regime,
       // and the stream-kernel instantiations of the epilogue are not doubled)
       const bool nt = s.BT->ell_col != nullptr && stream_vector_loads(s.n_u);

@@ -40,7 +40,29 @@ struct nss_dist_amg_s {
   double *res = nullptr, *rc = nullptr, *rc_local = nullptr, *ec = nullptr;   // work vectors (owned by the handle)
 };
 
+// The auxiliary-space term of MypreA, transform @ V(L) @ transform.T (templates/NavierStokesSIMPLE_iterative.py:336-337,
+// 357,380,383), on slabs: the velocity slab's rows of `transform` (columns: this rank's nodal planes + ghosts), the nodal
+// slab's rows of its transpose (columns: this rank's velocity dofs + ghosts) and the V-cycle on the stacked nodal
+// Laplacian with replicated coarse levels (nss_dist_amg_s).  Per apply: halo exchange of the argument, of the nodal
+// correction, the two of the V-cycle, and its coarse all-reduce.
+struct nss_dist_aux_s {
+  const nss_dist_s* d = nullptr;
+  const nss_csr_s* TT = nullptr;       // nodal rows x velocity columns [owned | ghosts]
+  const nss_csr_s* T = nullptr;        // velocity rows x nodal columns [owned | ghosts]
+  const nss_dist_amg_s* amg = nullptr;
+  nss_halo_t halo_x{};                 // of the velocity argument (ext = its halo-extended buffer)
+  nss_halo_t halo_e{};                 // of the nodal correction
+  nss_halo_t halo_y{};                 // of the loop's iterate t1 as A's operand (multiplicative form: residual x - A y)
+  bool has_halo_y = false;
+  int32_t n_u = 0, n_nodes = 0;
+  double* r_aux = nullptr;             // nodal work vector (owned by the handle)
+};
+
 namespace nss {
+
+// y (+)= scale * T V(L) T^T b on the slab
+void dist_aux_apply(const nss_dist_aux_s& a, double scale, const double* b, double* y, bool accumulate, hipStream_t st,
+                    const int32_t* done);
 
 // y = scale * V(b) on the slab; every kernel returns at once when *done != 0 (the collectives still run on all
 // ranks, on unchanged buffers)

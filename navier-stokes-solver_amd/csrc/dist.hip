@@ -179,11 +179,68 @@ void dist_amg_apply(const nss_dist_amg_s& a, double scale, const double* b, doub
   launch_csr_stream(*a.A, x, EpiJacobi{b, x, a.wdinv, y, 1.0, scale, done}, st);   // y = scale (x + w D^-1 (b - A x))
 }
 
+void dist_aux_apply(const nss_dist_aux_s& a, double scale, const double* b, double* y, bool accumulate, hipStream_t st,
+                    const int32_t* done) {
+  NSS_HIP(hipMemcpyAsync(a.halo_x.ext, b, sizeof(double) * size_t(a.n_u), hipMemcpyDeviceToDevice, st));   // (scratch: unguarded)
+  exchange(*a.d, a.halo_x, st);
+  launch_csr_stream(*a.TT, a.halo_x.ext, EpiAxpby{1.0, 0.0, a.r_aux, done}, st);                // transform.T
+  dist_amg_apply(*a.amg, 1.0, a.r_aux, a.halo_e.ext, st, done);                                 // V-cycle on the stacked Laplacian
+  exchange(*a.d, a.halo_e, st);
+  launch_csr_stream(*a.T, a.halo_e.ext, EpiAxpby{scale, accumulate ? 1.0 : 0.0, y, done}, st);  // transform
+}
+
 }  // namespace nss
 
 using namespace nss;
 
 extern "C" {
+
+int nss_dist_aux_create(nss_dist_t d, nss_csr_t tt_loc, const nss_halo_t* halo_x, nss_csr_t t_loc, const nss_halo_t* halo_e,
+                        nss_dist_amg_t amg, const nss_halo_t* halo_y, nss_dist_aux_t* out) {
+  return guarded([&] {
+    NSS_REQUIRE(d && tt_loc && halo_x && t_loc && halo_e && amg && out, "dist_aux_create: NULL argument");
+    const int32_t n_u = t_loc->m, n_nodes = tt_loc->m;
+    NSS_REQUIRE(tt_loc->n >= n_u && t_loc->n >= n_nodes && amg->n == n_nodes, "dist_aux_create: operator shapes do not chain");
+    check_halo(halo_x, *tt_loc, "dist_aux halo_x");
+    check_halo(halo_e, *t_loc, "dist_aux halo_e");
+    NSS_REQUIRE(amg->d == d, "dist_aux_create: the V-cycle belongs to another communicator handle");
+    nss_dist_aux_s* h = new nss_dist_aux_s;
+    try {
+      h->d = d;
+      h->TT = tt_loc;
+      h->T = t_loc;
+      h->amg = amg;
+      h->halo_x = *halo_x;
+      h->halo_e = *halo_e;
+      if (halo_y) {
+        h->halo_y = *halo_y;
+        h->has_halo_y = true;
+      }
+      h->n_u = n_u;
+      h->n_nodes = n_nodes;
+      NSS_HIP(hipMalloc(&h->r_aux, sizeof(double) * size_t(std::max(1, n_nodes))));
+    } catch (...) {
+      nss_dist_aux_destroy(h);
+      throw;
+    }
+    *out = h;
+  });
+}
+
+int nss_dist_aux_destroy(nss_dist_aux_t h) {
+  return guarded([&] {
+    if (!h) return;
+    (void)hipFree(h->r_aux);
+    delete h;
+  });
+}
+
+int nss_dist_aux_apply_f64(nss_dist_aux_t h, double scale, const double* b, double* y, nss_stream_t stream) {
+  return guarded([&] {
+    NSS_REQUIRE(h && b && y && b != y, "dist_aux_apply: bad argument");
+    dist_aux_apply(*h, scale, b, y, false, as_stream(stream), nullptr);
+  });
+}
 
 int nss_dist_amg_create(nss_dist_t d, nss_csr_t a_loc, const nss_halo_t* halo_x, nss_csr_t r_loc, nss_csr_t p_loc,
                         const double* wdinv, nss_amg_t coarse, nss_dist_amg_t* out) {

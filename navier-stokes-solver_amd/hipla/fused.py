@@ -37,7 +37,8 @@ class Bpcg2State(C.Structure):
                    ("ghost_s0", C.c_void_p), ("ghost_w0", C.c_void_p),
                    ("ghost_p_mode", C.c_int32), ("ghost_p_n", C.c_int32), ("ghost_b", C.c_void_p),
                    ("ghost_t3", C.c_void_p), ("ghost_w1", C.c_void_p), ("ghost_minv", C.c_void_p),
-                   ("local_sums", C.c_int32), ("pre_dist_amg", C.c_void_p), ("dist_compact", C.c_int32)])
+                   ("local_sums", C.c_int32), ("pre_dist_amg", C.c_void_p), ("dist_compact", C.c_int32),
+                   ("pre_dist_aux", C.c_void_p)])
 
 
 class HaloStruct(C.Structure):

@@ -343,6 +343,34 @@ class StokesSystem:
             L.sort_indices()
         return {"transform": T, "laplacians": lapl, "ranges": ranges}
 
+    def auxiliary_space_stacked(self):
+        """The auxiliary space of `auxiliary_space()` as ONE operator in slab-major order -- what a row partition
+        needs: the stacked nodal spaces of all components re-ordered so that the vertex plane is the slowest index
+        ([plane k | component c | in-plane node]), the block-diagonal Laplacian ``L = diag(aH1_1, .., aH1_d)`` and the
+        transform in that numbering.  ``transform @ V(L) @ transform.T`` with one V-cycle on L is the term
+        ``transform @ preAh1 @ transform.T`` of the reference's MypreA (templates/NavierStokesSIMPLE_iterative.py:336-337,
+        357,380,383) with the component V-cycles run as one (the components are not coupled: the hierarchy of L is the
+        union of theirs).  `node_slab_offsets[k]`: first stacked nodal dof of vertex plane k (plane k lies between the
+        cell slabs k and k + 1 and goes with slab k); length n + 1 like `velocity_slab_offsets`."""
+        space = self.auxiliary_space()
+        dim, b = self.dim, self.block_size
+        m = self.n - 1
+        ncomp, per_comp, per_plane = len(space["laplacians"]), m ** dim, m ** (dim - 1)
+        old = np.arange(ncomp * per_comp, dtype=np.int64)
+        c, rest = old // per_comp, old % per_comp
+        k, inplane = rest // per_plane, rest % per_plane
+        new_of_old = k * (ncomp * per_plane) + c * per_plane + inplane
+        if b > 1:                                            # every nodal unknown carries the b copies of its site
+            new_of_old = (new_of_old[:, None] * b + np.arange(b)[None, :]).ravel()
+        ntot = new_of_old.size
+        Q = sp.csr_matrix((np.ones(ntot), (np.arange(ntot), new_of_old)), shape=(ntot, ntot))   # column old -> new
+        L = (Q.T @ sp.block_diag(space["laplacians"], format="csr") @ Q).tocsr()
+        T = (space["transform"] @ Q).tocsr()
+        L.sort_indices()
+        T.sort_indices()
+        planes = np.minimum(np.arange(self.n + 1), m)       # slab n - 1 owns no vertex plane
+        return {"transform": T, "laplacian": L, "node_slab_offsets": planes * (ncomp * per_plane * b)}
+
     def condense(self, seed=0):
         """Static condensation of A: split the velocity dofs into an
         *interior* set I (a maximal independent set of A's graph, so A_ii is diagonal -- the role
