@@ -467,17 +467,143 @@ class DistributedAMG(BaseMatrix):
         return self
 
 
+class DistributedAuxiliary(BaseMatrix):
+    """The auxiliary-space term ``transform @ preAh1 @ transform.T`` of the reference's MypreA
+    (templates/NavierStokesSIMPLE_iterative.py:336-337,357,380,383) on slabs: the stacked nodal space in slab-major
+    order (`StokesSystem.auxiliary_space_stacked`), the vertex plane between the cell slabs k and k + 1 owned by the
+    rank of slab k; ``transform`` and its transpose as `DistSparseMatrix` (one neighbour plane of halo each) and ONE
+    smoothed-aggregation V-cycle on the block-diagonal nodal Laplacian with replicated coarse levels
+    (`DistributedAMG`).  Protocol operator on slab vectors; `native_handle` gives the `nss_dist_aux_t` the native
+    partitioned loop applies itself."""
+
+    def __init__(self, ops, **amg_options):
+        super().__init__()
+        sysm, comm, eng = ops.sysm, ops.comm, ops.engine
+        self.ops, self.comm, self.engine = ops, comm, eng
+        st = sysm.auxiliary_space_stacked()
+        slab = np.searchsorted(sysm.velocity_slab_offsets, ops.vel)            # slab index of every partition cut
+        if not np.array_equal(sysm.velocity_slab_offsets[slab], ops.vel):
+            raise ValueError("DistributedAuxiliary: the row partition must cut between grid slabs")
+        self.node_offsets = np.asarray(st["node_slab_offsets"], dtype=np.int64)[slab]
+        T = sp.csr_matrix(st["transform"])
+        TT = T.T.tocsr()
+        TT.sort_indices()
+        self.transform = DistSparseMatrix(T, ops.vel, self.node_offsets, comm, eng)
+        self.transform_t = DistSparseMatrix(TT, self.node_offsets, ops.vel, comm, eng)
+        self.L = DistSparseMatrix(st["laplacian"], self.node_offsets, self.node_offsets, comm, eng)
+        self.V = DistributedAMG(st["laplacian"], self.L, **amg_options)
+        self.level_sizes = self.V.level_sizes
+        self.n = ops.n_u
+        self._r, self._e = self.transform_t.CreateColVector(), self.transform_t.CreateColVector()
+        self._native = None
+
+    def Height(self):
+        return self.n
+
+    def Width(self):
+        return self.n
+
+    def CreateColVector(self):
+        return self.ops.A.CreateColVector()
+
+    CreateRowVector = CreateColVector
+
+    def Mult(self, x, y):
+        self._r.data = self.transform_t * x            # transform.T  (halo exchange of x)
+        self._e.data = self.V * self._r       # the V-cycle on the stacked nodal Laplacian
+        y.data = self.transform * self._e             # transform    (halo exchange of e)
+
+    MultTrans = Mult
+
+    @property
+    def T(self):
+        return self
+
+    def native_handle(self, dist_handle, t1=None):
+        """`nss_dist_aux_t` (created once).  `t1`: the loop's iterate as A's operand (`HaloVector`), needed by the
+        multiplicative MypreA."""
+        import ctypes as C
+        if self._native is None:
+            eng = self.engine
+            self._x_native, self._e_native = self.transform_t.operand(), self.transform.operand()
+            hx, he = self.transform_t.native_halo(self._x_native), self.transform.native_halo(self._e_native)
+            hy = self.ops.A.native_halo(t1) if t1 is not None else None
+            out = C.c_void_p()
+            eng._check(eng.lib.nss_dist_aux_create(dist_handle, self.transform_t.local.handle.ptr, C.byref(hx),
+                                                   self.transform.local.handle.ptr, C.byref(he), self.V.native_handle(dist_handle),
+                                                   C.byref(hy) if hy is not None else None, C.byref(out)))
+            self._native = (out, hx, he, hy, dist_handle)
+        return self._native[0]
+
+    def native_apply(self, scale, b, y):
+        eng = self.engine
+        eng._check(eng.lib.nss_dist_aux_apply_f64(self._native[0], float(scale), b.buf.data_ptr(), y.buf.data_ptr(), eng.stream))
+
+    def release(self):
+        if self._native is not None:
+            self.engine.lib.nss_dist_aux_destroy(self._native[0])
+            self._native = None
+        if getattr(self.V, "_native", None) is not None:
+            self.engine.lib.nss_dist_amg_destroy(self.V._native[0])
+            self.V._native = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
+class DistributedMypreA(BaseMatrix):
+    """``MypreA.Mult`` (templates/NavierStokesSIMPLE_iterative.py:375-383) on slabs, protocol form: `gs` = the block
+    smoother of the slab's diagonal block (sweeps inside the slab, additive across slabs), `aux` = `DistributedAuxiliary`.
+    GS=True: y = 0; Smooth; r = x - A y with the PARTITIONED A; y += aux r; SmoothBack.  GS=False: y = (aux + J) x."""
+
+    def __init__(self, ops, gs, aux, GS=True):
+        super().__init__()
+        self.ops, self.gs, self.aux, self.GS = ops, gs, aux, GS
+        self._res = ops.A.CreateColVector()
+
+    def Height(self):
+        return self.ops.n_u
+
+    def Width(self):
+        return self.ops.n_u
+
+    def CreateColVector(self):
+        return self.ops.A.CreateColVector()
+
+    CreateRowVector = CreateColVector
+
+    def Mult(self, x, y):
+        if self.GS:
+            y[:] = 0.0                                   # :377
+            self.gs.Smooth(y, x)                         # :378
+            self._res.data = x - self.ops.A * y          # :379
+            y.data += self.aux * self._res               # :380
+            self.gs.SmoothBack(y, x)                     # :381
+        else:
+            y.data = self.aux * x + self.gs * x          # :383
+
+    MultTrans = Mult
+
+    @property
+    def T(self):
+        return self
+
+
 class DistributedStokes:
     """The operands of the Stokes solve on this rank: A, B, B^T as `DistSparseMatrix`,
     block-Jacobi / Jacobi preA (or, `pre="amg"`, the `DistributedAMG` cycle) and lumped-mass preM
     restricted to the slab."""
 
-    def __init__(self, sysm, blocks, comm, engine=None, partition=None, pre=None):
+    def __init__(self, sysm, blocks, comm, engine=None, partition=None, pre=None, aux_options=None):
         self.comm = comm
         self.engine = engine if engine is not None else get_engine()
         r, size = comm.rank, comm.size
         vel, prs = partition if partition is not None else sysm.partition(size)
         self.vel, self.prs = np.asarray(vel, dtype=np.int64), np.asarray(prs, dtype=np.int64)
+        self.sysm = sysm
         self.n_u, self.n_p = int(self.vel[r + 1] - self.vel[r]), int(self.prs[r + 1] - self.prs[r])
         BT = sysm.B.T.tocsr()
         BT.sort_indices()
@@ -527,12 +653,28 @@ class DistributedStokes:
                 raise ValueError("a block-Jacobi block straddles the slab boundary")
             loc = blocks[:, mine]
             loc = np.where(loc >= 0, loc - v0, -1).astype(np.int32)
-            self.preA = BlockJacobi(self.A_diag, np.ascontiguousarray(loc))
+            self.local_blocks = np.ascontiguousarray(loc)
+            if pre in ("bgs", "mypre_a"):
+                # multicolour block Gauss-Seidel INSIDE the slab, additive across slabs (a "hybrid" sweep: no exchange
+                # inside a sweep; with one slab it is the single-GPU sweep).  Colours: first fit in block order on the
+                # slab's own block graph -- what the same colouring gives on the slab-block-diagonal global graph.
+                from hipla import BlockGaussSeidel
+                self.preA = BlockGaussSeidel(self.A_diag, self.local_blocks)
+            else:
+                self.preA = BlockJacobi(self.A_diag, self.local_blocks)
         else:
             from hipla import JacobiPreconditioner
             self.preA = JacobiPreconditioner(self.A_diag)
         if pre == "amg":
             self.preA = DistributedAMG(sysm.A, self.A)
+        self.gs = self.aux = None
+        if pre == "mypre_a":
+            # the reference's default preA on slabs: MypreA(GS=True) with the auxiliary-space term
+            if blocks is None:
+                raise ValueError("pre='mypre_a' needs the facet blocks")
+            self.gs = self.preA
+            self.aux = DistributedAuxiliary(self, **(aux_options or {}))
+            self.preA = DistributedMypreA(self, self.gs, self.aux, GS=True)
         p0, p1 = int(self.prs[r]), int(self.prs[r + 1])
         self.preM = DiagonalMatrix(1.0 / sysm.mass[p0:p1], engine=self.engine)
         self.inner = DistInner(comm)
@@ -618,12 +760,17 @@ class DistributedBpcg2:
     SCHEDULE_COMPACT = (("cphases", ("C1", "C1")), ("halo", "t1"), ("cphases", ("C23", "SUMA")), ("allreduce", 1),
                         ("cphases", ("C4", "SUMW")), ("allreduce", 2))
 
-    def __init__(self, sysm, f, g, blocks, dist, engine=None, comm=None, quiet=True, native=True, pre=None, plan=None):
+    def __init__(self, sysm, f, g, blocks, dist, engine=None, comm=None, quiet=True, native=True, pre=None, plan=None,
+                 aux_options=None):
         """`native=False` keeps the Python-driven schedule even when `comm` is an `RcclComm` (its
         collectives are then single ctypes calls into librccl between the device phases).
         `pre="amg"`: preA = the V-cycle with replicated coarse levels (`DistributedAMG`), applied inside the
         native loop (needs the RCCL communicator: the cycle's exchanges and its coarse all-reduce are issued
         from C); `pre="amg+bjac"` adds the block Jacobi (additive MypreA).
+        `pre="bgs"`: multicolour block Gauss-Seidel inside the slab, additive across slabs (no communication inside a
+        sweep; any communicator).  `pre="mypre_a"`: the reference's default -- MypreA(GS=True): those sweeps around the
+        auxiliary-space term on slabs (`DistributedAuxiliary`; `aux_options` go to its V-cycle), the residual between
+        them with the partitioned A; applied natively inside the loop (RCCL communicator, as `pre="amg"`).
         `plan`: "compact" (default; NSS_DIST_PLAN overrides) = C1 / preA / exchange / C23 / sum / all-reduce / C4 /
         sum / all-reduce with every ghost kept by recurrence behind the owned entries of its vector; "classic" = the
         eight-phase form (the only one with the interior / boundary overlap)."""
@@ -634,7 +781,8 @@ class DistributedBpcg2:
         from solvers.bramblepasciak_new import BpcgSession
         self.engine = engine if engine is not None else get_engine()
         self.comm = comm if comm is not None else TorchComm(dist, self.engine)
-        ops = self.ops = DistributedStokes(sysm, blocks, self.comm, self.engine)
+        ops = self.ops = DistributedStokes(sysm, blocks, self.comm, self.engine,
+                                           pre=pre if pre in ("bgs", "mypre_a") else None, aux_options=aux_options)
         self.dist_amg = None
         if pre in ("amg", "amg+bjac"):
             self.dist_amg = DistributedAMG(sysm.A, ops.A)
@@ -695,7 +843,20 @@ class DistributedBpcg2:
         compact = getattr(self, "compact", False)
         matB = ops.b_extended() if compact else ops.B.local
         extra = dict(ghost_rows_b=int(ops.BT.plan.n_ghost)) if compact else {}
-        if dist_amg is not None:
+        if getattr(ops, "aux", None) is not None:           # MypreA(GS=True) on slabs, natively inside the loop
+            import ctypes as C
+            comm_handle = getattr(self.comm, "comm", None)
+            if comm_handle is None:
+                raise RuntimeError("pre='mypre_a' inside the fused partitioned loop needs the RCCL communicator "
+                                   "(with torch.distributed use BramblePasciakCG on the distributed operands)")
+            handle = C.c_void_p()
+            self.engine._check(self.engine.lib.nss_dist_create(comm_handle, self.comm.size, self.comm.rank, C.byref(handle)))
+            self._amg_dist_handle = handle
+            self.loop = Bpcg2Loop.try_create(ops.A.local, matB, ops.BT.local, ops.gs, self.k, ops.preM, vecs,
+                                             distributed=True, dist_aux=ops.aux.native_handle(handle, vecs["t1"]), **extra)
+            if self.loop is not None:
+                self.loop.keep.append(ops.aux)
+        elif dist_amg is not None:
             self.loop = Bpcg2Loop.try_create(ops.A.local, matB, ops.BT.local, self.jacobi_part, self.k, ops.preM,
                                              vecs, distributed=True, dist_amg=dist_amg.native_handle(self._amg_dist_handle),
                                              **extra)
@@ -817,6 +978,9 @@ class DistributedBpcg2:
         """Free the native handles in dependency order: the loop's dist handle, the V-cycle's native handle (it
         points into the dist handle created for it), then that dist handle."""
         self.close()
+        aux = getattr(getattr(self, "ops", None), "aux", None)
+        if aux is not None:
+            aux.release()
         amg = getattr(self, "dist_amg", None)
         if amg is not None and getattr(amg, "_native", None) is not None:
             amg.engine.lib.nss_dist_amg_destroy(amg._native[0])

@@ -144,7 +144,7 @@ class Bpcg2Loop:
 
     @classmethod
     def try_create(cls, matA, matB, matBT, preA_unscaled, k, preM, vecs, distributed=False, condensed=None,
-                   dist_amg=None, ghost_rows_b=0):
+                   dist_amg=None, ghost_rows_b=0, dist_aux=None):
         """`distributed`: the matrices are the local row blocks of a partitioned run -- their
         column spaces carry halo entries behind the owned ones and t1 / t4 / s1 are the owned
         views of halo-extended buffers (same base pointer).  `condensed`: dict(HT, H, inner) of
@@ -164,7 +164,13 @@ class Bpcg2Loop:
         if distributed and (matA.width < n_u or matB.width < n_u or matBT.width < n_p):
             return None
         pm = native_diag(preM)
-        if dist_amg is not None:     # row-partitioned V-cycle (native handle) [+ an additive Jacobi part]
+        if dist_aux is not None:     # row-partitioned auxiliary-space term [+ Jacobi part | around Gauss-Seidel sweeps]
+            pa = native_velocity_pre(preA_unscaled) if preA_unscaled is not None else None
+            if pa is None:
+                pa = {"scale": 1.0, "amg": None, "diag": None, "bjac": None, "multiplicative": False}
+            if pa["amg"] is not None or pa["multiplicative"] or not distributed or dist_amg is not None:
+                return None
+        elif dist_amg is not None:   # row-partitioned V-cycle (native handle) [+ an additive Jacobi part]
             pa = native_velocity_pre(preA_unscaled) if preA_unscaled is not None else None
             if pa is None:
                 pa = {"scale": 1.0, "amg": None, "diag": None, "bjac": None, "multiplicative": False}
@@ -186,10 +192,10 @@ class Bpcg2Loop:
                 return None
             if not _extension_is_in_place_safe(condensed["H"]):
                 return None
-        return cls(eng, matA, matB, matBT, pa, k, pm, vecs, condensed, distributed, dist_amg, n_p)
+        return cls(eng, matA, matB, matBT, pa, k, pm, vecs, condensed, distributed, dist_amg, n_p, dist_aux)
 
     def __init__(self, eng, matA, matB, matBT, pa, k, pm, vecs, condensed=None, distributed=False, dist_amg=None,
-                 n_p=None):
+                 n_p=None, dist_aux=None):
         torch = eng.torch
         self.eng, self.lib = eng, eng.lib
         self.keep = [matA, matB, matBT, vecs, pa, pm, condensed]       # keep device memory alive
@@ -217,6 +223,7 @@ class Bpcg2Loop:
         st.n_u, st.n_p = matA.height, (matB.height if n_p is None else int(n_p))
         st.local_sums = 1 if distributed else 0     # the caller all-reduces scal[9], scal[10] into scal[1], scal[2]
         st.pre_dist_amg = dist_amg
+        st.pre_dist_aux = dist_aux
         self.keep.append(dist_amg)
         na, nb, nc = C.c_int64(), C.c_int64(), C.c_int64()
         eng._check(self.lib.nss_bpcg2_workspace(C.byref(st), C.byref(na), C.byref(nb), C.byref(nc)))

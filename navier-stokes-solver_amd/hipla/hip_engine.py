@@ -51,6 +51,9 @@ def _signatures():
         "nss_csr_plan_for_pairs": (C.c_int, [vp, c_i32_p]),
         "nss_csr_pair_staged": (C.c_int, [vp, c_i32_p]),
         "nss_csr_pair_mode": (C.c_int, [i32]),
+        "nss_dist_aux_create": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.POINTER(vp)]),
+        "nss_dist_aux_destroy": (C.c_int, [vp]),
+        "nss_dist_aux_apply_f64": (C.c_int, [vp, dbl, vp, vp, vp]),
         "nss_lanczos_workspace": (C.c_int, [vp, c_i64_p, c_i64_p]),
         "nss_lanczos_start": (C.c_int, [vp, vp]),
         "nss_lanczos_iterate": (C.c_int, [vp, i32, i32, vp]),
