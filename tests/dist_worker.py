@@ -153,6 +153,32 @@ def run(rank, world, mode, init_file, out_dir, dim, n, pre, tol, maxsteps):
         res["amg_hist"] = np.array([float(m) for m in _re.findall(r"it =\s+\d+\s+err =\s+(\S+)", out.getvalue())])
         res["amg_it"] = it_a
         res["amg_u"] = sol[0].numpy()
+    # ---- the reference's default preA on slabs: MypreA(GS=True) = Gauss-Seidel sweeps inside the slab around the
+    #      auxiliary-space term on slabs, residual with the partitioned A; BPCG v2 through the protocol --------------
+    if pre == "bjac":
+        from solvers.bramblepasciak_new import BramblePasciakCG
+        import re as _re2
+        mops = DistributedStokes(sysm, blocks, comm, eng, pre="mypre_a", aux_options=dict(coarse_size=40))
+        res["aux_levels"] = np.array(mops.aux.level_sizes)
+        xa = np.random.default_rng(9).standard_normal(sysm.n_u)
+        ya = hipla.Vector(mops.n_u)
+        ya.data = mops.preA * hipla.Vector.from_numpy(xa[us])
+        res["mypre_apply"] = ya.numpy()
+        fv, gv = mops.vectors(f, g)
+        sol = hipla.BlockVector([fv.CreateVector(), gv.CreateVector()])
+        out = io.StringIO()
+        with contextlib.redirect_stdout(out):
+            it_m, _ = BramblePasciakCG(Form(mops.A), Form(mops.B), None, fv, gv, mops.preA, mops.preM, sol, tol=tol,
+                                       maxsteps=maxsteps)
+        res["mypre_hist"] = np.array([float(m) for m in _re2.findall(r"it =\s+\d+\s+err =\s+(\S+)", out.getvalue())])
+        res["mypre_it"] = it_m
+        res["mypre_u"] = sol[0].numpy()
+        if mode == "gpu":
+            # hybrid Gauss-Seidel (inside the slab, additive across slabs) natively in the fused partitioned loop
+            grun = DistributedBpcg2(sysm, f, g, blocks, dist, eng, comm=comm, pre="bgs")
+            it_g, _ = grun.solve(tol=tol, maxsteps=maxsteps, poll_every=8)
+            res["bgs_hist"], res["bgs_it"], res["bgs_u"] = grun.history(it_g), it_g, grun.sol[0].numpy()
+            res["bgs_colors"] = int(grun.ops.preA.ncolors)
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), **res)
     dist.barrier()
     dist.destroy_process_group()

@@ -38,6 +38,50 @@ def launch(world, mode, dim, n, pre, tol, maxsteps):
     return [np.load(os.path.join(tmp, "rank%d.npz" % r)) for r in range(world)]
 
 
+def slab_twin_of_mypre_a(s, world, blocks, **amg_options):
+    """The single-process operator a `world`-way `DistributedStokes(pre="mypre_a")` applies: multicolour block
+    Gauss-Seidel sweeps over the slab-block-diagonal part of A (inside every slab, additive across slabs), the residual
+    between them with the full A, and `transform @ V(L) @ transform.T` with one V-cycle on the stacked nodal Laplacian
+    (`StokesSystem.auxiliary_space_stacked`).  Returns (MypreA twin, sweep-only twin, A, level sizes)."""
+    import hipla
+    import scipy.sparse as sp
+    vel, _ = s.partition(world)
+    A = hipla.SparseMatrix.from_scipy(s.A)
+    bd = sp.block_diag([s.A[vel[r]:vel[r + 1], vel[r]:vel[r + 1]] for r in range(world)], format="csr")
+    G = hipla.BlockGaussSeidel(hipla.SparseMatrix.from_scipy(bd), blocks)
+    st = s.auxiliary_space_stacked()
+    V = hipla.SmoothedAggregationAMG(hipla.SparseMatrix.from_scipy(st["laplacian"]), **amg_options)
+    aux = hipla.AuxiliarySpaceAMG(hipla.SparseMatrix.from_scipy(st["transform"]), [V])
+
+    class Twin(hipla.BaseMatrix):
+        def Height(self):
+            return s.n_u
+
+        def Width(self):
+            return s.n_u
+
+        def CreateColVector(self):
+            return hipla.Vector(s.n_u)
+
+        CreateRowVector = CreateColVector
+
+        def Mult(self, x, y):                      # templates/NavierStokesSIMPLE_iterative.py:377-381
+            y[:] = 0.0
+            G.Smooth(y, x)
+            res = x.CreateVector()
+            res.data = x - A * y
+            y.data += aux * res
+            G.SmoothBack(y, x)
+
+        MultTrans = Mult
+
+        @property
+        def T(self):
+            return self
+
+    return Twin(), G, A, V.level_sizes
+
+
 def single_rank_reference(dim, n, pre, tol, maxsteps, numpy_engine):
     import hipla
     from minres import MinRes
@@ -135,6 +179,37 @@ def test_gloo_row_partitioned_solve_matches_single_rank(numpy_engine, world, dim
     assert np.linalg.norm(p0 - pr) < 1e-4 * np.linalg.norm(pr)
     um = np.concatenate([d["minres_u"] for d in ranks])
     assert np.linalg.norm(um - ref["minres_u"]) < 1e-5 * np.linalg.norm(ref["minres_u"])
+    if pre == "bjac":
+        # the reference's default preA on slabs (MypreA with GS=True: sweeps inside the slab around the auxiliary-space
+        # term on slabs) == the same operator assembled in one process; BPCG v2 with it needs far fewer iterations
+        import hipla
+        from solvers.bramblepasciak_new import BramblePasciakCG
+        twin, _, A, levels = slab_twin_of_mypre_a(s, world, s.line_blocks(3), coarse_size=40)
+        np.testing.assert_array_equal(ranks[0]["aux_levels"], levels)
+        xa = np.random.default_rng(9).standard_normal(s.n_u)
+        ya = hipla.Vector(s.n_u)
+        twin.Mult(hipla.Vector.from_numpy(xa), ya)
+        got = np.concatenate([d["mypre_apply"] for d in ranks])
+        assert np.linalg.norm(got - ya.numpy()) < 1e-12 * np.linalg.norm(ya.numpy())
+
+        class Form:
+            def __init__(self, mat):
+                self.mat, self.condense = mat, False
+
+        f, g = s.rhs(0)
+        B = hipla.SparseMatrix.from_scipy(s.B)
+        sol = hipla.BlockVector([hipla.Vector(s.n_u), hipla.Vector(s.n_p)])
+        out = io.StringIO()
+        with contextlib.redirect_stdout(out):
+            it_m, _ = BramblePasciakCG(Form(A), Form(B), None, hipla.Vector.from_numpy(f), hipla.Vector.from_numpy(g), twin,
+                                       hipla.DiagonalMatrix(1.0 / s.mass), sol, tol=tol, maxsteps=maxsteps)
+        hist = np.array([float(m) for m in re.findall(r"it =\s+\d+\s+err =\s+(\S+)", out.getvalue())])
+        w = min(20, len(hist), len(ranks[0]["mypre_hist"]))
+        np.testing.assert_allclose(ranks[0]["mypre_hist"][:w], hist[:w], rtol=1e-8)
+        assert abs(int(ranks[0]["mypre_it"]) - it_m) <= max(3, int(0.05 * it_m))
+        um = np.concatenate([d["mypre_u"] for d in ranks])
+        assert np.linalg.norm(um - sol[0].numpy()) < 1e-5 * np.linalg.norm(sol[0].numpy())
+        assert it_m < ref["it"] / 2
 
 
 def test_halo_plan_bookkeeping():

@@ -6,6 +6,7 @@ device-side stop test -- and compares with the single-GPU fused solve."""
 
 import contextlib
 import io
+import re
 
 import numpy as np
 import pytest
@@ -30,9 +31,14 @@ def single_gpu(dim, n, pre, tol, maxsteps):
             self.mat, self.condense = mat, False
 
     sol = hipla.BlockVector([hipla.Vector(s.n_u), hipla.Vector(s.n_p)])
-    with contextlib.redirect_stdout(io.StringIO()):
-        ses = BpcgSession(Form(A), Form(B), None, hipla.Vector.from_numpy(f), hipla.Vector.from_numpy(g), preA, preM,
-                          sol=sol)
+    from hipla import eigen
+    eigen.NATIVE = False       # the partitioned set-up estimates k with the protocol recurrence (all-reducing inner
+    try:                       # product): the same recurrence here, so that the bit-for-bit comparisons below hold
+        with contextlib.redirect_stdout(io.StringIO()):
+            ses = BpcgSession(Form(A), Form(B), None, hipla.Vector.from_numpy(f), hipla.Vector.from_numpy(g), preA, preM,
+                              sol=sol)
+    finally:
+        eigen.NATIVE = True
     ses.first_direction()
     it, hist, conv = ses.fused.run(ses.wdn, ses.err0, tol, True, maxsteps)
     assert conv
@@ -59,9 +65,14 @@ def single_gpu_bpcg1(s, pre, tol, maxsteps):
     f, g = s.rhs(0)
     A, B = hipla.SparseMatrix.from_scipy(s.A), hipla.SparseMatrix.from_scipy(s.B)
     preA = hipla.BlockJacobi(A, s.line_blocks(3)) if pre == "bjac" else hipla.JacobiPreconditioner(A)
-    with contextlib.redirect_stdout(io.StringIO()):
-        x, errors = bramble_pasciak_cg(A, B, None, preA, hipla.DiagonalMatrix(1.0 / s.mass), hipla.Vector.from_numpy(f),
-                                       hipla.Vector.from_numpy(g), tolerance=tol, max_steps=maxsteps, print_rates=False)
+    from hipla import eigen
+    eigen.NATIVE = False       # (as in single_gpu: the protocol recurrence for k, like the partitioned set-up)
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            x, errors = bramble_pasciak_cg(A, B, None, preA, hipla.DiagonalMatrix(1.0 / s.mass), hipla.Vector.from_numpy(f),
+                                           hipla.Vector.from_numpy(g), tolerance=tol, max_steps=maxsteps, print_rates=False)
+    finally:
+        eigen.NATIVE = True
     return dict(errors=np.array(errors), u=x[0].numpy(), p=x[1].numpy())
 
 
@@ -142,6 +153,125 @@ def test_fused_distributed_loop_matches_single_gpu(hip_engine, world, dim, n, pr
         assert abs(int(ranks[0]["amg_it"]) - it_a) <= max(3, int(0.03 * it_a))
         ua = np.concatenate([d["amg_u"] for d in ranks])
         assert np.linalg.norm(ua - sol[0].numpy()) < 1e-5 * np.linalg.norm(sol[0].numpy())
+
+
+@pytest.mark.parametrize("world,dim,n", [(2, 3, 10), (3, 3, 9)])
+def test_gauss_seidel_and_auxiliary_space_preconditioners_on_slabs(hip_engine, world, dim, n):
+    """The reference's default velocity preconditioner on slabs (templates/NavierStokesSIMPLE_iterative.py:168,376-381):
+    (i) the multicolour block Gauss-Seidel sweep inside the slab, additive across slabs, applied natively by the fused
+    partitioned loop (no communication inside the preconditioner), and (ii) MypreA(GS=True) -- those sweeps around the
+    auxiliary-space term on slabs (`DistributedAuxiliary`: transform and its transpose with one plane of halo, one
+    V-cycle on the stacked nodal Laplacian with replicated coarse levels), BPCG v2 through the protocol -- against the
+    SAME operators assembled in one process and run by the single-GPU fused loop."""
+    import hipla
+    from solvers.bramblepasciak_new import BramblePasciakCG
+    from test_distributed_cpu import slab_twin_of_mypre_a
+    tol, maxsteps = 1e-8, 3000
+    ranks = launch(world, "gpu", dim, n, "bjac", tol, maxsteps)
+    s = mac_stokes(dim, n, 0.01)
+    f, g = s.rhs(0)
+    twin, G, A, levels = slab_twin_of_mypre_a(s, world, s.line_blocks(3), coarse_size=40)
+    B = hipla.SparseMatrix.from_scipy(s.B)
+
+    class Form:
+        def __init__(self, mat):
+            self.mat, self.condense = mat, False
+
+    def solve(preA):
+        sol = hipla.BlockVector([hipla.Vector(s.n_u), hipla.Vector(s.n_p)])
+        out = io.StringIO()
+        with contextlib.redirect_stdout(out):
+            it, _ = BramblePasciakCG(Form(A), Form(B), None, hipla.Vector.from_numpy(f), hipla.Vector.from_numpy(g), preA,
+                                     hipla.DiagonalMatrix(1.0 / s.mass), sol, tol=tol, maxsteps=maxsteps)
+        hist = np.array([float(m) for m in re.findall(r"it =\s+\d+\s+err =\s+(\S+)", out.getvalue())])
+        return it, hist, sol[0].numpy()
+
+    # (i) hybrid Gauss-Seidel in the fused partitioned loop == the symmetric sweep over the slab-block-diagonal part of A
+    it_g, hist_g, u_g = solve(G)
+    for d in ranks:
+        assert int(d["bgs_colors"]) == G.ncolors
+        np.testing.assert_array_equal(d["bgs_hist"], ranks[0]["bgs_hist"])
+        w = min(25, len(hist_g), len(d["bgs_hist"]))
+        np.testing.assert_allclose(d["bgs_hist"][:w], hist_g[:w], rtol=1e-8)
+        assert abs(int(d["bgs_it"]) - it_g) <= max(3, int(0.03 * it_g))
+    ug = np.concatenate([d["bgs_u"] for d in ranks])
+    assert np.linalg.norm(ug - u_g) < 1e-5 * np.linalg.norm(u_g)
+    # (ii) MypreA(GS=True) with the auxiliary-space term on slabs
+    np.testing.assert_array_equal(ranks[0]["aux_levels"], levels)
+    xa = np.random.default_rng(9).standard_normal(s.n_u)
+    ya = hipla.Vector(s.n_u)
+    twin.Mult(hipla.Vector.from_numpy(xa), ya)
+    got = np.concatenate([d["mypre_apply"] for d in ranks])
+    assert np.linalg.norm(got - ya.numpy()) < 1e-12 * np.linalg.norm(ya.numpy())
+    it_m, hist_m, u_m = solve(twin)
+    w = min(20, len(hist_m), len(ranks[0]["mypre_hist"]))
+    np.testing.assert_allclose(ranks[0]["mypre_hist"][:w], hist_m[:w], rtol=1e-8)
+    assert abs(int(ranks[0]["mypre_it"]) - it_m) <= max(3, int(0.05 * it_m))
+    um = np.concatenate([d["mypre_u"] for d in ranks])
+    assert np.linalg.norm(um - u_m) < 1e-5 * np.linalg.norm(u_m)
+
+
+def test_native_partitioned_mypre_a_single_rank(hip_engine, tmp_path):
+    """MypreA(GS=True) with the auxiliary-space term applied NATIVELY inside the partitioned BPCG loop (nss_dist_aux_*:
+    the C loop issues the halo exchanges of the argument and of the nodal correction, those of the V-cycle and its
+    coarse all-reduce, and the exchange of the iterate for the residual between the sweeps), on a 1-rank RCCL
+    communicator: the native auxiliary apply equals the protocol `DistributedAuxiliary.Mult`, and the solve follows the
+    single-GPU fused loop with the same operator (one slab: its Gauss-Seidel is the single-GPU sweep)."""
+    import torch.distributed as dist
+    import hipla
+    from distributed import DistributedBpcg2
+    from rccl_comm import RcclComm
+    from solvers.bramblepasciak_new import BramblePasciakCG
+    s = mac_stokes(3, 12, 0.01)
+    f, g = s.rhs(0)
+    tol, maxsteps = 1e-8, 2000
+
+    class Form:
+        def __init__(self, mat):
+            self.mat, self.condense = mat, False
+
+    dist.init_process_group("gloo", init_method="file://" + str(tmp_path / "rdv"), rank=0, world_size=1)
+    try:
+        comm = RcclComm(dist, hip_engine)
+        run = DistributedBpcg2(s, f, g, s.line_blocks(3), dist, hip_engine, comm=comm, pre="mypre_a",
+                               aux_options=dict(coarse_size=300))
+        assert run.native is not None and run.compact and run.ops.aux is not None
+        aux = run.ops.aux
+        x = hipla.Vector.from_numpy(np.random.default_rng(3).standard_normal(s.n_u))
+        y_host, y_native = hipla.Vector(s.n_u), hipla.Vector(s.n_u)
+        y_host.data = aux * x
+        aux.native_apply(1.0, x, y_native)
+        assert np.linalg.norm(y_native.numpy() - y_host.numpy()) <= 1e-13 * np.linalg.norm(y_host.numpy())
+        it, conv = run.solve(tol=tol, maxsteps=maxsteps, poll_every=16)
+        assert conv
+        # the same operator on one GPU: sweeps over A, one V-cycle on the stacked nodal Laplacian
+        A, B = hipla.SparseMatrix.from_scipy(s.A), hipla.SparseMatrix.from_scipy(s.B)
+        st = s.auxiliary_space_stacked()
+        V = hipla.SmoothedAggregationAMG(hipla.SparseMatrix.from_scipy(st["laplacian"]), coarse_size=300)
+        assert aux.level_sizes == V.level_sizes
+        single = hipla.BlockGaussSeidel(A, s.line_blocks(3),
+                                        middle=hipla.AuxiliarySpaceAMG(hipla.SparseMatrix.from_scipy(st["transform"]), [V]))
+        sol = hipla.BlockVector([hipla.Vector(s.n_u), hipla.Vector(s.n_p)])
+        out = io.StringIO()
+        from hipla import fused
+        runs, orig_run = [], fused.Bpcg2Loop.run
+        fused.Bpcg2Loop.run = lambda self, *a, **k: (runs.append(1), orig_run(self, *a, **k))[1]
+        try:
+            with contextlib.redirect_stdout(out):
+                it_s, _ = BramblePasciakCG(Form(A), Form(B), None, hipla.Vector.from_numpy(f), hipla.Vector.from_numpy(g),
+                                           single, hipla.DiagonalMatrix(1.0 / s.mass), sol, tol=tol, maxsteps=maxsteps)
+        finally:
+            fused.Bpcg2Loop.run = orig_run
+        assert runs == [1]                                                     # the single-GPU fused loop, natively
+        hist = np.array([float(m) for m in re.findall(r"it =\s+\d+\s+err =\s+(\S+)", out.getvalue())])
+        w = min(20, len(hist), it + 1)
+        np.testing.assert_allclose(run.history(it)[:w], hist[:w], rtol=1e-8)
+        assert abs(it - it_s) <= max(3, int(0.05 * it_s)) and it < 120
+        assert np.linalg.norm(run.sol[0].numpy() - sol[0].numpy()) < 1e-5 * np.linalg.norm(sol[0].numpy())
+        run.release()
+        comm.close()
+    finally:
+        dist.destroy_process_group()
 
 
 def test_rccl_ctypes_communicator_single_rank(hip_engine, tmp_path):
