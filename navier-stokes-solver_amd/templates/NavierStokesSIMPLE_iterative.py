@@ -81,9 +81,12 @@ def auxiliary_space_preconditioner(system):
     transform = hipla.SparseMatrix.from_scipy(space["transform"])
     ndof = transform.width
     comps, preAh1 = [], None
+    built = {}
     for lap, rng in zip(space["laplacians"], space["ranges"]):
-        aH1 = AssembledForm(hipla.SparseMatrix.from_scipy(lap))
-        pre_c = hipla.Preconditioner(aH1, "h1amg")                       # :326-329,340-349
+        if id(lap) not in built:       # components with the same boundary conditions share one matrix: one hierarchy
+            aH1 = AssembledForm(hipla.SparseMatrix.from_scipy(lap))
+            built[id(lap)] = hipla.Preconditioner(aH1, "h1amg")          # :326-329,340-349
+        pre_c = built[id(lap)]
         emb = hipla.Embedding(ndof, rng)                                 # :334-335,353-355
         term = emb @ pre_c @ emb.T
         preAh1 = term if preAh1 is None else preAh1 + term               # :337,357

@@ -1271,8 +1271,12 @@ def test_fused_loops_on_unstructured_saddle_systems(hip_engine, seed):
         ses = BpcgSession(Form(Ad), Form(Bd), None, hipla.Vector.from_numpy(f), hipla.Vector.from_numpy(g), preA, preS)
     assert ses.fused is not None
     it_o, u_o, p_o, hist_o = kr.bpcg_v2(A, B, pa, ps, f, g, ses.k, tol=tol, maxsteps=maxsteps)[:4]
-    w = min(25, len(hist), len(hist_o))
+    # (no stable window is recorded for these random systems; measured: a regrouping of the dot partials -- B planned
+    # with shorter row blocks -- moves entry 20 of seed 1 by 1.6e-8: 1e-8 over the first 15 entries, 1e-6 over 25)
+    w = min(15, len(hist), len(hist_o))
     np.testing.assert_allclose(hist[:w], hist_o[:w], rtol=1e-8)
+    w = min(25, len(hist), len(hist_o))
+    np.testing.assert_allclose(hist[:w], hist_o[:w], rtol=1e-6)
     assert abs(it - it_o) <= max(3, int(0.03 * it_o))
     assert np.linalg.norm(b - K @ sol.numpy()) < 1e-6 * np.linalg.norm(b)
 
