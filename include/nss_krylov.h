@@ -361,6 +361,11 @@ typedef struct nss_bpcg2_s {
    * (:376-381) whose sweeps run inside the slab (additive across slabs) and whose residual uses the partitioned A;
    * NULL otherwise */
   struct nss_dist_aux_s* pre_dist_aux;
+  /* row-partitioned runs on the compact plan: the mailbox transport (nss_p2p_create) -- the two all-reduces of an
+   * iteration happen INSIDE the sum kernels (remote stores into the peers' mailboxes, a bounded spin on the own one,
+   * the nranks values added in rank order) and the halo of t1 travels by a put kernel into the neighbours' landing
+   * zones; no collective library on the critical path.  NULL: RCCL (nss_dist_t). */
+  struct nss_p2p_s* p2p;
 } nss_bpcg2_t;
 
 enum {
@@ -480,6 +485,24 @@ NSS_API int nss_dist_aux_create(nss_dist_t d, nss_csr_t tt_loc, const nss_halo_t
                                 const nss_halo_t* halo_e, nss_dist_amg_t amg, const nss_halo_t* halo_y, nss_dist_aux_t* out);
 NSS_API int nss_dist_aux_destroy(nss_dist_aux_t h);
 NSS_API int nss_dist_aux_apply_f64(nss_dist_aux_t h, double scale, const double* b, double* y, nss_stream_t stream);
+
+/* ---- mailbox transport over xGMI (peer-mapped memory, no collective library) -----------------------------------
+ * Every rank owns a small fine-grained region -- a mailbox of 2 x nranks word pairs, one arrival flag per source rank
+ * and a landing zone for the ghost entries of ONE operand layout (`halo`, direct sends only) -- that its peers map
+ * through HIP IPC and write into with plain stores (csrc/p2p.h).  nss_p2p_create writes this rank's blob
+ * (nss_p2p_blob_bytes: the 64-byte IPC handle + where it wants each peer's segment); the host gathers the blobs of all
+ * ranks in rank order (any side channel) and hands them to nss_p2p_connect.  At most 16 ranks.  Every device-side
+ * spin is bounded (3 s): a peer that does not arrive stops the loop, nss_bpcg2_poll then reports done = 3.
+ * nss_p2p_allreduce_f64 (one double, rank-ordered sum, the same bits on every rank) and nss_p2p_exchange are the
+ * stand-alone forms of what the partitioned loop does with `nss_bpcg2_t.p2p` set (tests). */
+typedef struct nss_p2p_s* nss_p2p_t;
+NSS_API int nss_p2p_blob_bytes(int32_t nranks, int64_t* bytes);
+NSS_API int nss_p2p_create(int32_t nranks, int32_t rank, const nss_halo_t* halo, int32_t n_owned, nss_p2p_t* out, void* h_blob);
+NSS_API int nss_p2p_connect(nss_p2p_t p, const void* h_blobs);
+NSS_API int nss_p2p_destroy(nss_p2p_t p);
+NSS_API int nss_p2p_allreduce_f64(nss_p2p_t p, const double* src, double* dst, nss_stream_t stream);
+NSS_API int nss_p2p_exchange(nss_p2p_t p, const nss_halo_t* halo, int32_t n_owned, nss_stream_t stream);
+NSS_API int nss_p2p_error(nss_p2p_t p, int32_t* timed_out, nss_stream_t stream);
 
 /* Per-phase device times of the native partitioned loop: between _begin and _end every iteration issued by
  * nss_bpcg2_iterate_dist (up to max_iterations) records 9 HIP events on the compute stream; _end waits for them

@@ -231,6 +231,30 @@ __global__ __launch_bounds__(kSumLanes) void bpcg2_sum_kernel(const int32_t* __r
   if (threadIdx.x == 0) scal[slot] = t;
 }
 
+// The same sum followed, in the same launch, by the all-reduce over the ranks through the peer-mapped mailboxes
+// (p2p.h): the local sum goes to scal[local_slot], the global one -- the nranks values added in rank order, the same
+// bits on every rank -- to scal[slot].  A peer that does not arrive within the timeout stops the loop (breakdown code 3).
+__global__ __launch_bounds__(kSumLanes) void bpcg2_sum_p2p_kernel(int32_t* __restrict__ ctrl, int na,
+                                                                   const double* __restrict__ pa, int nb,
+                                                                   const double* __restrict__ pb, double* __restrict__ scal,
+                                                                   int slot, int local_slot, int it, P2pView v) {
+  __shared__ double lds[kRedDoubles];
+  static_assert(kRedDoubles >= kP2pMaxRanks, "reduction scratch too small for the mailbox values");
+  if (ctrl[C_DONE] != 0) return;
+  const double local = fixed_sum_1024<kSumLanes>(pa, na, pb, nb, lds);
+  const double total = p2p_allreduce_sum(v, local, lds);
+  if (threadIdx.x == 0) {
+    scal[local_slot] = local;
+    scal[slot] = total;
+    if (*reinterpret_cast<volatile int32_t*>(v.error) != 0) {
+      ctrl[C_BREAKDOWN] = 3;
+      ctrl[C_IT_FINAL] = it;
+      ctrl[C_PENDING] = 0;
+      ctrl[C_DONE] = 1;
+    }
+  }
+}
+
 struct K4Args {
   int32_t* ctrl;
   double* scal;
@@ -683,6 +707,9 @@ void bpcg2_check_state(const nss_bpcg2_t* s) {
                     s->ghost_w1 == s->w1 + s->n_p && s->ghost_t3 == s->t3 + s->n_p && (s->ghost_p_n == 0 || s->ghost_minv),
                 "bpcg2: compact partitioned plan: ghost copies must sit behind the owned entries of s0, w0, w1, t3");
     NSS_REQUIRE(!s->cond_HT, "bpcg2: compact partitioned plan takes no condensed form");
+    NSS_REQUIRE(!s->p2p || s->p2p->connected, "bpcg2: the mailbox transport is not connected");
+  } else if (s->p2p) {
+    throw Error("bpcg2: the mailbox transport (p2p) serves the compact partitioned plan only");
   } else {
     NSS_REQUIRE(s->B->m == s->n_p, "bpcg2: matrix row counts do not match n_p");
   }
@@ -814,8 +841,12 @@ void bpcg2_phase(const nss_bpcg2_t& s, int which, int it, hipStream_t st) {
       bpcg2_spmv_phase(s, which, it, st, 0, -1);
       break;
     case NSS_BPCG2_SUM1:
-      hipLaunchKernelGGL(bpcg2_sum_kernel, dim3(1), dim3(kSumLanes), 0, st, s.ctrl, s.A->nblk, s.partials_a, s.B->nblk,
-                         s.partials_b, s.scal, int(s.local_sums ? S_AS_LOCAL : S_AS));
+      if (s.p2p)
+        hipLaunchKernelGGL(bpcg2_sum_p2p_kernel, dim3(1), dim3(kSumLanes), 0, st, s.ctrl, s.A->nblk, s.partials_a, s.B->nblk,
+                           s.partials_b, s.scal, int(S_AS), int(S_AS_LOCAL), it, s.p2p->view(++s.p2p->seq));
+      else
+        hipLaunchKernelGGL(bpcg2_sum_kernel, dim3(1), dim3(kSumLanes), 0, st, s.ctrl, s.A->nblk, s.partials_a, s.B->nblk,
+                           s.partials_b, s.scal, int(s.local_sums ? S_AS_LOCAL : S_AS));
       NSS_CHECK_LAUNCH();
       break;
     case NSS_BPCG2_ALPHA:   // folded into K4 (kept as a phase id for callers that list all phases)
@@ -827,8 +858,12 @@ void bpcg2_phase(const nss_bpcg2_t& s, int which, int it, hipStream_t st) {
       launch_k4(s, it, false, st);
       break;
     case NSS_BPCG2_SUM2:
-      hipLaunchKernelGGL(bpcg2_sum_kernel, dim3(1), dim3(kSumLanes), 0, st, s.ctrl, k4_partials(s), s.partials_c, 0,
-                         s.partials_c, s.scal, int(s.local_sums ? S_WDN_LOCAL : S_WDN));
+      if (s.p2p)
+        hipLaunchKernelGGL(bpcg2_sum_p2p_kernel, dim3(1), dim3(kSumLanes), 0, st, s.ctrl, k4_partials(s), s.partials_c, 0,
+                           s.partials_c, s.scal, int(S_WDN), int(S_WDN_LOCAL), it, s.p2p->view(++s.p2p->seq));
+      else
+        hipLaunchKernelGGL(bpcg2_sum_kernel, dim3(1), dim3(kSumLanes), 0, st, s.ctrl, k4_partials(s), s.partials_c, 0,
+                           s.partials_c, s.scal, int(s.local_sums ? S_WDN_LOCAL : S_WDN));
       NSS_CHECK_LAUNCH();
       break;
     case NSS_BPCG2_BETA:    // folded into K5
@@ -982,7 +1017,8 @@ int nss_bpcg2_poll(const nss_bpcg2_t* s, int32_t* done, int32_t* it_final, int32
     int32_t h[4] = {0, 0, 0, 0};
     NSS_HIP(hipMemcpyAsync(h, s->ctrl, sizeof(int32_t) * 4, hipMemcpyDeviceToHost, as_stream(stream)));
     NSS_HIP(hipStreamSynchronize(as_stream(stream)));
-    if (done) *done = h[C_DONE] ? (h[C_BREAKDOWN] ? 2 : 1) : 0;   // 2: alpha = wd / 0 breakdown
+    // 2: alpha = wd / 0 breakdown; 3: a peer of the mailbox transport did not arrive in time
+    if (done) *done = h[C_DONE] ? (h[C_BREAKDOWN] == 3 ? 3 : (h[C_BREAKDOWN] ? 2 : 1)) : 0;
     if (it_final) *it_final = h[C_IT_FINAL];
     if (last_it) *last_it = h[C_LAST_IT];
   });

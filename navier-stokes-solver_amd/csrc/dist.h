@@ -2,6 +2,7 @@
 #pragma once
 
 #include "bpcg2.h"
+#include "p2p.h"
 
 #include <vector>
 

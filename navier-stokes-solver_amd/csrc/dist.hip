@@ -377,7 +377,7 @@ int nss_bpcg2_iterate_dist(const nss_bpcg2_t* s, nss_dist_t d, const nss_halo_t*
   return guarded([&] {
     bpcg2_check_state(s);
     NSS_REQUIRE(d != nullptr, "iterate_dist: NULL dist handle");
-    NSS_REQUIRE(d->nranks == 1 || d->comm != nullptr, "iterate_dist: multi-rank run without a communicator");
+    NSS_REQUIRE(d->nranks == 1 || d->comm != nullptr || s->p2p != nullptr, "iterate_dist: multi-rank run without a communicator");
     if (s->dist_compact) {
       // Compact plan: C1 (books of the previous iteration from the ALL-REDUCED <w, d>, rows of B^T, ghost copies of
       // s0) . preA . exchange of t1 . C23 (rows of A; owned and ghost rows of B on t1 - s0) . sum . all-reduce .
@@ -393,18 +393,19 @@ int nss_bpcg2_iterate_dist(const nss_bpcg2_t* s, nss_dist_t d, const nss_halo_t*
         mark(0);
         bpcg2_cphase(*s, NSS_BPCG2C_C1, it, cs);           // + preA
         mark(1);
-        exchange(*d, *halo_t1, cs);
+        if (s->p2p) p2p_exchange(*s->p2p, *halo_t1, s->n_u, s->ctrl, cs);   // put + wait/copy through the landing zones
+        else exchange(*d, *halo_t1, cs);
         mark(2);
         bpcg2_cphase(*s, NSS_BPCG2C_C23, it, cs);
         mark(3);
-        bpcg2_cphase(*s, NSS_BPCG2C_SUMA, it, cs);
+        bpcg2_cphase(*s, NSS_BPCG2C_SUMA, it, cs);          // mailbox transport: the all-reduce is part of this launch
         mark(4);
-        allreduce_slot(*s, *d, S_AS_SLOT, cs);
+        if (!s->p2p) allreduce_slot(*s, *d, S_AS_SLOT, cs);
         mark(5);
         bpcg2_cphase(*s, NSS_BPCG2C_C4, it, cs);           // alpha inside
         bpcg2_cphase(*s, NSS_BPCG2C_SUMW, it, cs);
         mark(6);
-        allreduce_slot(*s, *d, S_WDN_SLOT, cs);             // read by C1 of the next iteration (or the poll)
+        if (!s->p2p) allreduce_slot(*s, *d, S_WDN_SLOT, cs);   // read by C1 of the next iteration (or the poll)
         mark(7);
         mark(8);
         if (ev) ++d->prof_iters;

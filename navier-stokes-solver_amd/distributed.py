@@ -184,6 +184,51 @@ class TorchComm:
             self.dist.all_to_all_single(tail, send, output_split_sizes=outs, input_split_sizes=ins)
 
 
+class MailboxTransport:
+    """The mailbox transport of the native partitioned loop (csrc/p2p.h, `nss_p2p_*`): every rank owns a small
+    fine-grained region -- all-reduce mailbox, halo arrival flags, a landing zone for the ghosts of ONE operand layout --
+    that its peers map through HIP IPC and write into with plain remote stores over xGMI.  Set-up: create the region
+    for `halo` (the operand's `nss_halo_t`), gather everybody's blob (IPC handle + where each peer's segment is wanted)
+    over the set-up communicator, map the peers.  At most 16 ranks."""
+
+    def __init__(self, comm, engine, halo, n_owned):
+        import ctypes as C
+        self.engine, self.comm = engine, comm
+        nbytes = C.c_int64()
+        engine._check(engine.lib.nss_p2p_blob_bytes(comm.size, C.byref(nbytes)))
+        blob = C.create_string_buffer(nbytes.value)
+        self.handle = C.c_void_p()
+        self._halo = halo
+        engine._check(engine.lib.nss_p2p_create(comm.size, comm.rank, C.byref(halo), int(n_owned), C.byref(self.handle), blob))
+        blobs = comm.gather_objects(bytes(blob.raw)) if comm.size > 1 else [bytes(blob.raw)]
+        engine._check(engine.lib.nss_p2p_connect(self.handle, b"".join(blobs)))
+
+    def allreduce(self, src, dst):
+        """dst[0] = sum over the ranks of src[0] (device buffers), the ranks' values added in rank order."""
+        self.engine._check(self.engine.lib.nss_p2p_allreduce_f64(self.handle, src.data_ptr(), dst.data_ptr(), self.engine.stream))
+
+    def exchange(self, n_owned):
+        import ctypes as C
+        self.engine._check(self.engine.lib.nss_p2p_exchange(self.handle, C.byref(self._halo), int(n_owned), self.engine.stream))
+
+    def timed_out(self):
+        import ctypes as C
+        out = C.c_int32()
+        self.engine._check(self.engine.lib.nss_p2p_error(self.handle, C.byref(out), self.engine.stream))
+        return bool(out.value)
+
+    def close(self):
+        if self.handle is not None:
+            self.engine.lib.nss_p2p_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 # --------------------------------------------------------------------------------------
 # distributed operands
 # --------------------------------------------------------------------------------------
@@ -761,7 +806,7 @@ class DistributedBpcg2:
                         ("cphases", ("C4", "SUMW")), ("allreduce", 2))
 
     def __init__(self, sysm, f, g, blocks, dist, engine=None, comm=None, quiet=True, native=True, pre=None, plan=None,
-                 aux_options=None):
+                 aux_options=None, transport=None):
         """`native=False` keeps the Python-driven schedule even when `comm` is an `RcclComm` (its
         collectives are then single ctypes calls into librccl between the device phases).
         `pre="amg"`: preA = the V-cycle with replicated coarse levels (`DistributedAMG`), applied inside the
@@ -776,6 +821,7 @@ class DistributedBpcg2:
         eight-phase form (the only one with the interior / boundary overlap)."""
         import contextlib
         self.want_native = bool(native)
+        self.want_transport = transport          # "mailbox": csrc/p2p.h instead of RCCL inside the iterations
         import io
         from hipla import BlockVector
         from solvers.bramblepasciak_new import BpcgSession
@@ -880,6 +926,9 @@ class DistributedBpcg2:
         comm_handle = getattr(self.comm, "comm", None)         # RcclComm: an ncclComm_t
         if comm_handle is not None and getattr(self, "want_native", True) and hasattr(self.loop.lib, "nss_bpcg2_iterate_dist"):
             self.enable_native(comm_handle)
+        self.mailbox = None
+        if getattr(self, "want_transport", None) == "mailbox":
+            self.enable_mailbox()
 
     def _setup_ghosts(self):
         """Ghost copies of s0 / w0 on the ghost columns of B's operand (nss_bpcg2_t.ghost_*): every
@@ -969,7 +1018,30 @@ class DistributedBpcg2:
                  ops.B.native_halo(self.t4, interior.get("t4")))      # (the compact plan uses the middle one only)
         self.native = (handle, halos)
 
+    def enable_mailbox(self):
+        """Run the native compact loop over the mailbox transport (`MailboxTransport`): the all-reduces inside the sum
+        kernels, the halo of t1 by put / wait-copy kernels -- no RCCL call in an iteration.  The set-up communicator
+        (any `TorchComm`) only gathers the IPC blobs."""
+        import ctypes as C
+        if not getattr(self, "compact", False):
+            raise RuntimeError("the mailbox transport serves the compact partitioned plan")
+        if self.ops.A.plan.n_ghost and not self.ops.A.plan.direct:
+            raise RuntimeError("the mailbox transport needs contiguous send runs (slab partitions have them)")
+        self.close()
+        eng = self.engine
+        handle = C.c_void_p()
+        eng._check(eng.lib.nss_dist_create(None, self.comm.size, self.comm.rank, C.byref(handle)))
+        halo = self.ops.A.native_halo(self.t1, (0, 0))
+        self.native = (handle, (None, halo, None))
+        self.mailbox = MailboxTransport(self.comm, eng, halo, self.ops.n_u)
+        self.loop.state.p2p = self.mailbox.handle
+        self.loop.keep.append(self.mailbox)
+
     def close(self):
+        if getattr(self, "mailbox", None) is not None:
+            self.loop.state.p2p = None
+            self.mailbox.close()
+            self.mailbox = None
         if getattr(self, "native", None) is not None:
             self.engine.lib.nss_dist_destroy(self.native[0])
             self.native = None

@@ -38,7 +38,7 @@ class Bpcg2State(C.Structure):
                    ("ghost_p_mode", C.c_int32), ("ghost_p_n", C.c_int32), ("ghost_b", C.c_void_p),
                    ("ghost_t3", C.c_void_p), ("ghost_w1", C.c_void_p), ("ghost_minv", C.c_void_p),
                    ("local_sums", C.c_int32), ("pre_dist_amg", C.c_void_p), ("dist_compact", C.c_int32),
-                   ("pre_dist_aux", C.c_void_p)])
+                   ("pre_dist_aux", C.c_void_p), ("p2p", C.c_void_p)])
 
 
 class HaloStruct(C.Structure):
@@ -275,8 +275,9 @@ class Bpcg2Loop:
 
     def enqueue_dist(self, dist_handle, halos, overlap, it_begin, it_end):
         """Row-partitioned iterations issued natively (nss_bpcg2_iterate_dist)."""
-        self.eng._check(self.lib.nss_bpcg2_iterate_dist(C.byref(self.state), dist_handle, C.byref(halos[0]),
-                                                        C.byref(halos[1]), C.byref(halos[2]), int(overlap),
+        ref = lambda h: C.byref(h) if h is not None else None     # (compact plan: only the halo of t1 is used)
+        self.eng._check(self.lib.nss_bpcg2_iterate_dist(C.byref(self.state), dist_handle, ref(halos[0]),
+                                                        ref(halos[1]), ref(halos[2]), int(overlap),
                                                         int(it_begin), int(it_end), self.eng.stream))
 
     def poll(self):
@@ -284,6 +285,8 @@ class Bpcg2Loop:
         done, it_final, last = C.c_int32(), C.c_int32(), C.c_int32()
         self.eng._check(self.lib.nss_bpcg2_poll(C.byref(self.state), C.byref(done), C.byref(it_final),
                                                 C.byref(last), self.eng.stream))
+        if done.value == 3:
+            raise RuntimeError("mailbox transport: a peer did not arrive within the timeout (iteration %d)" % it_final.value)
         if done.value == 2:      # the reference's `alpha = wd / as_s` with as_s == 0 (:226)
             raise ZeroDivisionError("float division by zero (BPCG breakdown <s, K s> = 0 at iteration %d)"
                                     % it_final.value)

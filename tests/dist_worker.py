@@ -107,6 +107,37 @@ def run(rank, world, mode, init_file, out_dir, dim, n, pre, tol, maxsteps):
         res["ghost_mode"] = int(bool(run_.ghost_mode)) + int(bool(getattr(run_, "ghost_p_mode", False)))
         res["it"], res["k"], res["err0"] = it, run_.k, run_.err0
         res["u"], res["p"] = run_.sol[0].numpy(), run_.sol[1].numpy()
+        # ---- the mailbox transport (csrc/p2p.h): peer-mapped mailboxes / landing zones, no collective library --------
+        #      stand-alone: an all-reduce of rank-dependent values and the halo exchange of A's operand ...
+        from distributed import MailboxTransport
+        import torch as _torch
+        probe = ops.A.operand()
+        mb = MailboxTransport(comm, eng, ops.A.native_halo(probe, (0, 0)), ops.n_u)
+        vals = []
+        for rep in range(6):
+            src = _torch.tensor([np.sin(1.0 + rank + 10.0 * rep) * 1e3], dtype=_torch.float64, device=eng.device)
+            dst = _torch.zeros(1, dtype=_torch.float64, device=eng.device)
+            mb.allreduce(src, dst)
+            vals.append(float(dst.cpu()[0]))
+        res["mailbox_allreduce"] = np.array(vals)
+        xg = np.random.default_rng(21).standard_normal(sysm.n_u)
+        for rep in range(3):
+            probe.set_from((rep + 1.0) * xg[us])
+            mb.exchange(ops.n_u)
+            _torch.cuda.synchronize()
+            got = eng.to_host(probe.ext)[ops.n_u:]
+            res["mailbox_halo_err%d" % rep] = float(np.max(np.abs(got - (rep + 1.0) * xg[ops.A.plan.ghosts]))) if got.size else 0.0
+        res["mailbox_timeout"] = int(mb.timed_out())
+        mb.close()
+        #      ... and the native compact loop over it: no RCCL / gloo call inside an iteration
+        mrun = DistributedBpcg2(sysm, f, g, blocks, dist, eng, comm=comm, transport="mailbox")
+        assert mrun.mailbox is not None and mrun.native is not None
+        it_mb, _ = mrun.solve(tol=tol, maxsteps=maxsteps, poll_every=16)
+        res["mailbox_hist"], res["mailbox_it"] = mrun.history(it_mb), it_mb
+        res["mailbox_u"], res["mailbox_p"] = mrun.sol[0].numpy(), mrun.sol[1].numpy()
+        prof, nprof = mrun.profile(it_mb + 1, 8)          # (after the stop: the kernels return at once; the call path works)
+        res["mailbox_profile_n"] = nprof
+        mrun.release()
         # ---- fused row-partitioned MINRES (device phases + exchanges / all-reduces in between) ----------
         from distributed import DistributedMinres
         mr = DistributedMinres(sysm, f, g, blocks, dist, eng, comm=comm)

@@ -102,6 +102,28 @@ def test_fused_distributed_loop_matches_single_gpu(hip_engine, world, dim, n, pr
     assert np.linalg.norm(u - ref["u"]) < 1e-5 * np.linalg.norm(ref["u"])
     p0, pr = p - p.mean(), ref["p"] - ref["p"].mean()
     assert np.linalg.norm(p0 - pr) < 1e-4 * np.linalg.norm(pr)
+    # the mailbox transport (csrc/p2p.h) -- the `world` processes map each other's mailboxes / landing zones through
+    # HIP IPC (here all on one GPU; over xGMI on a node): the all-reduce adds the ranks' values in rank order (the same
+    # bits on every rank), the put / wait-copy exchange fills every ghost tail with the owners' entries, and the NATIVE
+    # compact loop over it -- no collective library inside an iteration -- reproduces the gloo-driven loop
+    for rep in range(6):
+        want = 0.0
+        for r in range(world):
+            want += np.sin(1.0 + r + 10.0 * rep) * 1e3
+        for d in ranks:
+            assert d["mailbox_allreduce"][rep] == want
+    for d in ranks:
+        assert int(d["mailbox_timeout"]) == 0
+        assert max(float(d["mailbox_halo_err%d" % rep]) for rep in range(3)) == 0.0
+        np.testing.assert_array_equal(d["mailbox_hist"], ranks[0]["mailbox_hist"])       # same decision on every rank
+        w = min(30, len(d["hist"]), len(d["mailbox_hist"]))
+        np.testing.assert_allclose(d["mailbox_hist"][:w], d["hist"][:w], rtol=1e-9)
+        assert abs(int(d["mailbox_it"]) - int(d["it"])) <= max(3, int(0.03 * int(d["it"])))
+        if world == 2:                # two values: the sum does not depend on the order -- identical bits
+            np.testing.assert_array_equal(d["mailbox_hist"], d["hist"])
+            np.testing.assert_array_equal(d["mailbox_u"], d["u"])
+    um = np.concatenate([d["mailbox_u"] for d in ranks])
+    assert np.linalg.norm(um - ref["u"]) < 1e-5 * np.linalg.norm(ref["u"])
     # fused row-partitioned MINRES against the single-GPU fused MINRES
     mref = single_gpu_minres(s, pre, tol, maxsteps)
     for d in ranks:

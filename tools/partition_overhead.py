@@ -126,6 +126,14 @@ def main():
         show("partitioned, native, %s plan (%d launches + 3 collectives)" % (plan, 6 if plan == "compact" else 9), us, phases)
         run.release()
         del run
+    # the mailbox transport (csrc/p2p.h) on one rank: the all-reduce is part of the sum kernel (a store to and a load
+    # from the own mailbox), no exchange -- the launch structure of an N-rank run without any link
+    run = DistributedBpcg2(s, f, g, s.line_blocks(3), dist, eng, comm=comm, transport="mailbox")
+    assert run.mailbox is not None
+    us, phases = rate(run)
+    show("partitioned, native, compact plan over the mailbox transport (6 launches, no collective library)", us, phases)
+    run.release()
+    del run
     if grid_b > 0:
         s = mac_stokes(3, grid_b, 0.01)
         f, g = s.rhs(0)
