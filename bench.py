@@ -522,7 +522,9 @@ def main():
         candidates = []
         if rccl is not None:
             candidates += [("rccl-python", rccl, False, None), ("native", rccl, True, None)]
-        if backend == "nccl" and os.environ.get("NSS_MAILBOX", "1") == "1" and world <= 16:
+        # (with the gloo rehearsal backend -- several ranks on one GPU -- only on request: NSS_MAILBOX=1)
+        if ((backend == "nccl" and os.environ.get("NSS_MAILBOX", "1") != "0") or os.environ.get("NSS_MAILBOX") == "1") \
+                and world <= 16:
             candidates += [("mailbox", torch_comm, True, "mailbox")]
         candidates = [c for c in candidates if TIERS.index(c[0]) <= tier_level]
         if candidates:
@@ -542,7 +544,7 @@ def main():
                     same = False
                     crosscheck_ms[label] = float("inf")
                 flag = torch.tensor([1.0 if same else 0.0, -crosscheck_ms[label] if same else 0.0], dtype=torch.float64,
-                                    device="cuda")
+                                    device="cuda" if backend == "nccl" else "cpu")
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)            # all ranks agree; the slowest rank's time counts
                 if flag[0].item() == 1.0:
                     if probe_child:
@@ -581,7 +583,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
             windows.append(time.perf_counter() - t0)
-        tt = torch.tensor(windows, dtype=torch.float64, device="cuda")
+        tt = torch.tensor(windows, dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)           # per window: the slowest rank
         windows = [float(v) for v in tt.tolist()]
         elapsed = float(np.median(windows))
