@@ -112,38 +112,52 @@ def _native_lanczos(mat, pre, start, tol, maxsteps, check_every):
     h_hist = torch.empty(2 * maxsteps, dtype=torch.float64).pin_memory()
     pending = []                                          # (end, event, slot)
 
+    # A batch is a multiple of `check_every` steps sized to ~1.5 ms of device work (launch-bound small systems: the
+    # host's per-batch work -- copies, event, the checks -- is then a small part); the checks of the steps
+    # check_every - 1, 2 check_every - 1, ... inside a batch are made in order afterwards, exactly as if the host had
+    # looked after each of them.
+    est_step = 25e-6 + (12.0 * mat.nnz + 80.0 * n) / 5e12
+    per_batch = check_every * max(1, min(8, int(round(1.5e-3 / est_step / check_every))))
+    nbatch = [0]
+
     def enqueue(j0):
-        end = min(maxsteps, j0 + check_every)
+        end = min(maxsteps, j0 + per_batch)
         eng._check(eng.lib.nss_lanczos_iterate(C.byref(st), j0, end, eng.stream))
-        slot = (j0 // check_every) & 1
+        slot = nbatch[0] & 1
+        nbatch[0] += 1
         h_ctrl[slot].copy_(ctrl, non_blocking=True)
         h_hist[2 * j0: 2 * end].copy_(hist[2 * j0: 2 * end], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        pending.append((end, ev, slot))
+        pending.append((j0, end, ev, slot))
         return end
 
     lo_prev = hi_prev = None
     diag = off = np.zeros(0)
+    finished = False
     j = enqueue(0)
-    while pending:
+    while pending and not finished:
         if j < maxsteps:
             j = enqueue(j)                                # the next batch runs while this one is looked at
-        end, ev, slot = pending.pop(0)
+        j0, end, ev, slot = pending.pop(0)
         ev.synchronize()
         stop, j_stop = int(h_ctrl[slot][0]), int(h_ctrl[slot][1])
         if stop and j_stop < 0:
             torch.cuda.synchronize()
             return np.zeros(0)                            # gamma_0 == 0
-        j_last = j_stop if stop else end - 1
-        h = h_hist[: 2 * (j_last + 1)].numpy()
-        diag, off = h[0::2][: j_last + 1].copy(), h[1::2][: j_last].copy()
-        lo, hi = _tridiag_extremes(diag, off)
-        if stop:
-            break
-        if lo_prev is not None and abs(lo - lo_prev) <= tol * abs(lo) and abs(hi - hi_prev) <= tol * abs(hi):
-            break
-        lo_prev, hi_prev = lo, hi
+        j_end = j_stop if stop and j_stop < end else end - 1          # last step of this batch that was computed
+        h = h_hist[: 2 * (j_end + 1)].numpy()
+        checks = [jj for jj in range(j0, j_end + 1) if (jj + 1) % check_every == 0 or jj + 1 == maxsteps]
+        if stop and j_stop <= j_end and j_stop not in checks:
+            checks.append(j_stop)                         # the breakdown step is looked at as well
+        for jj in sorted(checks):
+            diag, off = h[0::2][: jj + 1].copy(), h[1::2][: jj].copy()
+            lo, hi = _tridiag_extremes(diag, off)
+            if (stop and jj == j_stop) or (lo_prev is not None and abs(lo - lo_prev) <= tol * abs(lo)
+                                           and abs(hi - hi_prev) <= tol * abs(hi)):
+                finished = True
+                break
+            lo_prev, hi_prev = lo, hi
     torch.cuda.synchronize()                              # (the speculative batch, before its buffers go away)
     return _tridiag_eigs(list(diag), list(off))
 

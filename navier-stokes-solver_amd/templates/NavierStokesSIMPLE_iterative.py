@@ -91,6 +91,13 @@ def auxiliary_space_preconditioner(system):
         term = emb @ pre_c @ emb.T
         preAh1 = term if preAh1 is None else preAh1 + term               # :337,357
         comps.append(pre_c)
+    import os
+    if os.environ.get("NSS_AUX_FORM", "components") == "stacked":
+        # measurement variant: ONE V-cycle on the slab-major stacked block-diagonal Laplacian (what the row-partitioned
+        # form applies): a third of the launches on the launch-bound coarse levels, no shared hierarchy
+        st = system.auxiliary_space_stacked()
+        stacked = hipla.Preconditioner(AssembledForm(hipla.SparseMatrix.from_scipy(st["laplacian"])), "h1amg")
+        return transform, preAh1, hipla.AuxiliarySpaceAMG(hipla.SparseMatrix.from_scipy(st["transform"]), [stacked])
     return transform, preAh1, hipla.AuxiliarySpaceAMG(transform, comps)
 
 
