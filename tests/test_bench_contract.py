@@ -18,8 +18,16 @@ def _bench():
     return mod
 
 
+def _committed_line():
+    for name in ("r03_bench_n136.json", "r02_bench_n136.json", "r01_bench_n136.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            return path
+    raise FileNotFoundError("no committed bench line under profiles/")
+
+
 def test_committed_bench_line_has_the_contract_keys():
-    with open(os.path.join(ROOT, "profiles", "r01_bench_n136.json")) as fh:
+    with open(_committed_line()) as fh:
         lines = [ln for ln in fh.read().splitlines() if ln.strip()]
     assert len(lines) == 1                                   # ONE line on stdout
     d = json.loads(lines[0])
@@ -37,6 +45,17 @@ def test_committed_bench_line_has_the_contract_keys():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "iters/s" and c["value"] > 0 and c["sample"]
     assert d["parity"]["history_max_rel_diff"] < 1e-8
+    if "window_values" in d:                                 # round 3: value = median of consecutive windows of `steps` steps
+        import statistics
+        assert len(d["window_values"]) >= 5 and abs(statistics.median(d["window_values"]) - d["value"]) < 1e-6 * d["value"]
+        assert max(d["window_values"]) - min(d["window_values"]) < 0.05 * d["value"]
+        for key in ("roofline_mypre_a_gs", "secondary_configs", "roofline_hdg_like"):
+            assert key in d and "error" not in (d[key] or {}), key
+        m = d["roofline_mypre_a_gs"]
+        assert m["valid"] and 0.3 < m["sweep_call"]["frac"] < 1.0 and 0.3 < m["auxiliary_space_term"]["frac"] < 1.0
+        sec = d["secondary_configs"]
+        assert sec["cfg2"]["minres"]["us_per_iteration"] < 60 and sec["cfg3"]["bpcg_v2"]["us_per_iteration"] < 150
+        assert "spmv_A_plain_in_loop_cache_state" in d["hbm_GBs"]
 
 
 def test_rehearsal_reads_the_markers_of_the_child(tmp_path, monkeypatch):
