@@ -67,6 +67,7 @@ __global__ __launch_bounds__(kBlock) void p2p_wait_copy_kernel(WaitArgs a) {
       __builtin_amdgcn_s_sleep(1);
     }
   }
+  __threadfence_system();                                         // the flag before the data it announces
   __syncthreads();
   const int64_t stride = int64_t(gridDim.x) * kBlock;
   for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < a.n; i += stride)
