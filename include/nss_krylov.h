@@ -496,13 +496,22 @@ NSS_API int nss_dist_aux_apply_f64(nss_dist_aux_t h, double scale, const double*
  * nss_p2p_allreduce_f64 (one double, rank-ordered sum, the same bits on every rank) and nss_p2p_exchange are the
  * stand-alone forms of what the partitioned loop does with `nss_bpcg2_t.p2p` set (tests). */
 typedef struct nss_p2p_s* nss_p2p_t;
-NSS_API int nss_p2p_blob_bytes(int32_t nranks, int64_t* bytes);
-NSS_API int nss_p2p_create(int32_t nranks, int32_t rank, const nss_halo_t* halo, int32_t n_owned, nss_p2p_t* out, void* h_blob);
+NSS_API int nss_p2p_blob_bytes(int32_t nranks, int32_t nhalo, int64_t* bytes);
+/* `halos`: HOST array of nhalo (1 .. 4) descriptors, one per operand LAYOUT the loops exchange (BPCG v2: t1; MINRES /
+ * BPCG v1: A's operand and B^T's operand), n_owned[c] = owned entries of layout c.  A later exchange finds its layout by
+ * the identity of the descriptor's host tables (h_send_off / h_recv_off): pass copies of these descriptors with only
+ * `ext` changed. */
+NSS_API int nss_p2p_create(int32_t nranks, int32_t rank, int32_t nhalo, const nss_halo_t* const* halos,
+                           const int32_t* n_owned, nss_p2p_t* out, void* h_blob);
 NSS_API int nss_p2p_connect(nss_p2p_t p, const void* h_blobs);
 NSS_API int nss_p2p_destroy(nss_p2p_t p);
 NSS_API int nss_p2p_allreduce_f64(nss_p2p_t p, const double* src, double* dst, nss_stream_t stream);
-NSS_API int nss_p2p_exchange(nss_p2p_t p, const nss_halo_t* halo, int32_t n_owned, nss_stream_t stream);
+NSS_API int nss_p2p_exchange(nss_p2p_t p, const nss_halo_t* halo, nss_stream_t stream);
 NSS_API int nss_p2p_error(nss_p2p_t p, int32_t* timed_out, nss_stream_t stream);
+/* every exchange and every one-double all-reduce of the native loops that take this dist handle (MINRES, BPCG v1, the
+ * eight-phase BPCG v2 plan) goes through the mailbox transport instead of RCCL (NULL detaches); BPCG v2 on the compact
+ * plan fuses its all-reduces into the sum kernels through nss_bpcg2_t.p2p instead */
+NSS_API int nss_dist_attach_p2p(nss_dist_t d, nss_p2p_t p);
 
 /* Per-phase device times of the native partitioned loop: between _begin and _end every iteration issued by
  * nss_bpcg2_iterate_dist (up to max_iterations) records 9 HIP events on the compute stream; _end waits for them

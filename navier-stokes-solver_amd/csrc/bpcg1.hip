@@ -359,7 +359,7 @@ int nss_bpcg1_iterate_dist(const nss_bpcg1_t* s, nss_dist_t d, const nss_halo_t*
     bpcg1_check(s);
     NSS_REQUIRE(d != nullptr && s->local_sums, "bpcg1_iterate_dist: needs a dist handle and a row-partitioned state");
     NSS_REQUIRE(halo_u && halo_p, "bpcg1_iterate_dist: NULL halo");
-    NSS_REQUIRE(d->nranks == 1 || d->comm != nullptr, "bpcg1_iterate_dist: multi-rank run without a communicator");
+    NSS_REQUIRE(d->nranks == 1 || d->comm != nullptr || d->p2p != nullptr, "bpcg1_iterate_dist: multi-rank run without a communicator");
     nss_halo_t h0 = *halo_u, h1 = *halo_p;
     h0.ext = s->d[0];
     h1.ext = s->d[1];

@@ -22,6 +22,9 @@ struct nss_dist_s {
   // per-phase profile of the native loop (nss_dist_profile_begin / _end): kProfMarks events per iteration
   std::vector<hipEvent_t> prof_ev;
   int prof_cap = 0, prof_iters = 0;
+  // mailbox transport (nss_dist_attach_p2p): exchange() and the one-double all-reduces of every native partitioned
+  // loop go through peer-mapped memory instead of RCCL (csrc/p2p.h)
+  struct nss_p2p_s* p2p = nullptr;
 };
 
 

@@ -80,6 +80,11 @@ void exchange(const nss_dist_s& d, const nss_halo_t& h, hipStream_t st, const ns
       if (!p->direct) gather_launch(p->n_pack, p->send_idx, p->ext, p->sendbuf, st);
     }
   if (!any || d.nranks <= 1) return;
+  if (d.p2p) {                       // mailbox transport: put + wait/copy per operand layout
+    for (const nss_halo_t* p : hs)
+      if (p && (p->n_send > 0 || p->n_recv > 0)) p2p_exchange(*d.p2p, *p, nullptr, st);
+    return;
+  }
   nccl_check(d, d.GroupStart(), "ncclGroupStart");
   for (const nss_halo_t* p : hs) {
     if (!p) continue;
@@ -96,6 +101,11 @@ void exchange(const nss_dist_s& d, const nss_halo_t& h, hipStream_t st, const ns
 
 // dst[0 .. n) = sum over the ranks of src[0 .. n) (device pointers; out of place or in place)
 void allreduce_sum(const nss_dist_s& d, const double* src, double* dst, size_t n, hipStream_t st) {
+  if (d.p2p && d.nranks > 1) {
+    if (n != 1) throw Error("dist: the mailbox transport all-reduces single doubles (vectors need the RCCL communicator)");
+    p2p_allreduce(*d.p2p, src, dst, st);
+    return;
+  }
   if (d.comm == nullptr) {
     if (d.nranks > 1) throw Error("dist: no communicator");
     if (src != dst) NSS_HIP(hipMemcpyAsync(dst, src, sizeof(double) * n, hipMemcpyDeviceToDevice, st));
@@ -158,8 +168,12 @@ static void allreduce_slot(const nss_bpcg2_t& s, const nss_dist_s& d, int slot, 
     }
     return;
   }
-  if (d.comm == nullptr) throw Error("dist: no communicator");
   const double* local = s.local_sums ? s.scal + slot + S_LOCAL_OFFSET : s.scal + slot;
+  if (d.p2p) {
+    p2p_allreduce(*d.p2p, local, s.scal + slot, cs);
+    return;
+  }
+  if (d.comm == nullptr) throw Error("dist: no communicator");
   nccl_check(d, d.AllReduce(local, s.scal + slot, 1, kNcclFloat64, kNcclSum, d.comm, cs), "ncclAllReduce");
 }
 
@@ -328,6 +342,14 @@ int nss_dist_create(void* nccl_comm, int32_t nranks, int32_t rank, nss_dist_t* o
   });
 }
 
+int nss_dist_attach_p2p(nss_dist_t d, nss_p2p_t p) {
+  return guarded([&] {
+    NSS_REQUIRE(d != nullptr, "dist_attach_p2p: NULL dist handle");
+    NSS_REQUIRE(!p || (p->nranks == d->nranks && p->rank == d->rank), "dist_attach_p2p: rank / size mismatch");
+    d->p2p = p;
+  });
+}
+
 int nss_dist_destroy(nss_dist_t d) {
   return guarded([&] {
     if (!d) return;
@@ -377,7 +399,7 @@ int nss_bpcg2_iterate_dist(const nss_bpcg2_t* s, nss_dist_t d, const nss_halo_t*
   return guarded([&] {
     bpcg2_check_state(s);
     NSS_REQUIRE(d != nullptr, "iterate_dist: NULL dist handle");
-    NSS_REQUIRE(d->nranks == 1 || d->comm != nullptr || s->p2p != nullptr, "iterate_dist: multi-rank run without a communicator");
+    NSS_REQUIRE(d->nranks == 1 || d->comm != nullptr || s->p2p != nullptr || d->p2p != nullptr, "iterate_dist: multi-rank run without a communicator");
     if (s->dist_compact) {
       // Compact plan: C1 (books of the previous iteration from the ALL-REDUCED <w, d>, rows of B^T, ghost copies of
       // s0) . preA . exchange of t1 . C23 (rows of A; owned and ghost rows of B on t1 - s0) . sum . all-reduce .
@@ -393,7 +415,7 @@ int nss_bpcg2_iterate_dist(const nss_bpcg2_t* s, nss_dist_t d, const nss_halo_t*
         mark(0);
         bpcg2_cphase(*s, NSS_BPCG2C_C1, it, cs);           // + preA
         mark(1);
-        if (s->p2p) p2p_exchange(*s->p2p, *halo_t1, s->n_u, s->ctrl, cs);   // put + wait/copy through the landing zones
+        if (s->p2p) p2p_exchange(*s->p2p, *halo_t1, s->ctrl, cs);   // put + wait/copy through the landing zone
         else exchange(*d, *halo_t1, cs);
         mark(2);
         bpcg2_cphase(*s, NSS_BPCG2C_C23, it, cs);

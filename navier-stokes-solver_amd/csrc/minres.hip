@@ -580,7 +580,7 @@ int nss_minres_iterate_dist(const nss_minres_t* s, nss_dist_t d, const nss_halo_
     minres_check(s);
     NSS_REQUIRE(d != nullptr && s->local_sums, "minres_iterate_dist: needs a dist handle and a row-partitioned state");
     NSS_REQUIRE(k_begin >= 1, "minres_iterate_dist: iterations are counted from 1");
-    NSS_REQUIRE(d->nranks == 1 || d->comm != nullptr, "minres_iterate_dist: multi-rank run without a communicator");
+    NSS_REQUIRE(d->nranks == 1 || d->comm != nullptr || d->p2p != nullptr, "minres_iterate_dist: multi-rank run without a communicator");
     // the halo descriptors are checked against ring slot 0; slot 1 has the same layout
     nss_halo_t h0 = *halo_z0, h1 = *halo_z1;
     h0.ext = s->z[0][0];

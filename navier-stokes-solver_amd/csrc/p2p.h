@@ -15,8 +15,11 @@
 //                              owned entries of the operand.
 // Every spin is bounded (wall clock): a peer that never arrives stops the loop with an error code instead of hanging
 // the GPU.  Two mailbox parities suffice: a rank cannot finish all-reduce q + 1 before every rank has entered it, i.e.
-// left all-reduce q.  One landing zone suffices for the same reason (a put of iteration it + 1 follows two all-reduces
-// that the receiver only enters after its wait + copy of iteration it).
+// left all-reduce q.  Every landing zone exists TWICE, used alternately by the exchanges of its layout: a neighbour may
+// run one exchange ahead (BPCG v1 and MINRES exchange twice in a row without an all-reduce in between: its put of
+// exchange e + 1 can arrive before this rank has copied exchange e out -- found by running the native BPCG v1 loop with
+// two ranks), never two: its put of exchange e + 2 follows its wait for e + 1, i.e. this rank's put of e + 1, which this
+// rank's stream orders behind its copy of e.
 #pragma once
 
 #include "nss_common.h"
@@ -27,6 +30,7 @@ namespace nss {
 
 constexpr int kP2pMaxRanks = 16;
 constexpr int kP2pMaxSegments = 8;
+constexpr int kP2pMaxChannels = 4;    // operand layouts one handle serves (BPCG v2: t1; MINRES / BPCG v1: A's and B^T's operand)
 constexpr unsigned long long kP2pTimeoutTicks = 300000000ull;   // wall_clock64 runs at 100 MHz: 3 s
 
 struct P2pView {                      // what the kernels need (passed by value)
@@ -89,22 +93,40 @@ struct nss_p2p_s {
   char* region = nullptr;                    // own fine-grained region
   size_t region_bytes = 0;
   unsigned long long* mail = nullptr;        // region + 0
-  unsigned long long* flags = nullptr;       // [nranks] halo arrival flags (sequence numbers), one per source rank
-  double* landing = nullptr;
-  int64_t landing_doubles = 0;
   std::vector<char*> peer_region;            // mapped peers (own: region)
   unsigned long long** d_peer_mail = nullptr;   // device array [nranks]
   int32_t* d_error = nullptr;
   int32_t* d_ticket = nullptr;               // [kP2pMaxSegments] workgroup tickets of the put kernel
   uint32_t seq = 0;                          // host counter of collectives issued
-  // the halo this handle serves (bound once): own receive table and, after connect, where the peers want our data
-  std::vector<int64_t> recv_off, recv_cnt;   // per source rank: offset into the landing zone / count (0: none)
-  std::vector<int64_t> peer_land_off;        // per destination rank: offset into ITS landing zone for our segment
+  // One CHANNEL per operand layout this handle serves (bound at creation): its arrival flags (one per source rank),
+  // its landing zone, the own receive table and, after connect, where the peers want our segments.  A halo descriptor
+  // finds its channel by the identity of its host tables (h_send_off / h_recv_off): the loops pass copies of ONE
+  // descriptor per layout with only `ext` changed.
+  struct Channel {
+    const void *key_send = nullptr, *key_recv = nullptr;
+    int32_t n_owned = 0;
+    size_t flags_off = 0, landing_off = 0;   // byte offsets inside the own region (flags_off is the same in every region)
+    int64_t landing_doubles = 0;
+    size_t zone_bytes = 0;                   // distance of the two copies of the own landing zone
+    mutable uint32_t count = 0;              // exchanges of this layout issued so far (host; the same on every rank)
+    std::vector<int64_t> peer_zone_bytes;    // per destination rank: the distance of ITS two zones
+    std::vector<int64_t> recv_off, recv_cnt; // per source rank: offset into the landing zone / count (0: none)
+    std::vector<int64_t> peer_land_off;      // per destination rank: BYTE offset inside ITS region where our segment goes
+  };
+  std::vector<Channel> channels;
   bool connected = false;
+  const Channel* find(const nss_halo_t& h) const {
+    for (const Channel& c : channels)
+      if (c.key_send == (const void*)h.h_send_off && c.key_recv == (const void*)h.h_recv_off) return &c;
+    return nullptr;
+  }
   nss::P2pView view(uint32_t s) const { return nss::P2pView{mail, d_peer_mail, nranks, rank, s, d_error}; }
 };
 
 namespace nss {
-// halo exchange of `h` (direct sends only) through the landing zones: put + wait/copy on stream `st`
-void p2p_exchange(nss_p2p_s& p, const nss_halo_t& h, int32_t n_owned, const int32_t* done, hipStream_t st);
+// halo exchange of `h` (direct sends only; one of the layouts the handle was created for) through its landing zone:
+// put + wait/copy on stream `st`
+void p2p_exchange(nss_p2p_s& p, const nss_halo_t& h, const int32_t* done, hipStream_t st);
+// dst[0] = sum over the ranks of src[0], the ranks' values added in rank order (one small launch)
+void p2p_allreduce(nss_p2p_s& p, const double* src, double* dst, hipStream_t st);
 }  // namespace nss

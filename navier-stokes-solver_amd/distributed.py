@@ -185,31 +185,40 @@ class TorchComm:
 
 
 class MailboxTransport:
-    """The mailbox transport of the native partitioned loop (csrc/p2p.h, `nss_p2p_*`): every rank owns a small
-    fine-grained region -- all-reduce mailbox, halo arrival flags, a landing zone for the ghosts of ONE operand layout --
-    that its peers map through HIP IPC and write into with plain remote stores over xGMI.  Set-up: create the region
-    for `halo` (the operand's `nss_halo_t`), gather everybody's blob (IPC handle + where each peer's segment is wanted)
-    over the set-up communicator, map the peers.  At most 16 ranks."""
+    """The mailbox transport of the native partitioned loops (csrc/p2p.h, `nss_p2p_*`): every rank owns a small
+    fine-grained region -- all-reduce mailbox, and per operand LAYOUT the loop exchanges its arrival flags and a landing
+    zone for the ghosts -- that its peers map through HIP IPC and write into with plain remote stores over xGMI.
+    `halos`: list of (`nss_halo_t`, owned entries), one per layout (BPCG v2: t1; MINRES / BPCG v1: A's operand and B^T's
+    operand); the loops may pass copies of these descriptors with only `ext` changed.  Set-up: create the region,
+    gather everybody's blob (IPC handle + where each peer's segments are wanted) over the set-up communicator, map the
+    peers.  At most 16 ranks."""
 
-    def __init__(self, comm, engine, halo, n_owned):
+    def __init__(self, comm, engine, halos):
         import ctypes as C
         self.engine, self.comm = engine, comm
+        self._halos = [h for h, _ in halos]
+        nh = len(halos)
         nbytes = C.c_int64()
-        engine._check(engine.lib.nss_p2p_blob_bytes(comm.size, C.byref(nbytes)))
+        engine._check(engine.lib.nss_p2p_blob_bytes(comm.size, nh, C.byref(nbytes)))
         blob = C.create_string_buffer(nbytes.value)
         self.handle = C.c_void_p()
-        self._halo = halo
-        engine._check(engine.lib.nss_p2p_create(comm.size, comm.rank, C.byref(halo), int(n_owned), C.byref(self.handle), blob))
+        ptrs = (C.c_void_p * nh)(*[C.addressof(h) for h in self._halos])
+        owned = (C.c_int32 * nh)(*[int(n) for _, n in halos])
+        engine._check(engine.lib.nss_p2p_create(comm.size, comm.rank, nh, ptrs, owned, C.byref(self.handle), blob))
         blobs = comm.gather_objects(bytes(blob.raw)) if comm.size > 1 else [bytes(blob.raw)]
         engine._check(engine.lib.nss_p2p_connect(self.handle, b"".join(blobs)))
+
+    def attach(self, dist_handle):
+        """Route every exchange / one-double all-reduce of the native loops that take `dist_handle` through this transport."""
+        self.engine._check(self.engine.lib.nss_dist_attach_p2p(dist_handle, self.handle))
 
     def allreduce(self, src, dst):
         """dst[0] = sum over the ranks of src[0] (device buffers), the ranks' values added in rank order."""
         self.engine._check(self.engine.lib.nss_p2p_allreduce_f64(self.handle, src.data_ptr(), dst.data_ptr(), self.engine.stream))
 
-    def exchange(self, n_owned):
+    def exchange(self, which=0):
         import ctypes as C
-        self.engine._check(self.engine.lib.nss_p2p_exchange(self.handle, C.byref(self._halo), int(n_owned), self.engine.stream))
+        self.engine._check(self.engine.lib.nss_p2p_exchange(self.handle, C.byref(self._halos[which]), self.engine.stream))
 
     def timed_out(self):
         import ctypes as C
@@ -1033,7 +1042,7 @@ class DistributedBpcg2:
         eng._check(eng.lib.nss_dist_create(None, self.comm.size, self.comm.rank, C.byref(handle)))
         halo = self.ops.A.native_halo(self.t1, (0, 0))
         self.native = (handle, (None, halo, None))
-        self.mailbox = MailboxTransport(self.comm, eng, halo, self.ops.n_u)
+        self.mailbox = MailboxTransport(self.comm, eng, [(halo, self.ops.n_u)])
         self.loop.state.p2p = self.mailbox.handle
         self.loop.keep.append(self.mailbox)
 
@@ -1218,6 +1227,7 @@ class Bpcg1DistLoop:
     every rank takes the same stop decision."""
 
     NATIVE = True        # False: keep the host-driven schedule even over an RCCL communicator (tests)
+    TRANSPORT = None     # "mailbox": the native loop over the mailbox transport (csrc/p2p.h) with any set-up communicator
 
     @classmethod
     def try_create(cls, a_matrix, b_matrix, c_matrix, pre_a, pre_s, k, vecs, native=None):
@@ -1252,8 +1262,16 @@ class Bpcg1DistLoop:
         self.loop.state.local_sums = 1
         self.loop.enqueue = self.enqueue
         self.native = None
+        self.mailbox = None
         comm_handle = getattr(self.comm, "comm", None)        # RcclComm: an ncclComm_t
-        if native and comm_handle is not None and hasattr(eng.lib, "nss_bpcg1_iterate_dist"):
+        if self.TRANSPORT == "mailbox" and hasattr(eng.lib, "nss_p2p_create"):
+            handle = C.c_void_p()
+            eng._check(eng.lib.nss_dist_create(None, self.comm.size, self.comm.rank, C.byref(handle)))
+            halos = (A.native_halo(self.d0, (0, 0)), BT.native_halo(self.d1, (0, 0)))
+            self.mailbox = MailboxTransport(self.comm, eng, [(halos[0], A.n_cols_owned), (halos[1], BT.n_cols_owned)])
+            self.mailbox.attach(handle)
+            self.native = (handle, halos)
+        elif native and comm_handle is not None and hasattr(eng.lib, "nss_bpcg1_iterate_dist"):
             handle = C.c_void_p()
             eng._check(eng.lib.nss_dist_create(comm_handle, self.comm.size, self.comm.rank, C.byref(handle)))
             self.native = (handle, (A.native_halo(self.d0), BT.native_halo(self.d1)))
@@ -1262,6 +1280,9 @@ class Bpcg1DistLoop:
         if getattr(self, "native", None) is not None:
             self.engine.lib.nss_dist_destroy(self.native[0])
             self.native = None
+        if getattr(self, "mailbox", None) is not None:
+            self.mailbox.close()
+            self.mailbox = None
 
     def __del__(self):
         try:
@@ -1309,7 +1330,8 @@ class DistributedMinres:
     device phases (`nss_minres_phases`).  The scalars are identical on every rank, so every rank takes the
     same stop decision."""
 
-    def __init__(self, sysm, f, g, blocks, dist, engine=None, comm=None, native=True, sol=None, initialize=True):
+    def __init__(self, sysm, f, g, blocks, dist, engine=None, comm=None, native=True, sol=None, initialize=True,
+                 transport=None):
         import ctypes as C
         from math import sqrt
         from hipla import BlockVector
@@ -1357,8 +1379,16 @@ class DistributedMinres:
         self.loop.state.local_sums = 1
         self.z_ring = z_ring
         self.native = None
+        self.mailbox = None
         comm_handle = getattr(self.comm, "comm", None)        # RcclComm: an ncclComm_t
-        if native and comm_handle is not None and hasattr(eng.lib, "nss_minres_iterate_dist"):
+        if transport == "mailbox":        # the native loop over the mailbox transport (csrc/p2p.h), any set-up communicator
+            handle = C.c_void_p()
+            eng._check(eng.lib.nss_dist_create(None, self.comm.size, self.comm.rank, C.byref(handle)))
+            halos = (ops.A.native_halo(z_ring[0][0], (0, 0)), ops.BT.native_halo(z_ring[0][1], (0, 0)))
+            self.mailbox = MailboxTransport(self.comm, eng, [(halos[0], ops.n_u), (halos[1], ops.n_p)])
+            self.mailbox.attach(handle)
+            self.native = (handle, halos)
+        elif native and comm_handle is not None and hasattr(eng.lib, "nss_minres_iterate_dist"):
             handle = C.c_void_p()
             eng._check(eng.lib.nss_dist_create(comm_handle, self.comm.size, self.comm.rank, C.byref(handle)))
             self.native = (handle, (ops.A.native_halo(z_ring[0][0]), ops.BT.native_halo(z_ring[0][1])))
@@ -1367,6 +1397,9 @@ class DistributedMinres:
         if getattr(self, "native", None) is not None:
             self.engine.lib.nss_dist_destroy(self.native[0])
             self.native = None
+        if getattr(self, "mailbox", None) is not None:
+            self.mailbox.close()
+            self.mailbox = None
 
     def __del__(self):
         try:

@@ -51,12 +51,13 @@ def _signatures():
         "nss_csr_plan_for_pairs": (C.c_int, [vp, c_i32_p]),
         "nss_csr_pair_staged": (C.c_int, [vp, c_i32_p]),
         "nss_csr_pair_mode": (C.c_int, [i32]),
-        "nss_p2p_blob_bytes": (C.c_int, [i32, c_i64_p]),
-        "nss_p2p_create": (C.c_int, [i32, i32, vp, i32, C.POINTER(vp), vp]),
+        "nss_p2p_blob_bytes": (C.c_int, [i32, i32, c_i64_p]),
+        "nss_p2p_create": (C.c_int, [i32, i32, i32, vp, vp, C.POINTER(vp), vp]),
+        "nss_dist_attach_p2p": (C.c_int, [vp, vp]),
         "nss_p2p_connect": (C.c_int, [vp, vp]),
         "nss_p2p_destroy": (C.c_int, [vp]),
         "nss_p2p_allreduce_f64": (C.c_int, [vp, vp, vp, vp]),
-        "nss_p2p_exchange": (C.c_int, [vp, vp, i32, vp]),
+        "nss_p2p_exchange": (C.c_int, [vp, vp, vp]),
         "nss_p2p_error": (C.c_int, [vp, c_i32_p, vp]),
         "nss_dist_aux_create": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.POINTER(vp)]),
         "nss_dist_aux_destroy": (C.c_int, [vp]),

@@ -112,7 +112,7 @@ def run(rank, world, mode, init_file, out_dir, dim, n, pre, tol, maxsteps):
         from distributed import MailboxTransport
         import torch as _torch
         probe = ops.A.operand()
-        mb = MailboxTransport(comm, eng, ops.A.native_halo(probe, (0, 0)), ops.n_u)
+        mb = MailboxTransport(comm, eng, [(ops.A.native_halo(probe, (0, 0)), ops.n_u)])
         vals = []
         for rep in range(6):
             src = _torch.tensor([np.sin(1.0 + rank + 10.0 * rep) * 1e3], dtype=_torch.float64, device=eng.device)
@@ -123,7 +123,7 @@ def run(rank, world, mode, init_file, out_dir, dim, n, pre, tol, maxsteps):
         xg = np.random.default_rng(21).standard_normal(sysm.n_u)
         for rep in range(3):
             probe.set_from((rep + 1.0) * xg[us])
-            mb.exchange(ops.n_u)
+            mb.exchange()
             _torch.cuda.synchronize()
             got = eng.to_host(probe.ext)[ops.n_u:]
             res["mailbox_halo_err%d" % rep] = float(np.max(np.abs(got - (rep + 1.0) * xg[ops.A.plan.ghosts]))) if got.size else 0.0
@@ -144,6 +144,14 @@ def run(rank, world, mode, init_file, out_dir, dim, n, pre, tol, maxsteps):
         um, errs, rel = mr.solve(tol=tol, maxsteps=maxsteps, poll_every=8)
         res["minres_errors"], res["minres_rel"] = np.array(errs), int(rel)
         res["minres_u"], res["minres_p"] = um[0].numpy(), um[1].numpy()
+        #      ... the NATIVE C loop (nss_minres_iterate_dist) over the mailbox transport: grouped exchange of both operands
+        #      (ring slots swapped per iteration), two one-double all-reduces -- with more than one rank
+        mrm = DistributedMinres(sysm, f, g, blocks, dist, eng, comm=comm, transport="mailbox")
+        assert mrm.native is not None and mrm.mailbox is not None
+        umm, errsm, relm = mrm.solve(tol=tol, maxsteps=maxsteps, poll_every=16)
+        res["minres_mb_errors"], res["minres_mb_rel"], res["minres_mb_u"] = np.array(errsm), int(relm), umm[0].numpy()
+        res["minres_mb_timeout"] = int(mrm.mailbox.timed_out())
+        mrm.close()
         # ---- fused row-partitioned BPCG v1 behind the reference's entry point (distributed.Bpcg1DistLoop) ----
         from bramble_pasciak_cg import bramble_pasciak_cg
         import distributed
@@ -163,6 +171,27 @@ def run(rank, world, mode, init_file, out_dir, dim, n, pre, tol, maxsteps):
         res["bpcg1_fused"] = int(created == [True])
         res["bpcg1_errors"] = np.array(errs1)
         res["bpcg1_u"], res["bpcg1_p"] = x1[0].numpy(), x1[1].numpy()
+        #      ... and its NATIVE C loop (nss_bpcg1_iterate_dist) over the mailbox transport with more than one rank
+        distributed.Bpcg1DistLoop.TRANSPORT = "mailbox"
+        loops = []
+
+        def spy2(cls, *a, **k):
+            loops.append(orig(cls, *a, **k))
+            return loops[-1]
+
+        distributed.Bpcg1DistLoop.try_create = classmethod(spy2)
+        try:
+            fv, gv = ops.vectors(f, g)
+            with contextlib.redirect_stdout(io.StringIO()):
+                x1m, errs1m = bramble_pasciak_cg(ops.A, ops.B, None, ops.preA, ops.preM, fv, gv, tolerance=tol,
+                                                 max_steps=maxsteps, print_rates=False)
+            assert loops and loops[-1] is not None and loops[-1].mailbox is not None and loops[-1].native is not None
+            res["bpcg1_mb_errors"], res["bpcg1_mb_u"] = np.array(errs1m), x1m[0].numpy()
+            res["bpcg1_mb_timeout"] = int(loops[-1].mailbox.timed_out())
+            loops[-1].close()
+        finally:
+            distributed.Bpcg1DistLoop.TRANSPORT = None
+            distributed.Bpcg1DistLoop.try_create = classmethod(orig)
     # ---- distributed AMG (replicated coarse levels) as preA, BPCG v2 through the protocol ------------
     if pre == "bjac":
         from distributed import DistributedAMG

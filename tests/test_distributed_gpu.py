@@ -134,6 +134,17 @@ def test_fused_distributed_loop_matches_single_gpu(hip_engine, world, dim, n, pr
         assert int(d["minres_rel"]) == 1
     um = np.concatenate([d["minres_u"] for d in ranks])
     assert np.linalg.norm(um - mref["u"]) < 1e-5 * np.linalg.norm(mref["u"])
+    # ... and the native C loop over the mailbox transport (the first time nss_minres_iterate_dist runs with > 1 rank)
+    for d in ranks:
+        assert int(d["minres_mb_timeout"]) == 0 and int(d["minres_mb_rel"]) == 1
+        np.testing.assert_array_equal(d["minres_mb_errors"], ranks[0]["minres_mb_errors"])
+        w = min(40, len(d["minres_errors"]), len(d["minres_mb_errors"]))
+        np.testing.assert_allclose(d["minres_mb_errors"][:w], d["minres_errors"][:w], rtol=1e-9)
+        assert abs(len(d["minres_mb_errors"]) - len(d["minres_errors"])) <= max(3, int(0.03 * len(d["minres_errors"])))
+        if world == 2:
+            np.testing.assert_array_equal(d["minres_mb_errors"], d["minres_errors"])
+    umm = np.concatenate([d["minres_mb_u"] for d in ranks])
+    assert np.linalg.norm(umm - mref["u"]) < 1e-5 * np.linalg.norm(mref["u"])
     # fused row-partitioned BPCG v1 (behind bramble_pasciak_cg on distributed operands) against the single-GPU loop
     vref = single_gpu_bpcg1(s, pre, tol, maxsteps)
     for d in ranks:
@@ -144,6 +155,16 @@ def test_fused_distributed_loop_matches_single_gpu(hip_engine, world, dim, n, pr
         assert abs(len(d["bpcg1_errors"]) - len(vref["errors"])) <= max(3, int(0.03 * len(vref["errors"])))
     u1 = np.concatenate([d["bpcg1_u"] for d in ranks])
     assert np.linalg.norm(u1 - vref["u"]) < 1e-5 * np.linalg.norm(vref["u"])
+    for d in ranks:                       # nss_bpcg1_iterate_dist over the mailbox transport, > 1 rank
+        assert int(d["bpcg1_mb_timeout"]) == 0
+        np.testing.assert_array_equal(d["bpcg1_mb_errors"], ranks[0]["bpcg1_mb_errors"])
+        w = min(30, len(d["bpcg1_errors"]), len(d["bpcg1_mb_errors"]))
+        np.testing.assert_allclose(d["bpcg1_mb_errors"][:w], d["bpcg1_errors"][:w], rtol=1e-9)
+        assert abs(len(d["bpcg1_mb_errors"]) - len(d["bpcg1_errors"])) <= max(3, int(0.03 * len(d["bpcg1_errors"])))
+        if world == 2:
+            np.testing.assert_array_equal(d["bpcg1_mb_errors"], d["bpcg1_errors"])
+    u1m = np.concatenate([d["bpcg1_mb_u"] for d in ranks])
+    assert np.linalg.norm(u1m - vref["u"]) < 1e-5 * np.linalg.norm(vref["u"])
     if pre == "bjac":
         # DistributedAMG (finest level on the slabs, coarse levels replicated on every rank) on the
         # product engine: same hierarchy, same V-cycle and same BPCG history as one GPU
