@@ -578,11 +578,26 @@ typedef struct nss_lanczos_s {
   int32_t n;
 } nss_lanczos_t;
 NSS_API int nss_lanczos_workspace(const nss_lanczos_t* s, int64_t* partials_a, int64_t* partials_b);
+/* out[i] = the start vector's entry of global index offset + i (hipla/eigen.py::lanczos_start_values: a hash of the
+ * index, so a row-partitioned run fills its slice of the same vector) -- formed on the device instead of uploaded */
+NSS_API int nss_lanczos_start_values(int64_t offset, int64_t n, double* out, nss_stream_t stream);
 /* z[0] = preA v[0], gamma_0 = sqrt|<z[0], v[0]>|; clears scal / ctrl */
 NSS_API int nss_lanczos_start(const nss_lanczos_t* s, nss_stream_t stream);
 /* enqueue steps j_begin .. j_end - 1: no host synchronisation */
 NSS_API int nss_lanczos_iterate(const nss_lanczos_t* s, int32_t j_begin, int32_t j_end, nss_stream_t stream);
 NSS_API int nss_lanczos_poll(const nss_lanczos_t* s, int32_t* stop, int32_t* j_stop, int32_t* last_j, nss_stream_t stream);
+/* Small systems run a step in two launches (the rows of A; one kernel that sums both sets of dot partials in every
+ * workgroup, keeps the books and applies the update + block Jacobi + dot) when preA is a block Jacobi over runs of
+ * consecutive dofs and a sum has <= 1024 partials -- a step is launch-bound there.  Process-wide override for tests
+ * and A/B runs: -1 by size (default), 0 never, 1 whenever the operands allow. */
+NSS_API int nss_lanczos_fold_mode(int32_t mode);
+/* HOST function (no device work): smallest and largest eigenvalue of the symmetric tridiagonal matrix with diagonal
+ * diag[0..n) and off-diagonal off[0..n-1) -- the convergence check of the Ritz values every `check_every` steps
+ * (Laguerre's iteration from outside the spectrum, verified by Sturm counts, bisection as the fallback; absolute
+ * accuracy ~16 ulps of the matrix norm).  On entry *lo / *hi may hold starting points believed to lie below the
+ * smallest / above the largest eigenvalue (e.g. the previous check's values pushed outwards; NaN: none) -- used only
+ * when a Sturm count confirms them. */
+NSS_API int nss_tridiag_extremes(const double* diag, const double* off, int32_t n, double* lo, double* hi);
 
 /* ---- fused preconditioned MINRES ----------------------------------------------------------
  * Replaces the loop body of minres.py:96-144 for K = [[A, B^T], [B, 0]], C = diag(preA, preS)

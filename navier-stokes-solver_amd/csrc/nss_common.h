@@ -185,9 +185,10 @@ __device__ __forceinline__ double block_sum(double v, double* lds) {
 // THREADS = 1024 (the stand-alone sum kernel: one virtual lane per thread, shortest dependent chain) gives
 // the same bits as THREADS = 256 (inside a kernel's workgroup).
 constexpr int kSumLanes = 1024;
+struct SumPair { double a, b; };        // the totals of pa and of pb
 template <int THREADS = kBlock>
-__device__ __forceinline__ double fixed_sum_1024(const double* __restrict__ pa, int na, const double* __restrict__ pb,
-                                                 int nb, double* lds) {
+__device__ __forceinline__ SumPair fixed_sums_1024(const double* __restrict__ pa, int na, const double* __restrict__ pb,
+                                                   int nb, double* lds) {
   static_assert(THREADS % kWave == 0 && kSumLanes % THREADS == 0, "fixed_sum_1024: bad workgroup size");
   const int tid = threadIdx.x;
   __syncthreads();                      // protect lds reuse
@@ -229,7 +230,7 @@ __device__ __forceinline__ double fixed_sum_1024(const double* __restrict__ pa, 
       ta += lds[w];
       tb += lds[kSumLanes / kWave + w];
     }
-    return ta + tb;
+    return SumPair{ta, tb};
   }
 #pragma unroll
   for (int j = 0; j < kSumLanes / THREADS; ++j) {
@@ -267,7 +268,14 @@ __device__ __forceinline__ double fixed_sum_1024(const double* __restrict__ pa, 
     ta += lds[w];
     tb += lds[kSumLanes / kWave + w];
   }
-  return ta + tb;
+  return SumPair{ta, tb};
+}
+
+template <int THREADS = kBlock>
+__device__ __forceinline__ double fixed_sum_1024(const double* __restrict__ pa, int na, const double* __restrict__ pb,
+                                                 int nb, double* lds) {
+  const SumPair s = fixed_sums_1024<THREADS>(pa, na, pb, nb, lds);
+  return s.a + s.b;
 }
 
 // Library-wide scratch for reductions: partial sums (device) + one pinned host slot.

@@ -27,20 +27,8 @@ def _tridiag_eigs(diag, off):
     from scipy.linalg import eigvalsh_tridiagonal
     if len(diag) == 1:
         return np.array(diag, dtype=np.float64)
-    return eigvalsh_tridiagonal(np.asarray(diag), np.asarray(off[: len(diag) - 1]))
-
-
-def _tridiag_extremes(diag, off):
-    """Smallest and largest eigenvalue only (bisection, O(j) each): what the convergence check of a batch needs --
-    the full spectrum (O(j^2)) is computed once, at the end."""
-    from scipy.linalg import eigvalsh_tridiagonal
-    n = len(diag)
-    if n == 1:
-        return float(diag[0]), float(diag[0])
-    d, e = np.asarray(diag), np.asarray(off[: n - 1])
-    lo = eigvalsh_tridiagonal(d, e, select="i", select_range=(0, 0))[0]
-    hi = eigvalsh_tridiagonal(d, e, select="i", select_range=(n - 1, n - 1))[0]
-    return float(lo), float(hi)
+    # values only: the root-free QL/QR variant (dsterf) is 3x cheaper than scipy's default (dstemr) at a few hundred rows
+    return eigvalsh_tridiagonal(np.asarray(diag), np.asarray(off[: len(diag) - 1]), lapack_driver="sterf")
 
 
 class _LanczosState:
@@ -62,6 +50,13 @@ class _LanczosState:
 
 
 NATIVE = True          # tests flip this to force the protocol recurrence on native operands
+TRACE = None           # tools/lanczos_time.py: a list that receives (label, perf_counter) marks of the native run
+
+
+def _mark(label):
+    if TRACE is not None:
+        import time
+        TRACE.append((label, time.perf_counter()))
 
 
 def _native_lanczos(mat, pre, start, tol, maxsteps, check_every):
@@ -82,6 +77,7 @@ def _native_lanczos(mat, pre, start, tol, maxsteps, check_every):
     if pa is None or (pa["multiplicative"] and pa["bjac"].mat is not mat):
         return None
     n = mat.height
+    _mark("enter")
     st = _LanczosState.get()()
     st.A = mat.handle.ptr
     st.pre_diag = pa["diag"].d.data_ptr() if pa["diag"] is not None else None
@@ -102,6 +98,7 @@ def _native_lanczos(mat, pre, start, tol, maxsteps, check_every):
     ctrl = eng.torch.zeros(4, dtype=eng.torch.int32, device=eng.device)
     hist = eng.zeros(2 * maxsteps)
     st.scal, st.ctrl, st.hist = scal.data_ptr(), ctrl.data_ptr(), hist.data_ptr()
+    _mark("workspace")
     eng._check(eng.lib.nss_lanczos_start(C.byref(st), eng.stream))
     torch = eng.torch
     # The host looks at a batch while the device already runs the next one: after every batch the control words and
@@ -110,14 +107,16 @@ def _native_lanczos(mat, pre, start, tol, maxsteps, check_every):
     # batch b + 1 were wasted work -- the result does not see them.
     h_ctrl = [torch.empty(4, dtype=torch.int32).pin_memory() for _ in range(2)]
     h_hist = torch.empty(2 * maxsteps, dtype=torch.float64).pin_memory()
+    h_one = torch.ones(1, dtype=torch.int32).pin_memory()
     pending = []                                          # (end, event, slot)
 
-    # A batch is a multiple of `check_every` steps sized to ~1.5 ms of device work (launch-bound small systems: the
-    # host's per-batch work -- copies, event, the checks -- is then a small part); the checks of the steps
-    # check_every - 1, 2 check_every - 1, ... inside a batch are made in order afterwards, exactly as if the host had
-    # looked after each of them.
-    est_step = 25e-6 + (12.0 * mat.nnz + 80.0 * n) / 5e12
-    per_batch = check_every * max(1, min(8, int(round(1.5e-3 / est_step / check_every))))
+    # A batch is a multiple of `check_every` steps sized to ~0.25 ms of device work: long enough that the host's
+    # per-batch work (two copies, an event, the checks: ~50 us) hides behind it, short enough that the steps enqueued
+    # beyond the one that ends the run -- the rest of its batch and the speculative next one -- stay a small part
+    # (40-step batches wasted 70 of 360 steps at 6.7e4 rows).  The checks of the steps check_every - 1,
+    # 2 check_every - 1, ... inside a batch are made in order afterwards, exactly as if the host had looked after each.
+    est_step = 12e-6 + (12.0 * mat.nnz + 80.0 * n) / 5e12          # (two launches + the bytes of a step)
+    per_batch = check_every * max(1, min(8, int(round(0.25e-3 / est_step / check_every))))
     nbatch = [0]
 
     def enqueue(j0):
@@ -132,9 +131,26 @@ def _native_lanczos(mat, pre, start, tol, maxsteps, check_every):
         pending.append((j0, end, ev, slot))
         return end
 
+    # The check itself: the library's host routine (Laguerre from just outside the previous check's values, verified
+    # by Sturm counts: ~20 us at 300 rows where LAPACK's bisection through scipy took ~200 -- with a check every 5
+    # steps that was more host time than a small system's steps take on the device).
+    c_lo, c_hi = C.c_double(), C.c_double()
+    moved = [None, None]
+
+    def extremes(diag, off):
+        if moved[0] is None:
+            c_lo.value = c_hi.value = float("nan")
+        else:                                             # the extreme Ritz values only move outwards (interlacing)
+            pad = 1e-14 * abs(hi_prev)
+            c_lo.value, c_hi.value = lo_prev - 2.0 * moved[0] - pad, hi_prev + 2.0 * moved[1] + pad
+        eng._check(eng.lib.nss_tridiag_extremes(diag.ctypes.data, off.ctypes.data if len(off) else None, len(diag),
+                                                C.byref(c_lo), C.byref(c_hi)))
+        return c_lo.value, c_hi.value
+
     lo_prev = hi_prev = None
     diag = off = np.zeros(0)
     finished = False
+    _mark("pinned buffers")
     j = enqueue(0)
     while pending and not finished:
         if j < maxsteps:
@@ -152,14 +168,25 @@ def _native_lanczos(mat, pre, start, tol, maxsteps, check_every):
             checks.append(j_stop)                         # the breakdown step is looked at as well
         for jj in sorted(checks):
             diag, off = h[0::2][: jj + 1].copy(), h[1::2][: jj].copy()
-            lo, hi = _tridiag_extremes(diag, off)
+            lo, hi = extremes(diag, off)
             if (stop and jj == j_stop) or (lo_prev is not None and abs(lo - lo_prev) <= tol * abs(lo)
                                            and abs(hi - hi_prev) <= tol * abs(hi)):
                 finished = True
                 break
+            if lo_prev is not None:
+                moved[0], moved[1] = max(lo_prev - lo, 0.0), max(hi - hi_prev, 0.0)
             lo_prev, hi_prev = lo, hi
-    torch.cuda.synchronize()                              # (the speculative batch, before its buffers go away)
-    return _tridiag_eigs(list(diag), list(off))
+    # The steps still in flight are no longer needed: raise the stop flag from a second stream (every kernel then
+    # returns at once) and solve the final eigenproblem while they drain.
+    _mark("converged (%d steps, %d enqueued)" % (len(diag), j))
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        ctrl[0:1].copy_(h_one, non_blocking=True)
+    ritz = _tridiag_eigs(list(diag), list(off))
+    _mark("all Ritz values")
+    torch.cuda.synchronize()                              # (before the buffers of the speculative steps go away)
+    _mark("drained")
+    return ritz
 
 
 def lanczos_ritz(mat, pre, start, tol=1e-10, maxsteps=2000, check_every=5, dot=InnerProduct):
@@ -227,10 +254,18 @@ def EigenValues_Preconditioner(mat, pre, tol=1e-10, inner=InnerProduct):
     the same global start vector."""
     start = mat.CreateColVector()
     off = int(getattr(mat, "row_offset", 0))
+
+    def fill(c, off):
+        eng = getattr(c, "engine", None)
+        if hasattr(eng, "lanczos_start_values") and hasattr(c, "buf"):
+            eng.lanczos_start_values(c.buf[: len(c)], off)        # on the device: no host pass, no upload
+        else:
+            c.set_from(lanczos_start_values(off, len(c)))
+
     if isinstance(start, BlockVector):
         for c in start.components:
-            c.set_from(lanczos_start_values(off, len(c)))
+            fill(c, off)
             off += len(c)
     else:
-        start.set_from(lanczos_start_values(off, len(start)))
+        fill(start, off)
     return lanczos_ritz(mat, pre, start, tol=tol, dot=inner)

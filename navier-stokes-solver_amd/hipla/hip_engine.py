@@ -129,6 +129,9 @@ def _signatures():
         "nss_minres_phases": (C.c_int, [vp, i32, i32, i32, vp]),
         "nss_minres_iterate_dist": (C.c_int, [vp, vp, vp, vp, i32, i32, vp]),
         "nss_minres_fold_mode": (C.c_int, [i32]),
+        "nss_lanczos_fold_mode": (C.c_int, [i32]),
+        "nss_lanczos_start_values": (C.c_int, [i64, i64, vp, vp]),
+        "nss_tridiag_extremes": (C.c_int, [vp, vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "nss_minres_fuse_mode": (C.c_int, [i32]),
     }
 
@@ -162,6 +165,8 @@ def load_library(path=None):
         for name in ("nss_bpcg2_fold_mode", "nss_minres_fold_mode"):
             if hasattr(lib, name):
                 getattr(lib, name)(int(os.environ["NSS_FOLD_SUMS"]))
+    if os.environ.get("NSS_LANCZOS_FOLD") and hasattr(lib, "nss_lanczos_fold_mode"):      # measurements: -1 / 0 / 1
+        lib.nss_lanczos_fold_mode(int(os.environ["NSS_LANCZOS_FOLD"]))
     return lib
 
 
@@ -309,6 +314,10 @@ class HipEngine:
 
     def upload(self, arr, buf):
         buf.copy_(self.torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float64)))
+
+    def lanczos_start_values(self, buf, offset):
+        """buf[i] = hipla.eigen.lanczos_start_values(offset, len(buf))[i], formed on the device (the same bits)"""
+        self._check(self.lib.nss_lanczos_start_values(int(offset), buf.numel(), buf.data_ptr(), self.stream))
 
     def to_host(self, buf):
         return buf.detach().cpu().numpy()

@@ -77,3 +77,54 @@ def test_product_engine_fails_loudly_without_gpu():
             hipla.Vector(4)
     finally:
         hipla.set_engine(prev)
+
+
+def test_host_routine_tridiagonal_extremes_against_lapack(lib):
+    """`nss_tridiag_extremes` is host code (the convergence check of the device-resident Lanczos, hipla/eigen.py): the
+    smallest / largest eigenvalue of random tridiagonals, of the tridiagonals of a Lanczos run with converged copies
+    of its extreme Ritz values (clusters: Laguerre's iteration turns linear there), with and without starting hints,
+    with wrong hints (inside the spectrum: rejected by the Sturm count), sizes 1 ... 5000 (rescaling of the recurrences)."""
+    import numpy as np
+    from scipy.linalg import eigvalsh_tridiagonal
+
+    def extremes(d, e, hint_lo=float("nan"), hint_hi=float("nan")):
+        d, e = np.ascontiguousarray(d, dtype=np.float64), np.ascontiguousarray(e, dtype=np.float64)
+        lo, hi = ctypes.c_double(hint_lo), ctypes.c_double(hint_hi)
+        rc = lib.nss_tridiag_extremes(d.ctypes.data, e.ctypes.data if len(e) else None, len(d), ctypes.byref(lo), ctypes.byref(hi))
+        assert rc == 0, lib.nss_last_error()
+        return lo.value, hi.value
+
+    rng = np.random.default_rng(0)
+    for n in (1, 2, 3, 5, 17, 100, 290, 1000, 5000):
+        for trial in range(4):
+            d = rng.random(n) * 2 - (trial % 2)
+            e = rng.standard_normal(max(n - 1, 0)) * 10.0 ** rng.integers(-8, 1)
+            ref = eigvalsh_tridiagonal(d, e) if n > 1 else d
+            lo, hi = extremes(d, e)
+            scale = max(abs(ref).max(), 1e-300)
+            assert abs(lo - ref[0]) <= 1e-13 * scale and abs(hi - ref[-1]) <= 1e-13 * scale, (n, trial)
+            mid = 0.5 * (ref[0] + ref[-1])                    # hints inside the spectrum change nothing
+            assert extremes(d, e, mid, mid) == (lo, hi) or n == 1
+    lam = np.linspace(0.003, 1.9, 2000)
+    v = rng.standard_normal(len(lam))
+    v /= np.linalg.norm(v)
+    v_old, beta, ds, es = np.zeros_like(v), 0.0, [], []
+    for _ in range(400):                                       # plain Lanczos, no re-orthogonalisation
+        w = lam * v - beta * v_old
+        a = w @ v
+        w -= a * v
+        beta = np.linalg.norm(w)
+        ds.append(a)
+        es.append(beta)
+        v_old, v = v, w / beta
+    ds, es = np.array(ds), np.array(es)
+    prev = None
+    for j in range(5, 400, 5):
+        ref = eigvalsh_tridiagonal(ds[:j], es[:j - 1])
+        lo, hi = extremes(ds[:j], es[:j - 1])
+        assert abs(lo - ref[0]) <= 1e-13 * ref[-1] and abs(hi - ref[-1]) <= 1e-13 * ref[-1], j
+        if prev is not None:                                   # from just outside the previous check's values
+            lo2, hi2 = extremes(ds[:j], es[:j - 1], prev[0] - 2 * (prev[0] - lo) - 1e-14, prev[1] + 2 * (hi - prev[1]) + 1e-14)
+            assert abs(lo2 - lo) <= 1e-13 * ref[-1] and abs(hi2 - hi) <= 1e-13 * ref[-1], j
+        prev = (lo, hi)
+    assert lib.nss_tridiag_extremes(None, None, 3, None, None) != 0 and b"tridiag_extremes" in lib.nss_last_error()

@@ -675,6 +675,62 @@ def test_device_resident_lanczos_matches_the_protocol_recurrence(hip_engine):
         eigen._native_lanczos = orig
 
 
+def test_two_launch_lanczos_step_for_small_systems(hip_engine):
+    """Small systems run a Lanczos step in two launches (csrc/lanczos.hip: the rows of A, then one kernel that sums
+    both sets of dot partials in every workgroup, keeps the books and applies update + block Jacobi + dot; include/
+    nss_krylov.h::nss_lanczos_fold_mode).  Against the five-launch form: the same steps, Ritz values to 1e-10 (the sums
+    use another tree), for the all-folded form (A's partials <= 1024), the mixed form (A's sum stand-alone: n = 48) and
+    with a breakdown at step 0 (preA A = I) -- in batches whose ends fall on every residue of the step count."""
+    import scipy.sparse as sp
+    import hipla
+    from hipla import eigen
+    lib = hip_engine.lib
+
+    def ritz(A, pre, mode, tol=1e-3, check_every=5):
+        hip_engine._check(lib.nss_lanczos_fold_mode(mode))
+        try:
+            start = A.CreateColVector()
+            start.set_from(eigen.lanczos_start_values(0, len(start)))
+            out = eigen._native_lanczos(A, pre, start, tol, 400, check_every)
+            assert out is not None
+            return out
+        finally:
+            hip_engine._check(lib.nss_lanczos_fold_mode(-1))
+
+    for n in (10, 48):
+        s = mac_stokes(3, n, 0.01)
+        A = hipla.SparseMatrix.from_scipy(s.A)
+        assert (A.handle.info()["row_blocks"] > 1024) == (n == 48)
+        for pre in (hipla.BlockJacobi(A, s.line_blocks(3)), 0.5 * hipla.BlockJacobi(A, s.line_blocks(2))):
+            five = ritz(A, pre, 0)
+            for mode in (-1, 1):
+                two = ritz(A, pre, mode)
+                assert len(two) == len(five), (n, mode, len(two), len(five))
+                np.testing.assert_allclose(two, five, rtol=1e-10, atol=1e-12 * five.max())
+            if n == 10:
+                for every in (1, 3, 7):         # other batch ends: the books kernel and the next batch's first kernel
+                    a, b = ritz(A, pre, 0, check_every=every), ritz(A, pre, 1, check_every=every)
+                    assert len(a) == len(b)
+                    np.testing.assert_allclose(b, a, rtol=1e-10, atol=1e-12 * a.max())
+    # the start vector is formed on the device: the bits of the numpy form, at any offset (64-bit wrap-around)
+    for off in (0, 7, 3_000_000_000, 2 ** 40 + 5):
+        buf = hip_engine.zeros(1003)
+        hip_engine.lanczos_start_values(buf, off)
+        assert np.array_equal(hip_engine.to_host(buf), eigen.lanczos_start_values(off, 1003)), off
+    # breakdown: block-diagonal A with the blocks of the preconditioner -> preA A = I, gamma_1 = 0 at step 0
+    rng = np.random.default_rng(5)
+    blocks, mats = [], []
+    for b in range(700):
+        m = rng.standard_normal((3, 3))
+        mats.append(m @ m.T + 3.0 * np.eye(3))
+        blocks.append([3 * b, 3 * b + 1, 3 * b + 2])
+    A = hipla.SparseMatrix.from_scipy(sp.block_diag(mats, format="csr"))
+    pre = hipla.BlockJacobi(A, blocks)
+    for mode in (0, 1):
+        got = ritz(A, pre, mode)
+        assert len(got) == 1 and abs(got[0] - 1.0) < 1e-12, (mode, got)
+
+
 def test_reuse_aware_dispatch_order_changes_no_bit(hip_engine):
     """Grid operators beyond ~1e7 rows get a second, dispatch-ordered copy of their row-block descriptors
     (csrc/csr_stream.h: blkdisp): inside every XCD's share the blocks b, b + P, ..., b + (T - 1) P of T grid planes

@@ -22,8 +22,10 @@ for name in (sys.argv[1:] or ["cfg2", "cfg3", "cfg4"]):
     A = hipla.SparseMatrix.from_scipy(s.A)
     pre = hipla.BlockJacobi(A, s.line_blocks(3))
     out = {}
-    for mode in ("native", "protocol"):
-        eigen.NATIVE = mode == "native"
+    eng = hipla.get_engine()
+    for mode in ("native", "five-launch", "protocol"):
+        eigen.NATIVE = mode != "protocol"
+        eng.lib.nss_lanczos_fold_mode(0 if mode == "five-launch" else -1)     # native: the two-launch step by size
         eigen.EigenValues_Preconditioner(mat=A, pre=pre, tol=1e-3)        # warm-up (workspaces, kernels)
         best = 1e9
         for _ in range(3):
@@ -34,6 +36,8 @@ for name in (sys.argv[1:] or ["cfg2", "cfg3", "cfg4"]):
             best = min(best, time.perf_counter() - t0)
         out[mode] = (best, len(lams), float(lams.min()), float(lams.max()))
     eigen.NATIVE = True
-    (tn, kn, lo_n, hi_n), (tp, kp, lo_p, hi_p) = out["native"], out["protocol"]
-    print("%s (%d rows): device-resident %.1f ms (%d steps, %.1f us/step) | protocol %.1f ms (%d steps) | x %.2f | "
-          "lambda_min rel. diff %.1e" % (name, s.n_u, 1e3 * tn, kn, 1e6 * tn / kn, 1e3 * tp, kp, tp / tn, abs(lo_n - lo_p) / lo_p))
+    eng.lib.nss_lanczos_fold_mode(-1)
+    (tn, kn, lo_n, hi_n), (tp, kp, lo_p, hi_p), (t5, k5, _, _) = out["native"], out["protocol"], out["five-launch"]
+    print("%s (%d rows): device-resident %.1f ms (%d steps, %.1f us/step; five-launch steps only: %.1f ms, %d steps) | "
+          "protocol %.1f ms (%d steps) | x %.2f | lambda_min rel. diff %.1e"
+          % (name, s.n_u, 1e3 * tn, kn, 1e6 * tn / kn, 1e3 * t5, k5, 1e3 * tp, kp, tp / tn, abs(lo_n - lo_p) / lo_p))
