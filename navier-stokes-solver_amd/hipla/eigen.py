@@ -107,7 +107,6 @@ def _native_lanczos(mat, pre, start, tol, maxsteps, check_every):
     # batch b + 1 were wasted work -- the result does not see them.
     h_ctrl = [torch.empty(4, dtype=torch.int32).pin_memory() for _ in range(2)]
     h_hist = torch.empty(2 * maxsteps, dtype=torch.float64).pin_memory()
-    h_one = torch.ones(1, dtype=torch.int32).pin_memory()
     pending = []                                          # (end, event, slot)
 
     # A batch is a multiple of `check_every` steps sized to ~0.25 ms of device work: long enough that the host's
@@ -176,12 +175,10 @@ def _native_lanczos(mat, pre, start, tol, maxsteps, check_every):
             if lo_prev is not None:
                 moved[0], moved[1] = max(lo_prev - lo, 0.0), max(hi - hi_prev, 0.0)
             lo_prev, hi_prev = lo, hi
-    # The steps still in flight are no longer needed: raise the stop flag from a second stream (every kernel then
-    # returns at once) and solve the final eigenproblem while they drain.
     _mark("converged (%d steps, %d enqueued)" % (len(diag), j))
-    side = torch.cuda.Stream()
-    with torch.cuda.stream(side):
-        ctrl[0:1].copy_(h_one, non_blocking=True)
+    # The final eigenproblem is solved while the speculative steps still in flight (less than one batch: ~0.25 ms of
+    # device work by the batch size) drain.  (Raising the stop flag from a second stream to cut them short was tried:
+    # it gains nothing once the two overlap, and the first use of a second torch stream costs 5.5 ms.)
     ritz = _tridiag_eigs(list(diag), list(off))
     _mark("all Ritz values")
     torch.cuda.synchronize()                              # (before the buffers of the speculative steps go away)
