@@ -761,7 +761,9 @@ def main():
     #   C1 6 + 5 (q, z0, t2, s0, w0, u0 | u0, z0, q, s0, t0) and the gathers of s1, w1;  preA 2 (t0 | t1);
     #   C23 rows of A: gather t1, s0, t0 | t2;  rows of B: gathers of t1, s0;  s1, w1 | s1, t3;
     #   C4 5 + 2 (t0, t1, t2, d0, w0 | d0, w0) and 6 + 3 (s1, t3, u1, d1, minv, w1 | u1, d1, w1)
-    vec_bytes = 8 * (26 * n_u + 15 * n_p)
+    #   (block Jacobi applied in C1's epilogue: t0 is not read back -- one velocity pass fewer)
+    pre_in_c1 = loop.c1_applies_preA()
+    vec_bytes = 8 * ((25 if pre_in_c1 else 26) * n_u + 15 * n_p)
     iter_bytes = mat_bytes + pre_bytes + vec_bytes
     iter_gbs = iter_bytes / (elapsed / K) / 1e9
 
@@ -860,7 +862,7 @@ def main():
         "kernel_ms": {"C1_BT_preA": k1_ms, "C23_A_B": k2_ms, "C4_update": k4_ms, "sum_kernels": sums_ms,
                       "spmv_A_plain_in_loop_cache_state": spmv_ms, "spmv_A_plain_back_to_back": spmv_b2b_ms,
                       "triad_1.6GB": triad_ms},
-        "launches_per_iteration": {"sums_folded_into_consumers": folds},
+        "launches_per_iteration": {"sums_folded_into_consumers": folds, "preA_applied_in_C1_epilogue": pre_in_c1},
         "bytes_per_iteration": iter_bytes,
         "parity": parity,
         "setup_s": {"assemble_host": t_asm, "upload_lanczos_initial_residual": t_setup},

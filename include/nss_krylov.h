@@ -160,6 +160,13 @@ NSS_API int nss_csr_operand_form(nss_csr_t a, int32_t* form);
  * place with shorter row blocks (1024 products) when that gets it there -- per-row sums keep their bits, the
  * dot-product partials are regrouped -- and reports whether the matrix is pair-stageable now.  Set-up only
  * (synchronises the device); a no-op for matrices that are not staged at all or already qualify. */
+/* Re-plan `a` (in place, set-up only) so that every row block holds whole blocks of `j` and at most 512 rows, and record
+ * the first Jacobi block of every row block: a kernel over the rows of `a` can then apply `j` to its own result in the
+ * epilogue (nss_bpcg2_fuse_block_jacobi).  Needs symmetric inverse blocks over runs of consecutive dofs that tile the
+ * rows of `a` (in any numbering of the blocks), and a system the size rule of nss_bpcg2_fuse_block_jacobi wants fused;
+ * *planned = 0 (and nothing changes) otherwise.  Per-row sums keep their
+ * bits: only the partition of the rows into workgroups changes. */
+NSS_API int nss_csr_plan_for_blocks(nss_csr_t a, nss_bjac_t j, int32_t* planned);
 NSS_API int nss_csr_plan_for_pairs(nss_csr_t a, int32_t* pair_staged);
 /* the same question without re-planning */
 NSS_API int nss_csr_pair_staged(nss_csr_t a, int32_t* pair_staged);
@@ -415,6 +422,15 @@ NSS_API int nss_bpcg2_cphases(const nss_bpcg2_t* s, int32_t first, int32_t last,
  * measurements: -1 automatic (default), 0 never fold, 1 always fold. */
 NSS_API int nss_bpcg2_folds_sums(const nss_bpcg2_t* s, int32_t* folds);
 NSS_API int nss_bpcg2_fold_mode(int32_t mode);
+/* Block Jacobi alone as preA (templates/NavierStokesSIMPLE_iterative.py:360-373,383 with GS=False and no auxiliary
+ * term): when B^T's row blocks are planned around the Jacobi blocks (nss_csr_plan_for_blocks) C1 applies
+ * t1 = k J t0 in its epilogue -- the row block's t0 passes through LDS, one lane per Jacobi block, the arithmetic of
+ * the stand-alone apply (identical bits) -- instead of a launch of its own that reads t0 back: 3 dependent launches
+ * per iteration.  By size (mode -1, the default: up to 2^18 velocity rows -- the launch-bound regime, where it is
+ * worth 8-25 % of an iteration; above 1e6 DoF the stand-alone apply is 2-3 % faster); 0 never, 1 whenever B^T is
+ * planned for it (tests, A/B runs).  nss_bpcg2_c1_applies_preA: what the next C1 of this state will do. */
+NSS_API int nss_bpcg2_fuse_block_jacobi(int32_t mode);
+NSS_API int nss_bpcg2_c1_applies_preA(const nss_bpcg2_t* s, int32_t* yes);
 /* wait for the stream and read ctrl: done (0 running, 1 stop test fired, 2 breakdown
  * <s, K s> == 0 where the reference raises ZeroDivisionError, :226), iteration at which it
  * happened, last iteration whose history entry was written */

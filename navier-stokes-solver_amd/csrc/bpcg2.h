@@ -16,6 +16,8 @@ void bpcg2_phase(const nss_bpcg2_t& s, int which, int it, hipStream_t st);
 // after their arrival)
 void bpcg2_spmv_phase(const nss_bpcg2_t& s, int which, int it, hipStream_t st, int b0, int b1, bool ghost_tail = true);
 void bpcg2_k1_finish(const nss_bpcg2_t& s, hipStream_t st);
+// the size rule / override of nss_bpcg2_fuse_block_jacobi for a system with `rows` velocity rows
+bool fuse_block_jacobi_wanted(int64_t rows);
 void bpcg2_cphase(const nss_bpcg2_t& s, int which, int it, hipStream_t st);
 void gather_launch(int64_t n, const int32_t* idx, const double* src, double* dst, hipStream_t st);
 }  // namespace nss

@@ -513,6 +513,14 @@ struct EpiK1c {
   int32_t ghost_n = 0;
   double* __restrict__ ghost_s0 = nullptr;
   const double* __restrict__ ghost_w0 = nullptr;
+  // block Jacobi applied here (B^T planned around its blocks, nss_csr_plan_for_blocks): t1 = k J t0 from the LDS copy
+  // of this row block's t0, one lane per Jacobi block, the arithmetic of bjac_apply_sym_kernel (row i: the chain
+  // fma(M_ij, x_j, .) over j ascending) -- no launch of its own, t0 is not read back
+  const int32_t* __restrict__ jb_first = nullptr;    // nullptr: not fused
+  const int32_t* __restrict__ jb_order = nullptr;
+  const int32_t* __restrict__ jb_run = nullptr;
+  const double* __restrict__ jb_packed = nullptr;
+  int32_t jb_count = 0, jb_bs = 0;
   double alpha = 0.0, beta = 0.0;
   bool pending = false;
   __device__ bool skip() const { return cl.ctrl[C_DONE] != 0; }
@@ -570,8 +578,30 @@ struct EpiK1c {
     const double t = qv + bts;
     NSS_ST3(t0[r], t);
     if (dinv) t1[r] = k * (dinv[r] * t);
+    if (jb_first) {
+      extern __shared__ double k1_t0[];
+      k1_t0[r & (kBlockRows - 1)] = t;                   // (a row block holds at most kBlockRows consecutive rows)
+    }
   }
-  __device__ void finish(int, double*) const {
+  __device__ void finish(int b, double*) const {
+    if (jb_first && b >= 0) {                            // (uniform over the workgroup)
+      extern __shared__ double k1_t0[];
+      __syncthreads();
+      const int j1 = jb_first[b + 1];
+      for (int pos = jb_first[b] + int(threadIdx.x); pos < j1; pos += kBlock) {
+        const int jb = jb_order[pos];
+        const int32_t w = jb_run[jb], first = w >> 5, len = w & 31;
+        for (int i = 0; i < len; ++i) {
+          double s = 0.0;
+          for (int j = 0; j < len; ++j) {
+            const int lo = i < j ? i : j, hi = i < j ? j : i;
+            const int tri = lo * jb_bs - (lo * (lo - 1)) / 2 + (hi - lo);      // upper triangle, row-major
+            s = fma(jb_packed[size_t(tri) * jb_count + jb], k1_t0[(first + j) & (kBlockRows - 1)], s);
+          }
+          t1[first + i] = k * s;
+        }
+      }
+    }
     if (it == 0 || ghost_n == 0) return;
     const int stride = gridDim.x * kBlock;
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < ghost_n; i += stride) ghost_s0[i] = fma(beta, ghost_s0[i], ghost_w0[i]);
@@ -885,6 +915,18 @@ static CloseArgs close_args(const nss_bpcg2_t& s, bool fold) {
   return CloseArgs{s.ctrl, s.scal, s.hist, s.partials_c, k4_partials(s), fold ? 1 : 0};
 }
 
+// C1 applies the block Jacobi itself when preA is that alone, B^T is planned around its blocks and the system is small:
+// measured over 1e4 ... 1e7 DoF (profiles/r03_fuse_bjac_sizes.txt) the launch it removes is worth 25 % of an
+// iteration at 1e4 DoF, 8 % at 1e5, 2 % at 2.7e5 -- and from 1e6 DoF on the fused form LOSES 2-3 %: the per-block
+// tail of every workgroup, and C23 no longer finds t1 fresh in the memory-side cache (it was the last thing written).
+constexpr int kFuseBjacMaxRows = 1 << 18;
+static int g_fuse_bjac = -1;          // -1: by size, 0: never, 1: whenever B^T is planned for it
+bool fuse_block_jacobi_wanted(int64_t rows) { return g_fuse_bjac == 1 || (g_fuse_bjac == -1 && rows <= kFuseBjacMaxRows); }
+bool c1_applies_block_jacobi(const nss_bpcg2_t& s) {
+  return fuse_block_jacobi_wanted(s.n_u) && s.pre_bjac && !s.pre_bjac->gs_mat && !s.pre_amg && !s.pre_dist_amg && !s.pre_dist_aux && !s.pre_diag &&
+         !s.cond_HT && s.BT->jb_first && s.BT->jb_serial == s.pre_bjac->serial && s.pre_bjac->inv_sym && s.pre_bjac->run;
+}
+
 void bpcg2_cphase(const nss_bpcg2_t& s, int which, int it, hipStream_t st) {
   const bool fold = fold_sums(s);
   switch (which) {
@@ -893,15 +935,20 @@ void bpcg2_cphase(const nss_bpcg2_t& s, int which, int it, hipStream_t st) {
       // (streaming operand loads only where B^T takes the row-per-lane kernel: that is the large-system regime,
       // and the stream-kernel instantiations of the epilogue are not doubled)
       const bool nt = s.BT->ell_col != nullptr && stream_vector_loads(s.n_u);
+      const bool fj = c1_applies_block_jacobi(s);
+      const nss_bjac_s* J = s.pre_bjac;
+      const size_t lds = fj ? sizeof(double) * kBlockRows : 0;
 #define NSS_C1(FOLD, NT, LAUNCH)                                                                                       \
   LAUNCH(*s.BT, s.s1, EpiK1c<FOLD, NT>{close_args(s, FOLD), s.u0, s.q, s.z0, s.t2, s.s0, s.w0, s.t0, s.t1, dinv, s.k, it, \
-                                       s.s1, s.w1, s.dist_compact ? s.ghost_n : 0, s.ghost_s0, s.ghost_w0}, st)
+                                       s.s1, s.w1, s.dist_compact ? s.ghost_n : 0, s.ghost_s0, s.ghost_w0,                 \
+                                       fj ? s.BT->jb_first : nullptr, fj ? s.BT->jb_order : nullptr, fj ? J->run : nullptr, fj ? J->inv_sym : nullptr,   \
+                                       fj ? J->nblocks : 0, fj ? J->bs : 0}, st, 0, -1, lds)
       if (nt && fold) NSS_C1(true, true, launch_csr_direct);
       else if (nt) NSS_C1(false, true, launch_csr_direct);
       else if (fold) NSS_C1(true, false, launch_csr_stream);
       else NSS_C1(false, false, launch_csr_stream);
 #undef NSS_C1
-      bpcg2_k1_finish(s, st);
+      if (!fj) bpcg2_k1_finish(s, st);
       break;
     }
     case NSS_BPCG2C_C23: {
@@ -984,6 +1031,20 @@ int nss_bpcg2_cphases(const nss_bpcg2_t* s, int32_t first, int32_t last, int32_t
     NSS_REQUIRE(s->dist_compact || (!s->ghost_mode && !s->ghost_p_mode && !s->local_sums),
                 "bpcg2_cphases: single-GPU states, or row-partitioned states laid out for the compact plan");
     for (int ph = first; ph <= last; ++ph) bpcg2_cphase(*s, ph, it, as_stream(stream));
+  });
+}
+
+int nss_bpcg2_fuse_block_jacobi(int32_t mode) {
+  return guarded([&] {
+    NSS_REQUIRE(mode >= -1 && mode <= 1, "bpcg2_fuse_block_jacobi: -1 (by size), 0 (never) or 1 (whenever B^T is planned for it)");
+    g_fuse_bjac = mode;
+  });
+}
+
+int nss_bpcg2_c1_applies_preA(const nss_bpcg2_t* s, int32_t* yes) {
+  return guarded([&] {
+    NSS_REQUIRE(s && s->BT && yes, "bpcg2_c1_applies_preA: NULL argument");
+    *yes = c1_applies_block_jacobi(*s) ? 1 : 0;
   });
 }
 

@@ -162,6 +162,15 @@ struct nss_csr_s {
   // passes, the epilogue's loads of each pass behind the previous one's stores).
   int32_t* ell_col = nullptr;
   double* ell_val = nullptr;
+  // Row blocks planned around the blocks of ONE block-Jacobi handle (nss_csr_plan_for_blocks: every row block holds
+  // whole Jacobi blocks and at most kBlockRows rows): a kernel over the rows of this matrix can then apply that
+  // preconditioner to its own result in the epilogue -- the row block's results pass through LDS, lanes take one
+  // Jacobi block each (the fused BPCG loop: t1 = k J t0 inside C1, no launch of its own and no re-read of t0).
+  // jb_order = the Jacobi blocks in row order (callers number them as they like); jb_first[b] = position in jb_order of
+  // the first Jacobi block of row block b (nblk + 1 entries); jb_serial = nss_bjac_s::serial of that handle.
+  int32_t* jb_first = nullptr;
+  int32_t* jb_order = nullptr;
+  uint64_t jb_serial = 0;
   // `stageable`: the kernel's operand functor is one stored vector that can be copied to LDS (XOp::kStageable);
   // `pairable`: it is an expression of two (XOp::kStageablePair)
   int idx_mode(bool stageable = true, bool pairable = false) const {
@@ -276,6 +285,7 @@ struct EpiPrologue<E, std::void_t<decltype(std::declval<E&>().prologue(static_ca
   static __device__ bool run(E& e, double* lds) { return e.prologue(lds); }
 };
 
+constexpr int kBlockRows = 512;   // rows per row block of a matrix planned around Jacobi blocks (their results: 4 KiB of LDS)
 constexpr int kRedDoubles = 32;   // per-workgroup reduction scratch (block_sum: 4, fixed_sum_1024: 32)
 
 // Phase 1 of one row block for ONE form of the column stream (IDX: 0 = 4-byte columns, 1 = 16-bit
@@ -657,11 +667,11 @@ __global__ __launch_bounds__(kBlock) void csr_direct_kernel(CsrView a, const int
 // the row-per-lane kernel alone (A must hold the fixed-width copy): for epilogue variants that only exist for it
 template <class Epi>
 inline void launch_csr_direct(const nss_csr_s& A, const double* x, const Epi& epi, hipStream_t st, int b0 = 0,
-                              int b1 = -1) {
+                              int b1 = -1, size_t dyn_lds = 0) {
   if (b1 < 0) b1 = A.nblk;
   if (A.m == 0 || b1 <= b0) return;
   if (!A.ell_col) throw Error("csr_direct: the matrix has no fixed-width copy");
-  hipLaunchKernelGGL((csr_direct_kernel<Epi>), dim3(nss_csr_s::grid(b1 - b0)), dim3(kBlock), 0, st, A.view(b0, b1, 0),
+  hipLaunchKernelGGL((csr_direct_kernel<Epi>), dim3(nss_csr_s::grid(b1 - b0)), dim3(kBlock), dyn_lds, st, A.view(b0, b1, 0),
                      A.ell_col, A.ell_val, x, epi);
   NSS_CHECK_LAUNCH();
 }
@@ -673,7 +683,7 @@ inline void launch_csr_stream(const nss_csr_s& A, const double* x, const Epi& ep
   if (b1 < 0) b1 = A.nblk;
   if (A.m == 0 || b1 <= b0) return;
   if (A.ell_col) {
-    launch_csr_direct(A, x, epi, st, b0, b1);
+    launch_csr_direct(A, x, epi, st, b0, b1, dyn_lds);
     return;
   }
   constexpr bool kCanStage = EpiX<Epi>::type::kStageable;

@@ -6,6 +6,7 @@
 #include <vector>
 
 struct nss_bjac_s {
+  uint64_t serial = 0;         // unique per handle (matrices planned around its blocks remember it: nss_csr_s::jb_serial)
   int32_t bs = 0, nblocks = 0;
   int64_t n = 0;
   int32_t* idx = nullptr;      // [bs][nblocks], -1 = padding

@@ -477,6 +477,8 @@ int nss_bjac_create(nss_csr_t a, int32_t bs, int32_t nblocks, const int32_t* h_i
     nss_bjac_s* j = new nss_bjac_s;
     int32_t* singular = nullptr;
     try {
+      static uint64_t next_serial = 0;
+      j->serial = ++next_serial;
       j->bs = bs;
       j->nblocks = nblocks;
       j->n = a->m;

@@ -1,5 +1,7 @@
 // CSR matrix handles (upload, launch plan) and the plain alpha/beta SpMV entry point.
+#include "bpcg2.h"
 #include "csr_stream.h"
+#include "precond.h"
 
 #include <algorithm>
 #include <climits>
@@ -745,18 +747,27 @@ int nss_csr_destroy(nss_csr_t a) {
     (void)hipFree(a->pos16);
     (void)hipFree(a->ell_col);
     (void)hipFree(a->ell_val);
+    (void)hipFree(a->jb_first);
+    (void)hipFree(a->jb_order);
     delete a;
   });
 }
 
 // new launch plan with at most `products` products per row block; every derived column stream is rebuilt
-static void replan(nss_csr_s& A, int products) {
+static void replan(nss_csr_s& A, int products, int max_rows = 0, const uint8_t* row_pos = nullptr,
+                   std::vector<int32_t>* blk_out = nullptr) {
   NSS_HIP(hipDeviceSynchronize());                       // no kernel may still read the arrays that go away
   std::vector<int32_t> h_rowptr(size_t(A.m) + 1);
   NSS_HIP(hipMemcpy(h_rowptr.data(), A.rowptr, sizeof(int32_t) * h_rowptr.size(), hipMemcpyDeviceToHost));
   std::vector<int32_t> blk;
   int32_t rg = 1, chunk = kChunk;
-  plan_row_blocks(A.m, A.nnz, h_rowptr.data(), &rg, &chunk, blk, A.cuts.data(), int(A.cuts.size()), products);
+  plan_row_blocks(A.m, A.nnz, h_rowptr.data(), &rg, &chunk, blk, A.cuts.data(), int(A.cuts.size()), products, max_rows,
+                  row_pos);
+  (void)hipFree(A.jb_first);                             // a plan around Jacobi blocks ends with the plan
+  (void)hipFree(A.jb_order);
+  A.jb_first = nullptr;
+  A.jb_order = nullptr;
+  A.jb_serial = 0;
   int32_t* rowblk = nullptr;
   NSS_HIP(hipMalloc(&rowblk, sizeof(int32_t) * blk.size()));
   NSS_HIP(hipMemcpy(rowblk, blk.data(), sizeof(int32_t) * blk.size(), hipMemcpyHostToDevice));
@@ -779,6 +790,7 @@ static void replan(nss_csr_s& A, int products) {
   A.nblk = int32_t(blk.size()) - 1;
   A.blk_products = products;
   compress_columns(A, nullptr);
+  if (blk_out) blk_out->swap(blk);
 }
 
 int nss_csr_plan_for_pairs(nss_csr_t a, int32_t* pair_staged) {
@@ -791,6 +803,54 @@ int nss_csr_plan_for_pairs(nss_csr_t a, int32_t* pair_staged) {
       if (!a->pair_ok) replan(*a, before);               // wide operators: shorter blocks do not help; back to the full plan
     }
     if (pair_staged) *pair_staged = (a->blkseg && a->pair_ok) ? 1 : 0;
+  });
+}
+
+int nss_csr_plan_for_blocks(nss_csr_t a, nss_bjac_t j, int32_t* planned) {
+  return guarded([&] {
+    NSS_REQUIRE(a != nullptr && j != nullptr, "csr_plan_for_blocks: NULL argument");
+    static_assert(kBlockRows >= kDirectRows, "a row block of the row-per-lane kernel must fit the LDS copy of its results");
+    if (planned) *planned = 0;
+    if (a->jb_first && a->jb_serial == j->serial) {      // already planned around this handle
+      if (planned) *planned = 1;
+      return;
+    }
+    // what the fused epilogue applies: symmetric inverse blocks over runs of consecutive dofs that tile the rows in order
+    if (j->n != a->m || !j->run || !j->inv_sym || j->gs_mat || j->n_uncovered != 0 || j->nblocks == 0) return;
+    if (!fuse_block_jacobi_wanted(a->m)) return;         // (large systems: the stand-alone apply is faster; no re-plan)
+    std::vector<int32_t> run(size_t(j->nblocks));
+    NSS_HIP(hipMemcpy(run.data(), j->run, sizeof(int32_t) * run.size(), hipMemcpyDeviceToHost));
+    // the blocks in row order (callers number them as they like: the lines of one velocity component after the other)
+    std::vector<int32_t> order(run.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = int32_t(i);
+    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return (run[size_t(x)] >> 5) < (run[size_t(y)] >> 5); });
+    std::vector<uint8_t> row_pos(size_t(a->m), 0);
+    int64_t next = 0;
+    for (int32_t jb : order) {
+      const int32_t first = run[size_t(jb)] >> 5, len = run[size_t(jb)] & 31;
+      if (first != next || len < 1 || first + len > a->m) return;          // the blocks do not tile the rows: no fusion
+      for (int c = 0; c < len; ++c) row_pos[size_t(first + c)] = uint8_t(c);
+      next = first + len;
+    }
+    if (next != a->m) return;
+    std::vector<int32_t> blk;
+    replan(*a, a->blk_products, kBlockRows, row_pos.data(), &blk);
+    // position (in row order) of the first Jacobi block of every row block (row blocks start at block starts)
+    std::vector<int32_t> first_of(blk.size());
+    size_t b = 0;
+    for (size_t i = 0; i < blk.size(); ++i) {
+      while (b < order.size() && (run[size_t(order[b])] >> 5) < blk[i]) ++b;
+      // (a forced cut of the matrix inside a Jacobi block, or one over-long row: the plan stands, without the fusion)
+      if (!(i + 1 == blk.size() ? b == order.size() : (b < order.size() && (run[size_t(order[b])] >> 5) == blk[i]))) return;
+      if (i > 0 && blk[i] - blk[i - 1] > kBlockRows) return;
+      first_of[i] = int32_t(b);
+    }
+    NSS_HIP(hipMalloc(&a->jb_first, sizeof(int32_t) * first_of.size()));
+    NSS_HIP(hipMemcpy(a->jb_first, first_of.data(), sizeof(int32_t) * first_of.size(), hipMemcpyHostToDevice));
+    NSS_HIP(hipMalloc(&a->jb_order, sizeof(int32_t) * order.size()));
+    NSS_HIP(hipMemcpy(a->jb_order, order.data(), sizeof(int32_t) * order.size(), hipMemcpyHostToDevice));
+    a->jb_serial = j->serial;
+    if (planned) *planned = 1;
   });
 }
 

@@ -207,6 +207,9 @@ class Bpcg2Loop:
         # the rows of B multiply t1 - s0 (:212-213): with row blocks short enough both vectors are read from LDS copies
         self.pair_staged_b = (os.environ.get("NSS_PAIR_STAGE", "1") == "1" and hasattr(matB.handle, "plan_for_pairs")
                               and matB.handle.plan_for_pairs())
+        # block Jacobi alone as preA: B^T's row blocks are planned around its blocks and C1 applies it in its epilogue
+        self.c1_applies_bjac = (pa["bjac"] is not None and pa["diag"] is None and pa["amg"] is None and condensed is None
+                                and hasattr(matBT.handle, "plan_for_blocks") and matBT.handle.plan_for_blocks(pa["bjac"].handle))
         st.A, st.B, st.BT = matA.handle.ptr, matB.handle.ptr, matBT.handle.ptr
         st.pre_diag = pa["diag"].d.data_ptr() if pa["diag"] is not None else None
         st.pre_bjac = pa["bjac"].handle.ptr if pa["bjac"] is not None else None
@@ -271,6 +274,13 @@ class Bpcg2Loop:
     def folds_sums(self):
         out = C.c_int32()
         self.eng._check(self.lib.nss_bpcg2_folds_sums(C.byref(self.state), C.byref(out)))
+        return bool(out.value)
+
+    def c1_applies_preA(self):
+        """Whether the next C1 applies the block Jacobi in its epilogue (B^T planned around the blocks, and the size
+        rule / override of nss_bpcg2_fuse_block_jacobi)."""
+        out = C.c_int32()
+        self.eng._check(self.lib.nss_bpcg2_c1_applies_preA(C.byref(self.state), C.byref(out)))
         return bool(out.value)
 
     def enqueue_dist(self, dist_handle, halos, overlap, it_begin, it_end):

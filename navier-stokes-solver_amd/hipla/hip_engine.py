@@ -130,6 +130,9 @@ def _signatures():
         "nss_minres_iterate_dist": (C.c_int, [vp, vp, vp, vp, i32, i32, vp]),
         "nss_minres_fold_mode": (C.c_int, [i32]),
         "nss_lanczos_fold_mode": (C.c_int, [i32]),
+        "nss_bpcg2_fuse_block_jacobi": (C.c_int, [i32]),
+        "nss_bpcg2_c1_applies_preA": (C.c_int, [vp, c_i32_p]),
+        "nss_csr_plan_for_blocks": (C.c_int, [vp, vp, c_i32_p]),
         "nss_lanczos_start_values": (C.c_int, [i64, i64, vp, vp]),
         "nss_tridiag_extremes": (C.c_int, [vp, vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "nss_minres_fuse_mode": (C.c_int, [i32]),
@@ -165,6 +168,8 @@ def load_library(path=None):
         for name in ("nss_bpcg2_fold_mode", "nss_minres_fold_mode"):
             if hasattr(lib, name):
                 getattr(lib, name)(int(os.environ["NSS_FOLD_SUMS"]))
+    if os.environ.get("NSS_FUSE_BJAC") and hasattr(lib, "nss_bpcg2_fuse_block_jacobi"):   # measurements: 0 / 1
+        lib.nss_bpcg2_fuse_block_jacobi(int(os.environ["NSS_FUSE_BJAC"]))
     if os.environ.get("NSS_LANCZOS_FOLD") and hasattr(lib, "nss_lanczos_fold_mode"):      # measurements: -1 / 0 / 1
         lib.nss_lanczos_fold_mode(int(os.environ["NSS_LANCZOS_FOLD"]))
     return lib
@@ -184,6 +189,13 @@ class _CsrHandle:
         out = np.zeros(nb + 1, dtype=np.int32)
         self.engine._check(self.engine.lib.nss_csr_row_blocks(self.ptr, out.ctypes.data, out.size))
         return out
+
+    def plan_for_blocks(self, bjac_handle):
+        """Re-plan (in place, set-up only) around the blocks of a block-Jacobi handle (nss_csr_plan_for_blocks) so that
+        a kernel over these rows can apply it in its epilogue; returns whether that is possible now."""
+        out = C.c_int32()
+        self.engine._check(self.engine.lib.nss_csr_plan_for_blocks(self.ptr, bjac_handle.ptr, C.byref(out)))
+        return bool(out.value)
 
     def plan_for_pairs(self, replan=True):
         """Re-plan (in place, set-up only) so that kernels whose operand is an expression of two vectors can take both

@@ -559,6 +559,66 @@ def test_compact_plan_equals_eight_phase_form_bit_for_bit(hip_engine, case):
         lib.nss_bpcg2_fold_mode(-1)
 
 
+@pytest.mark.parametrize("dim,n,inflate,bs", [(3, 20, 1, 3), (2, 90, 1, 3), (2, 40, 1, 2), (2, 24, 4, 1), (3, 56, 1, 3)])
+def test_block_jacobi_applied_in_the_epilogue_of_c1(hip_engine, dim, n, inflate, bs):
+    """Block Jacobi alone as preA (templates/NavierStokesSIMPLE_iterative.py:360-373,383): with B^T's row blocks
+    planned around the Jacobi blocks (nss_csr_plan_for_blocks) C1 applies t1 = k J t0 itself -- the row block's t0
+    passes through LDS, one lane per Jacobi block -- instead of a launch that reads t0 back.  (i) the re-planned B^T
+    multiplies to the bits of the original plan; (ii) history and solution equal the stand-alone apply's bit for bit,
+    for the row-per-lane kernel (3-D, large 2-D), the stream kernel (small / wide B^T) and ragged line ends;
+    (iii) blocks that do not tile the rows are declined and the loop runs as before."""
+    import hipla
+    from solvers.bramblepasciak_new import BpcgSession
+    s = mac_stokes(dim, n, 0.01)
+    if inflate > 1:
+        s = s.inflate(inflate)
+    f, g = s.rhs(0)
+    lib = hip_engine.lib
+    xp = hipla.Vector.from_numpy(np.random.default_rng(2).standard_normal(s.n_p))
+    BT0 = hipla.SparseMatrix.from_scipy(s.B.T.tocsr())
+    y0 = hipla.Vector(s.n_u)
+    y0.data = BT0 * xp
+
+    def run(fuse, blocks, nit=30):
+        hip_engine._check(lib.nss_bpcg2_fuse_block_jacobi(1 if fuse else 0))      # (-1, the default: by size)
+        A, B = hipla.SparseMatrix.from_scipy(s.A), hipla.SparseMatrix.from_scipy(s.B)
+        preA = hipla.BlockJacobi(A, blocks)
+        sol = hipla.BlockVector([hipla.Vector(s.n_u), hipla.Vector(s.n_p)])
+        with contextlib.redirect_stdout(io.StringIO()):
+            ses = BpcgSession(Form(A), Form(B), None, hipla.Vector.from_numpy(f), hipla.Vector.from_numpy(g), preA,
+                              hipla.DiagonalMatrix(1.0 / s.mass), sol=sol)
+        loop = ses.fused
+        ses.first_direction()
+        loop.start(ses.wdn, ses.err0, 0.0, True, nit)
+        loop.enqueue(0, nit)
+        loop.poll()
+        y = hipla.Vector(s.n_u)
+        y.data = ses.matBT * xp
+        assert loop.c1_applies_preA() == (bool(fuse) and loop.c1_applies_bjac)
+        return loop.history(nit - 1).copy(), sol.numpy(), y.numpy(), loop.c1_applies_bjac
+
+    try:
+        blocks = s.line_blocks(bs)
+        apart = run(False, blocks)
+        fused = run(True, blocks)
+        assert fused[3] and not apart[3]                     # (mode 0: B^T is not even re-planned)
+        np.testing.assert_array_equal(fused[2], y0.numpy())                  # (i)
+        np.testing.assert_array_equal(fused[0], apart[0])                    # (ii)
+        np.testing.assert_array_equal(fused[1], apart[1])
+        assert np.all(np.isfinite(fused[0])) and fused[0][-1] < fused[0][0]
+        if dim == 2 and n == 40:
+            rev = np.ascontiguousarray(np.asarray(blocks)[:, ::-1])          # any block numbering: taken in row order
+            a, b = run(False, rev), run(True, rev)
+            assert b[3] and not a[3]
+            np.testing.assert_array_equal(a[0], b[0])
+            np.testing.assert_array_equal(a[1], b[1])
+            fewer = np.ascontiguousarray(np.asarray(blocks)[:, :-1])         # (iii) a dof in no block: declined
+            declined = run(True, fewer)
+            assert not declined[3] and np.all(np.isfinite(declined[0]))
+    finally:
+        lib.nss_bpcg2_fuse_block_jacobi(-1)
+
+
 @pytest.mark.parametrize("dim,n,inflate", [(3, 16, 1), (2, 40, 1), (3, 6, 12)])
 def test_pair_staged_operands_give_identical_bits(hip_engine, dim, n, inflate):
     """Kernels whose SpMV operand is an expression of two stored vectors -- the rows of B multiply t1 - s0, the rows
