@@ -260,11 +260,18 @@ def mypre_a_gs_roofline(torch, eng, hipla, sysm, A, B, its=60, warm=10):
                    + 2 * 16 * n + 16 * n)                                                                   # gathers of x, y; scatter of y
     spmv_bytes = lambda i: i["algorithmic_bytes"]
     aux_bytes = spmv_bytes(aux.transform.handle.info()) + spmv_bytes(aux.transform_t.handle.info())
-    for comp in aux.components:
+    # components that share one hierarchy are cycled together (csrc/amg.hip: csr_multi_kernel): every level operator
+    # is read once (4-byte columns), the vectors K times
+    together = len(set(id(c) for c in aux.components)) == 1 and len(aux.components) in (2, 3) \
+        and os.environ.get("NSS_AMG_BATCH", "1") != "0" and len(aux.components[0].levels) >= 2
+    ncomp = len(aux.components)
+    multi_bytes = lambda i: 12 * i["nnz"] + 4 * (i["rows"] + 1) + 8 * ncomp * (i["rows"] + i["cols"])
+    for comp in (aux.components[:1] if together else aux.components):
+        one = multi_bytes if together else spmv_bytes
         for lv in comp.levels:
-            aux_bytes += spmv_bytes(lv["inv"].handle.info()) if "inv" in lv else (
-                2 * spmv_bytes(lv["A"].handle.info()) + spmv_bytes(lv["P"].handle.info()) + spmv_bytes(lv["R"].handle.info())
-                + 8 * 6 * lv["n"])
+            aux_bytes += one(lv["inv"].handle.info()) if "inv" in lv else (
+                2 * one(lv["A"].handle.info()) + one(lv["P"].handle.info()) + one(lv["R"].handle.info())
+                + 8 * 6 * lv["n"] * (ncomp if together else 1))
 
     def roof(nbytes, ms):
         gbs = nbytes / (ms * 1e-3) / 1e9
@@ -279,8 +286,10 @@ def mypre_a_gs_roofline(torch, eng, hipla, sysm, A, B, its=60, warm=10):
             "scale_factor_k": ses.k, "C1_with_whole_preA_ms_in_loop": c1_ms,
             "sweep_call": dict(roof(sweep_bytes, sweep_ms), kernel="gs_enter + csr_stream_kernel<EpiGsFused> x %d colours + "
                                "gs_leave (one Smooth / SmoothBack call)" % preA.ncolors, calls_per_iteration=2),
-            "auxiliary_space_term": dict(roof(aux_bytes, aux_ms), kernel="T^T SpMV, %d smoothed-aggregation V(1,1)-cycles, "
-                                         "T SpMV (nss_amg_create_auxiliary)" % len(aux.components), calls_per_iteration=1),
+            "auxiliary_space_term": dict(roof(aux_bytes, aux_ms), kernel="T^T SpMV, %d smoothed-aggregation V(1,1)-cycles%s, "
+                                         "T SpMV (nss_amg_create_auxiliary)"
+                                         % (ncomp, " cycled together: every level operator read once (csr_multi_kernel)" if together else ""),
+                                         calls_per_iteration=1),
             "setup_s": {"amg_hierarchies_colouring_permutation": t_pre, "scale_factor_initial_residual": t_setup},
             "valid": valid}
 

@@ -282,6 +282,10 @@ NSS_API int nss_amg_create(int32_t nlevels, const nss_amg_level_t* h_levels, nss
  * wherever a V-cycle handle is (nss_amg_apply_f64, pre_amg of the fused loops). */
 NSS_API int nss_amg_create_auxiliary(nss_csr_t T, nss_csr_t TT, int32_t ncomp, const nss_amg_t* h_comps,
                                      nss_amg_t* out);
+/* Components that share ONE hierarchy handle (the same Laplacian and boundary conditions for every velocity component)
+ * are cycled together: every level operator is read once for all right-hand sides (csrc/amg.hip: csr_multi_kernel,
+ * 2 or 3 components).  on = 0 cycles them one after the other as round 2 did (tests, A/B runs); default 1. */
+NSS_API int nss_amg_batch_components(int32_t on);
 NSS_API int nss_amg_destroy(nss_amg_t a);
 /* x = V(bscale * b);  b and x have the finest level's size and must not alias */
 NSS_API int nss_amg_apply_f64(nss_amg_t a, double bscale, const double* b, double* x, nss_stream_t stream);

@@ -31,6 +31,14 @@ struct nss_amg_s {
   std::vector<const nss_amg_s*> comps;
   std::vector<int32_t> comp_off;     // comps.size() + 1 offsets into the stacked auxiliary vector
   double *aux_r = nullptr, *aux_z = nullptr;
+  // Components that share ONE hierarchy (the same Laplacian with the same boundary conditions for every velocity
+  // component: the usual case) are cycled TOGETHER: every level operator is read once for all K right-hand sides
+  // (amg.hip: csr_multi_kernel).  The cycle's internal vectors are interleaved [row][K]; the stacked auxiliary vectors
+  // at its two ends are addressed with strides.  Work vectors per level of the shared hierarchy (K * n doubles each):
+  struct MultiLevel {
+    double *x = nullptr, *r = nullptr, *b = nullptr, *y = nullptr;
+  };
+  std::vector<MultiLevel> multi;     // empty: components are cycled one after the other
 };
 
 namespace nss {

@@ -198,6 +198,10 @@ void compress_columns(nss_csr_s& A, hipStream_t st);
 
 bool direct_rows_candidate(int32_t m, const int32_t* rowptr);
 
+// New launch plan with at most `products` products per row block (set-up only: synchronises the device and rebuilds
+// every derived column stream); per-row sums keep their bits.
+void replan_row_blocks(nss_csr_s& A, int products);
+
 // Launch plan of a CSR matrix: lanes per row (*rg_out) and the row-block boundaries (spmv.hip).
 // `products`: products per row block to aim at (<= kChunk; the lanes-per-row choice does not depend on it, so the
 // per-row sums of a re-planned matrix keep their bits)

@@ -793,6 +793,14 @@ static void replan(nss_csr_s& A, int products, int max_rows = 0, const uint8_t* 
   if (blk_out) blk_out->swap(blk);
 }
 
+extern "C++" {
+namespace nss {
+void replan_row_blocks(nss_csr_s& A, int products) {
+  if (A.blk_products != products) replan(A, products);
+}
+}  // namespace nss
+}
+
 int nss_csr_plan_for_pairs(nss_csr_t a, int32_t* pair_staged) {
   return guarded([&] {
     NSS_REQUIRE(a != nullptr, "csr_plan_for_pairs: NULL matrix");

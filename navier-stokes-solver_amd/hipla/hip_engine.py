@@ -130,6 +130,7 @@ def _signatures():
         "nss_minres_iterate_dist": (C.c_int, [vp, vp, vp, vp, i32, i32, vp]),
         "nss_minres_fold_mode": (C.c_int, [i32]),
         "nss_lanczos_fold_mode": (C.c_int, [i32]),
+        "nss_amg_batch_components": (C.c_int, [i32]),
         "nss_bpcg2_fuse_block_jacobi": (C.c_int, [i32]),
         "nss_bpcg2_c1_applies_preA": (C.c_int, [vp, c_i32_p]),
         "nss_csr_plan_for_blocks": (C.c_int, [vp, vp, c_i32_p]),
@@ -170,6 +171,8 @@ def load_library(path=None):
                 getattr(lib, name)(int(os.environ["NSS_FOLD_SUMS"]))
     if os.environ.get("NSS_FUSE_BJAC") and hasattr(lib, "nss_bpcg2_fuse_block_jacobi"):   # measurements: 0 / 1
         lib.nss_bpcg2_fuse_block_jacobi(int(os.environ["NSS_FUSE_BJAC"]))
+    if os.environ.get("NSS_AMG_BATCH") and hasattr(lib, "nss_amg_batch_components"):      # measurements: 0 / 1
+        lib.nss_amg_batch_components(int(os.environ["NSS_AMG_BATCH"]))
     if os.environ.get("NSS_LANCZOS_FOLD") and hasattr(lib, "nss_lanczos_fold_mode"):      # measurements: -1 / 0 / 1
         lib.nss_lanczos_fold_mode(int(os.environ["NSS_LANCZOS_FOLD"]))
     return lib

@@ -1522,6 +1522,57 @@ def test_mypre_a_mult_against_the_oracle(hip_engine):
                 assert np.linalg.norm(got - want) < tol * np.linalg.norm(want), (s.n_u, gs, tol)
 
 
+def test_components_sharing_a_hierarchy_are_cycled_together(hip_engine):
+    """The auxiliary-space term `T (sum_c E_c V_c E_c^T) T^T` (templates/NavierStokesSIMPLE_iterative.py:336-337,357,
+    380,383): components whose Laplacians are the same matrix share one hierarchy and are cycled TOGETHER -- every
+    level operator read once for all right-hand sides (csrc/amg.hip: csr_multi_kernel, interleaved work vectors) --
+    instead of one V-cycle after the other.  Same cycle, another summation order inside a row: 1e-13 against the
+    component-by-component form, 2 and 3 components, several levels, plain and accumulating applies, inside the fused
+    BPCG loop with MypreA(GS=True)."""
+    import hipla
+    from solvers.bramblepasciak_new import BpcgSession
+    from templates.NavierStokesSIMPLE_iterative import MypreA, auxiliary_space_preconditioner
+    lib = hip_engine.lib
+    try:
+        for dim, n, min_levels in ((2, 300, 3), (3, 40, 2)):
+            s = mac_stokes(dim, n, 0.01)
+            _, _, aux = auxiliary_space_preconditioner(s)
+            assert len(set(id(c) for c in aux.components)) == 1 and len(aux.components) == dim
+            assert len(aux.components[0].level_sizes) >= min_levels, aux.components[0].level_sizes
+            x = hipla.Vector.from_numpy(np.random.default_rng(3).standard_normal(s.n_u))
+            out = {}
+            for on in (0, 1):
+                hip_engine._check(lib.nss_amg_batch_components(on))
+                y = hipla.Vector(s.n_u)
+                aux.Mult(x, y)
+                z = hipla.Vector.from_numpy(np.ones(s.n_u))
+                aux.MultAdd(0.5, x, z)
+                out[on] = (y.numpy(), z.numpy())
+            for a, b in zip(out[0], out[1]):
+                assert np.linalg.norm(a - b) <= 1e-13 * np.linalg.norm(a)
+            # ... and inside the fused loop (multiplicative MypreA: the term is applied to the residual between the sweeps)
+            f, g = s.rhs(0)
+            A, B = hipla.SparseMatrix.from_scipy(s.A), hipla.SparseMatrix.from_scipy(s.B)
+            hist = {}
+            for on in (0, 1):
+                hip_engine._check(lib.nss_amg_batch_components(on))
+                preA = MypreA(None, Form(A), s.line_blocks(3), GS=True, aux=aux)
+                sol = hipla.BlockVector([hipla.Vector(s.n_u), hipla.Vector(s.n_p)])
+                with contextlib.redirect_stdout(io.StringIO()):
+                    ses = BpcgSession(Form(A), Form(B), None, hipla.Vector.from_numpy(f), hipla.Vector.from_numpy(g), preA,
+                                      hipla.DiagonalMatrix(1.0 / s.mass), sol=sol)
+                assert ses.fused is not None
+                ses.first_direction()
+                ses.fused.start(ses.wdn, ses.err0, 0.0, True, 25)
+                ses.fused.enqueue(0, 25)
+                ses.fused.poll()
+                hist[on] = ses.fused.history(24).copy()
+            np.testing.assert_allclose(hist[1], hist[0], rtol=1e-9)
+            assert hist[1][-1] < 1e-1 * hist[1][0]
+    finally:
+        lib.nss_amg_batch_components(1)
+
+
 def test_fused_cg_solver(hip_engine):
     """hipla.CGSolver on native operands takes the device-resident loop (nss_cg_*): same history as
     the protocol loop, all preconditioner kinds, config-1 CG against the golden."""
