@@ -54,6 +54,8 @@ static void cycle(const nss_amg_s& a, int l, const double* b, double* out, hipSt
 // interleaved [row][K] (one 8 K-byte gather per entry), what the epilogue reads and writes is addressed with strides
 // (VecK) so that the stacked auxiliary vectors at the two ends of the cycle need no transposition pass.
 constexpr int kMultiChunk = 1024;
+constexpr int kMultiPlane = kMultiChunk + 1;   // the K planes of products in LDS, one bank apart: the lanes of the K pairs of
+                                               // a row read the same offset of their planes at the same time
 
 struct VecK {
   double* p;
@@ -66,7 +68,7 @@ struct VecK {
 // the matrix stream so that their latency hides behind it.
 template <int K, class Epi>
 __global__ __launch_bounds__(kBlock) void csr_multi_kernel(CsrView a, const double* __restrict__ x, Epi epi) {
-  __shared__ double prod[K * kMultiChunk];
+  __shared__ double prod[K * kMultiPlane];
   __shared__ double red[kRedDoubles];
   if (epi.skip()) return;
   const int tid = threadIdx.x, wg = int(blockIdx.x);
@@ -110,7 +112,7 @@ __global__ __launch_bounds__(kBlock) void csr_multi_kernel(CsrView a, const doub
       const int i = tid + q * kBlock;
       if (i < cnt) {
 #pragma unroll
-        for (int k = 0; k < K; ++k) prod[k * kMultiChunk + i] = vv[q] * xv[q][k];
+        for (int k = 0; k < K; ++k) prod[k * kMultiPlane + i] = vv[q] * xv[q][k];
       }
     }
     __syncthreads();
@@ -119,7 +121,7 @@ __global__ __launch_bounds__(kBlock) void csr_multi_kernel(CsrView a, const doub
       const int idx = tid + q * kBlock;
       if (idx < pairs) {
         const int i = r0 + idx / K, k = idx % K;
-        const double* __restrict__ plane = prod + k * kMultiChunk - p0;
+        const double* __restrict__ plane = prod + k * kMultiPlane - p0;
         double sum = 0.0;
         for (int j = ps[q]; j < pe[q]; ++j) sum += plane[j];
         epi.elem(i, k, sum, pre[q]);
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(kBlock) void csr_multi_kernel(CsrView a, const doub
     }
     for (int idx = tid + kPF * kBlock; idx < pairs; idx += kBlock) {   // short rows: more pairs than prefetch slots
       const int i = r0 + idx / K, k = idx % K;
-      const double* __restrict__ plane = prod + k * kMultiChunk - p0;
+      const double* __restrict__ plane = prod + k * kMultiPlane - p0;
       double sum = 0.0;
       for (int j = a.rowptr[i]; j < a.rowptr[i + 1]; ++j) sum += plane[j];
       epi.elem(i, k, sum, epi.fetch(i, k));
