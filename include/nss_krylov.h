@@ -674,7 +674,10 @@ NSS_API int nss_minres_iterate_dist(const nss_minres_t* s, nss_dist_t d, const n
 NSS_API int nss_minres_fold_mode(int32_t mode);
 /* the same kind of override for applying a block-Jacobi preA (runs of consecutive dofs) inside the
  * element-wise kernel M3 instead of as its own launch: automatic = in the launch-bound regime only.
- * The dot partials are grouped differently in the two forms: results agree to rounding, not bitwise. */
+ * The dot partials are grouped differently in the two forms: results agree to rounding, not bitwise.
+ * Round 3: the same regime also runs the rows of B^T INSIDE the launch of A's rows when B^T has at most two entries
+ * per row (a fixed-width copy, built on first use; the rows of B share the launch): three dependent launches per
+ * iteration.  That part keeps every bit (mode 2 = merged rows only, block Jacobi apart: for tests). */
 NSS_API int nss_minres_fuse_mode(int32_t mode);
 
 /* ---- fused Bramble-Pasciak CG, textbook form ------------------------------------------------

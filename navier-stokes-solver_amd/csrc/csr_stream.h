@@ -170,6 +170,13 @@ struct nss_csr_s {
   // the first Jacobi block of row block b (nblk + 1 entries); jb_serial = nss_bjac_s::serial of that handle.
   int32_t* jb_first = nullptr;
   int32_t* jb_order = nullptr;
+  // Fixed-width copy for EPILOGUE use (nss::fixed_width_copy, built on first request): the kDirectWidth (column,
+  // value) slots per row of a matrix with at most that many entries per row, whatever its size -- a kernel over the
+  // rows of ANOTHER matrix with the same row count can then add this matrix's row product from registers (fused
+  // MINRES: B^T z1 inside the rows of A).  Aliases ell_col / ell_val when those exist.  fw_state: 0 not tried, 1, -1.
+  int32_t* fw_col = nullptr;
+  double* fw_val = nullptr;
+  int fw_state = 0;
   uint64_t jb_serial = 0;
   // `stageable`: the kernel's operand functor is one stored vector that can be copied to LDS (XOp::kStageable);
   // `pairable`: it is an expression of two (XOp::kStageablePair)
@@ -197,6 +204,9 @@ namespace nss {
 void compress_columns(nss_csr_s& A, hipStream_t st);
 
 bool direct_rows_candidate(int32_t m, const int32_t* rowptr);
+
+// the fixed-width copy of A for epilogue use (see nss_csr_s::fw_col); false when a row has more than kDirectWidth entries
+bool fixed_width_copy(nss_csr_s& A);
 
 // New launch plan with at most `products` products per row block (set-up only: synchronises the device and rebuilds
 // every derived column stream); per-row sums keep their bits.

@@ -5,6 +5,9 @@
 //   M1  rows of B^T and rows of B in ONE launch (neither depends on the other):
 //         kz0 = B^T z1;   kz1 = B z0, partial <kz1, z1>                                 (:97-98)
 //   M2  rows of A   : kz0 += A z0, partial <kz0, z0>                                    (:97-98)
+//       Launch-bound systems whose B^T has at most two entries per row (the staggered grids) run M1 + M2 as ONE
+//       launch: the rows of A add their row of B^T z1 from a fixed-width copy in the epilogue (same products, same
+//       order of additions: identical bits), the rows of B share the launch -- three dependent launches per iteration.
 //   M3  element-wise, delta = sum of the partials first (in every workgroup when the sum is short,
 //        else from the stand-alone sum kernel): v_new = kz - delta v - gamma v_old (:99);
 //        z_new = C v_new (:101) -- point Jacobi and preS fused; block Jacobi over runs of
@@ -94,6 +97,49 @@ struct EpiMAccDot {  // y (+)= A (scale * x) ; partial <y, scale * z>
   __device__ Pre fetch(int r) const { return Pre{accumulate ? y[r] : 0.0, z[r]}; }   // (before the prologue)
   __device__ void row(int r, double ax, const Pre& p) {
     const double t = accumulate ? p.y + ax : ax;
+    y[r] = t;
+    acc = fma(t, p.z * sz, acc);
+  }
+  __device__ void finish(int b, double* lds) {
+    const double s = block_sum(acc, lds);
+    if (threadIdx.x == 0 && b >= 0) partials[b] = s;
+  }
+};
+
+// rows of A with the row of B^T z1 added in the epilogue: kz0 = B^T (sz z1) + A (sz z0), partial <kz0, sz z0>.
+// B^T's row comes from its fixed-width copy (two slots per row, column -1 = unused) and is summed exactly as
+// csr_direct_kernel sums it (0 + p0 + p1, products rounded on their own); then bts + az as M2 did.
+struct EpiMRowsA {
+  const int32_t* __restrict__ ctrl;
+  int k;
+  double* __restrict__ y;
+  const double* __restrict__ z;
+  double* __restrict__ partials;
+  const double* __restrict__ set;
+  const int32_t* __restrict__ ecol;
+  const double* __restrict__ eval;
+  const double* __restrict__ z1;
+  double acc = 0.0;
+  double sz = 1.0;
+  __device__ bool skip() const { return minres_skip(ctrl, k); }
+  __device__ bool prologue(double*) {
+    sz = set[M_SZ];
+    return true;
+  }
+  using X = XScaledZ;
+  __device__ X xop(const double* x) const { return X{x, sz}; }
+  struct Pre { double z = 0.0, v0 = 0.0, v1 = 0.0, x0 = 0.0, x1 = 0.0; bool h0 = false, h1 = false; };
+  __device__ Pre fetch(int r) const {                        // (before the prologue: raw z1, scaled in row())
+    typedef int32_t int2v __attribute__((ext_vector_type(2)));
+    const int2v c = reinterpret_cast<const int2v*>(ecol)[r];
+    const dbl2v v = reinterpret_cast<const dbl2v*>(eval)[r];
+    return Pre{z[r], v.x, v.y, c.x >= 0 ? z1[c.x] : 0.0, c.y >= 0 ? z1[c.y] : 0.0, c.x >= 0, c.y >= 0};
+  }
+  __device__ void row(int r, double ax, const Pre& p) {
+    double bts = 0.0;
+    if (p.h0) bts += mul_unfused(p.v0, p.x0 * sz);
+    if (p.h1) bts += mul_unfused(p.v1, p.x1 * sz);
+    const double t = bts + ax;
     y[r] = t;
     acc = fma(t, p.z * sz, acc);
   }
@@ -383,6 +429,7 @@ static int m3_gu(const nss_minres_t& s) {
 }
 
 constexpr int kMFoldMax = 1024;      // as kFoldMax of bpcg2.hip (measured there and here: 1e6 DoF +9 % unfolded)
+constexpr int kMMergeMaxRows = 1 << 22;   // rows of B^T inside the launch of A's rows up to this many velocity rows
 constexpr int kMFuseMax = 4096;      // the block Jacobi fused into M3 still pays at 1e6 DoF (+5 %)
 static int g_minres_fold_mode = -1;
 static bool m_small(const nss_minres_t& s, int limit) {       // launch-bound regime: every sum of the iteration is short
@@ -401,8 +448,19 @@ static bool m_fold(const nss_minres_t& s) {
 // bandwidth does (1e7 DoF: -6 %).  Automatic: fuse exactly in the launch-bound regime.
 static bool m_fused_bjac(const nss_minres_t& s) {
   if (!m_fusable_bjac(s)) return false;
-  if (g_minres_fuse_mode >= 0) return g_minres_fuse_mode != 0;
+  if (g_minres_fuse_mode >= 0) return g_minres_fuse_mode == 1;
   return m_small(s, kMFuseMax);
+}
+
+// M1 + M2 as one launch (see the head of the file): in the launch-bound regime, when B^T has a fixed-width copy
+static bool m_merged_rows(const nss_minres_t& s, bool dist) {
+  if (dist || s.local_sums) return false;                    // row-partitioned: B^T's operand has its own halo
+  if (g_minres_fuse_mode == 0) return false;
+  // measured over 1e4 ... 1e7 DoF (profiles/r03_minres_sizes.txt): -27 % per iteration at 1e5 DoF, -16 % at 1.2e6,
+  // -9 % at 4e6, nothing either way at 1e7 -- the launch and the round trip of kz0 it saves against the wider
+  // epilogue of A's rows
+  if (g_minres_fuse_mode < 0 && s.A->m > kMMergeMaxRows) return false;
+  return s.BT->m == s.A->m && fixed_width_copy(*s.BT);
 }
 
 static void minres_check(const nss_minres_t* s) {
@@ -456,13 +514,21 @@ static void minres_iteration(const nss_minres_t& s, int k, hipStream_t st, int f
     exchange(*dist->d, h0, st, &h1);
   }
   // M1: kz0 = B^T z1 and kz1 = B z0 with <kz1, z1>;  M2: kz0 += A z0 with <kz0, z0>
-  EpiMStore e_bt{s.ctrl, k, s.kz[0], set};
   EpiMAccDot e_b{s.ctrl, k, 0, s.kz[1], s.z[zc][1], s.partials_b, set};
+  if (m_merged_rows(s, dist != nullptr)) {                   // one launch: rows of A (+ their row of B^T z1) and rows of B
+    EpiMRowsA e_a{s.ctrl, k, s.kz[0], s.z[zc][0], s.partials_a, set, s.BT->fw_col, s.BT->fw_val, s.z[zc][1]};
+    if (!launch_csr_stream_dual(*s.A, s.z[zc][0], e_a, *s.B, s.z[zc][0], e_b, st)) {
+      launch_csr_stream(*s.A, s.z[zc][0], e_a, st);
+      launch_csr_stream(*s.B, s.z[zc][0], e_b, st);
+    }
+  } else {
+  EpiMStore e_bt{s.ctrl, k, s.kz[0], set};
   if (!launch_csr_stream_dual(*s.BT, s.z[zc][1], e_bt, *s.B, s.z[zc][0], e_b, st)) {
     launch_csr_stream(*s.BT, s.z[zc][1], e_bt, st);
     launch_csr_stream(*s.B, s.z[zc][0], e_b, st);
   }
   launch_csr_stream(*s.A, s.z[zc][0], EpiMAccDot{s.ctrl, k, 1, s.kz[0], s.z[zc][0], s.partials_a, set}, st);
+  }
   }
   if (on(2) && !fold) {
     hipLaunchKernelGGL(minres_sum_kernel, dim3(1), dim3(kSumLanes), 0, st, s.ctrl, k, s.A->nblk, s.partials_a,
@@ -601,7 +667,7 @@ int nss_minres_fold_mode(int32_t mode) {
 
 int nss_minres_fuse_mode(int32_t mode) {
   return guarded([&] {
-    NSS_REQUIRE(mode >= -1 && mode <= 1, "minres_fuse_mode: -1 (automatic), 0 (never) or 1 (always)");
+    NSS_REQUIRE(mode >= -1 && mode <= 2, "minres_fuse_mode: -1 (automatic), 0 (never), 1 (always) or 2 (merged rows only)");
     g_minres_fuse_mode = mode;
   });
 }

@@ -749,6 +749,10 @@ int nss_csr_destroy(nss_csr_t a) {
     (void)hipFree(a->ell_val);
     (void)hipFree(a->jb_first);
     (void)hipFree(a->jb_order);
+    if (a->fw_col != a->ell_col) {
+      (void)hipFree(a->fw_col);
+      (void)hipFree(a->fw_val);
+    }
     delete a;
   });
 }
@@ -763,6 +767,13 @@ static void replan(nss_csr_s& A, int products, int max_rows = 0, const uint8_t* 
   int32_t rg = 1, chunk = kChunk;
   plan_row_blocks(A.m, A.nnz, h_rowptr.data(), &rg, &chunk, blk, A.cuts.data(), int(A.cuts.size()), products, max_rows,
                   row_pos);
+  if (A.fw_col != A.ell_col) {                            // (an own fixed-width copy; an alias of ell_col goes with it below)
+    (void)hipFree(A.fw_col);
+    (void)hipFree(A.fw_val);
+  }
+  A.fw_col = nullptr;
+  A.fw_val = nullptr;
+  A.fw_state = 0;
   (void)hipFree(A.jb_first);                             // a plan around Jacobi blocks ends with the plan
   (void)hipFree(A.jb_order);
   A.jb_first = nullptr;
@@ -795,6 +806,47 @@ static void replan(nss_csr_s& A, int products, int max_rows = 0, const uint8_t* 
 
 extern "C++" {
 namespace nss {
+bool fixed_width_copy(nss_csr_s& A) {
+  if (A.fw_state != 0) return A.fw_state > 0;
+  A.fw_state = -1;
+  if (A.ell_col) {
+    A.fw_col = A.ell_col;
+    A.fw_val = A.ell_val;
+    A.fw_state = 1;
+    return true;
+  }
+  if (A.m == 0 || A.nnz > int64_t(kDirectWidth) * A.m) return false;
+  int32_t* ecol = nullptr;
+  double* eval = nullptr;
+  int32_t* wide = nullptr;
+  int32_t h_wide = 1;
+  try {
+    NSS_HIP(hipMalloc(&ecol, sizeof(int32_t) * size_t(A.m) * kDirectWidth));
+    NSS_HIP(hipMalloc(&eval, sizeof(double) * size_t(A.m) * kDirectWidth));
+    NSS_HIP(hipMalloc(&wide, sizeof(int32_t)));
+    NSS_HIP(hipMemset(wide, 0, sizeof(int32_t)));
+    hipLaunchKernelGGL(ell_build_kernel, dim3(stream_grid(A.m, kBlock * 4)), dim3(kBlock), 0, nullptr, A.m, A.rowptr, A.col,
+                       A.val, ecol, eval, wide);
+    NSS_CHECK_LAUNCH();
+    NSS_HIP(hipMemcpy(&h_wide, wide, sizeof(int32_t), hipMemcpyDeviceToHost));
+  } catch (...) {
+    (void)hipFree(ecol);
+    (void)hipFree(eval);
+    (void)hipFree(wide);
+    throw;
+  }
+  (void)hipFree(wide);
+  if (h_wide != 0) {
+    (void)hipFree(ecol);
+    (void)hipFree(eval);
+    return false;
+  }
+  A.fw_col = ecol;
+  A.fw_val = eval;
+  A.fw_state = 1;
+  return true;
+}
+
 void replan_row_blocks(nss_csr_s& A, int products) {
   if (A.blk_products != products) replan(A, products);
 }

@@ -878,6 +878,46 @@ def test_minres_sum_placement_gives_identical_bits(hip_engine, case):
     check_iterations(len(outs[0][0]) - 1, d["iterations"], d)
 
 
+@pytest.mark.parametrize("case", ["stokes3d_n10_bjac_minres", "stokes2d_n24_jacobi_minres",
+                                  "stokes3d_n5_facet_x12_minres"])
+def test_minres_merged_launches_give_identical_bits(hip_engine, case):
+    """Launch-bound systems run the fused MINRES iteration (minres.py:96-144) in three dependent launches: the rows of
+    A add their row of B^T z1 from a fixed-width copy in the epilogue (B^T of the staggered grids has two entries per
+    row) and share the launch with the rows of B (nss_minres_fuse_mode).  Same products, same order of additions as
+    the round-2 form: with the block Jacobi kept apart (mode 2) errors and solution agree BIT FOR BIT with mode 0;
+    with the block Jacobi inside M3 as well (mode 1, what small systems run) the dot partials are grouped differently
+    and the history agrees to rounding; every form matches the golden.  An operator whose B^T is wider (facet blocks)
+    keeps its own rows launch."""
+    import hipla
+    from minres import MinRes
+    d = np.load(golden_path(case))
+    c, _, A, B, preA, preS = case_operands(d)
+    K = hipla.BlockMatrix([[A, B.T], [B, None]])
+    Cm = hipla.BlockMatrix([[preA, None], [None, preS]])
+    lib = hip_engine.lib
+    outs = {}
+    try:
+        for mode in (0, 2, 1):
+            assert lib.nss_minres_fuse_mode(mode) == 0
+            with contextlib.redirect_stdout(io.StringIO()), fused_loops_counted() as counts:
+                u, errors = MinRes(mat=K, pre=Cm, rhs=hipla.BlockVector([hipla.Vector.from_numpy(c.f),
+                                                                         hipla.Vector.from_numpy(c.g)]),
+                                   maxsteps=int(d["maxsteps"]), tol=float(d["tol"]), printrates=False)
+            assert counts["minres"] == 1
+            outs[mode] = (np.array(errors), u.numpy())
+    finally:
+        lib.nss_minres_fuse_mode(-1)
+    np.testing.assert_array_equal(outs[2][0], outs[0][0])
+    np.testing.assert_array_equal(outs[2][1], outs[0][1])
+    w = min(25, len(outs[1][0]), len(outs[0][0]))           # (rounding differences grow along a Krylov history)
+    np.testing.assert_allclose(outs[1][0][:w], outs[0][0][:w], rtol=1e-7)
+    for mode in (0, 1):
+        check_history(outs[mode][0], d["errors"], d["window"])
+        check_iterations(len(outs[mode][0]) - 1, d["iterations"], d)
+    info = B.T.handle.info()
+    assert (info["nnz"] <= 2 * info["rows"]) == ("facet" not in case)
+
+
 def test_drivers_on_gpu(hip_engine, tmp_path):
     """Harness / driver shape on the product engine: NavierStokes.SolveInitial takes the fused
     loop, run.py writes the reference's CSV columns, stokes_hcurldiv's call converges."""
