@@ -886,8 +886,8 @@ def test_minres_merged_launches_give_identical_bits(hip_engine, case):
     row) and share the launch with the rows of B (nss_minres_fuse_mode).  Same products, same order of additions as
     the round-2 form: with the block Jacobi kept apart (mode 2) errors and solution agree BIT FOR BIT with mode 0;
     with the block Jacobi inside M3 as well (mode 1, what small systems run) the dot partials are grouped differently
-    and the history agrees to rounding; every form matches the golden.  An operator whose B^T is wider (facet blocks)
-    keeps its own rows launch."""
+    and the history agrees to rounding; every form matches the golden (plain grids and the facet-block inflation, whose
+    B^T keeps two entries per row)."""
     import hipla
     from minres import MinRes
     d = np.load(golden_path(case))
@@ -914,8 +914,6 @@ def test_minres_merged_launches_give_identical_bits(hip_engine, case):
     for mode in (0, 1):
         check_history(outs[mode][0], d["errors"], d["window"])
         check_iterations(len(outs[mode][0]) - 1, d["iterations"], d)
-    info = B.T.handle.info()
-    assert (info["nnz"] <= 2 * info["rows"]) == ("facet" not in case)
 
 
 def test_drivers_on_gpu(hip_engine, tmp_path):
