@@ -66,7 +66,9 @@ struct VecK {
 // Phase 2 gives every (row, k) pair a lane (k fastest: the interleaved vectors are then read and written with unit
 // stride, the stacked ones as K unit-stride streams); the pair's row bounds and epilogue operands are requested BEFORE
 // the matrix stream so that their latency hides behind it.
-template <int K, class Epi>
+// L lanes share a pair when rows are long (the Galerkin operators of the coarser levels: ~30 entries per row, where one
+// lane per pair would leave most of the workgroup idle while it adds up its products).
+template <int K, int L, class Epi>
 __global__ __launch_bounds__(kBlock) void csr_multi_kernel(CsrView a, const double* __restrict__ x, Epi epi) {
   __shared__ double prod[K * kMultiPlane];
   __shared__ double red[kRedDoubles];
@@ -79,17 +81,19 @@ __global__ __launch_bounds__(kBlock) void csr_multi_kernel(CsrView a, const doub
   const int p0 = a.rowptr[r0], cnt = a.rowptr[r1] - p0;
   if (cnt <= kMultiChunk) {
     constexpr int kPF = 2;                                             // pairs per lane whose operands are prefetched
+    constexpr int kLanePairs = kBlock / L;                             // pairs per pass of the workgroup
     const int pairs = (r1 - r0) * K;
+    const int sub = tid % L, slot = tid / L;
     int ps[kPF], pe[kPF];
     typename Epi::Pre pre[kPF];
 #pragma unroll
     for (int q = 0; q < kPF; ++q) {
-      const int idx = tid + q * kBlock;
+      const int idx = slot + q * kLanePairs;
       if (idx < pairs) {
         const int i = r0 + idx / K, k = idx % K;
         ps[q] = a.rowptr[i];
         pe[q] = a.rowptr[i + 1];
-        pre[q] = epi.fetch(i, k);
+        if (sub == 0) pre[q] = epi.fetch(i, k);
       }
     }
     // all loads of the lane's entries are requested before the first product (as the single-vector stream kernel does)
@@ -116,23 +120,28 @@ __global__ __launch_bounds__(kBlock) void csr_multi_kernel(CsrView a, const doub
       }
     }
     __syncthreads();
+    // (whole groups of L lanes take the same branch: the shuffles below stay inside a group)
 #pragma unroll
     for (int q = 0; q < kPF; ++q) {
-      const int idx = tid + q * kBlock;
+      const int idx = slot + q * kLanePairs;
       if (idx < pairs) {
         const int i = r0 + idx / K, k = idx % K;
         const double* __restrict__ plane = prod + k * kMultiPlane - p0;
         double sum = 0.0;
-        for (int j = ps[q]; j < pe[q]; ++j) sum += plane[j];
-        epi.elem(i, k, sum, pre[q]);
+        for (int j = ps[q] + sub; j < pe[q]; j += L) sum += plane[j];
+#pragma unroll
+        for (int off = L / 2; off > 0; off >>= 1) sum += __shfl_xor(sum, off, kWave);
+        if (sub == 0) epi.elem(i, k, sum, pre[q]);
       }
     }
-    for (int idx = tid + kPF * kBlock; idx < pairs; idx += kBlock) {   // short rows: more pairs than prefetch slots
+    for (int idx = slot + kPF * kLanePairs; idx < pairs; idx += kLanePairs) {   // more pairs than prefetch slots
       const int i = r0 + idx / K, k = idx % K;
       const double* __restrict__ plane = prod + k * kMultiPlane - p0;
       double sum = 0.0;
-      for (int j = a.rowptr[i]; j < a.rowptr[i + 1]; ++j) sum += plane[j];
-      epi.elem(i, k, sum, epi.fetch(i, k));
+      for (int j = a.rowptr[i] + sub; j < a.rowptr[i + 1]; j += L) sum += plane[j];
+#pragma unroll
+      for (int off = L / 2; off > 0; off >>= 1) sum += __shfl_xor(sum, off, kWave);
+      if (sub == 0) epi.elem(i, k, sum, epi.fetch(i, k));
     }
   } else {                            // one row longer than the chunk (the dense coarse inverse): the workgroup reduces it
     double acc[K];
@@ -218,7 +227,12 @@ __global__ __launch_bounds__(kBlock) void amg_diag_multi_kernel(int32_t n, doubl
 template <int K, class Epi>
 static void launch_multi(const nss_csr_s& A, const double* x, const Epi& epi, hipStream_t st) {
   if (A.m == 0 || A.nblk == 0) return;
-  hipLaunchKernelGGL((csr_multi_kernel<K, Epi>), dim3(nss_csr_s::grid(A.nblk)), dim3(kBlock), 0, st, A.view(0, A.nblk, 0), x, epi);
+  const dim3 grid(nss_csr_s::grid(A.nblk)), block(kBlock);
+  const CsrView v = A.view(0, A.nblk, 0);
+  const double mean = double(A.nnz) / double(A.m);                     // lanes per (row, k) pair by the mean row length
+  if (mean >= 48.0) hipLaunchKernelGGL((csr_multi_kernel<K, 4, Epi>), grid, block, 0, st, v, x, epi);
+  else if (mean >= 20.0) hipLaunchKernelGGL((csr_multi_kernel<K, 2, Epi>), grid, block, 0, st, v, x, epi);
+  else hipLaunchKernelGGL((csr_multi_kernel<K, 1, Epi>), grid, block, 0, st, v, x, epi);
   NSS_CHECK_LAUNCH();
 }
 
