@@ -453,8 +453,9 @@ static bool m_fused_bjac(const nss_minres_t& s) {
 }
 
 // M1 + M2 as one launch (see the head of the file): in the launch-bound regime, when B^T has a fixed-width copy
-static bool m_merged_rows(const nss_minres_t& s, bool dist) {
-  if (dist || s.local_sums) return false;                    // row-partitioned: B^T's operand has its own halo
+static bool m_merged_rows(const nss_minres_t& s) {
+  // (row-partitioned runs too: both operands' ghosts arrive in the one grouped exchange in front of the launch, and
+  // the fixed-width copy of the slab's B^T carries the column numbers of z1's [owned | ghosts] layout)
   if (g_minres_fuse_mode == 0) return false;
   // measured over 1e4 ... 1e7 DoF (profiles/r03_minres_sizes.txt): -27 % per iteration at 1e5 DoF, -16 % at 1.2e6,
   // -9 % at 4e6, nothing either way at 1e7 -- the launch and the round trip of kz0 it saves against the wider
@@ -515,7 +516,7 @@ static void minres_iteration(const nss_minres_t& s, int k, hipStream_t st, int f
   }
   // M1: kz0 = B^T z1 and kz1 = B z0 with <kz1, z1>;  M2: kz0 += A z0 with <kz0, z0>
   EpiMAccDot e_b{s.ctrl, k, 0, s.kz[1], s.z[zc][1], s.partials_b, set};
-  if (m_merged_rows(s, dist != nullptr)) {                   // one launch: rows of A (+ their row of B^T z1) and rows of B
+  if (m_merged_rows(s)) {                   // one launch: rows of A (+ their row of B^T z1) and rows of B
     EpiMRowsA e_a{s.ctrl, k, s.kz[0], s.z[zc][0], s.partials_a, set, s.BT->fw_col, s.BT->fw_val, s.z[zc][1]};
     if (!launch_csr_stream_dual(*s.A, s.z[zc][0], e_a, *s.B, s.z[zc][0], e_b, st)) {
       launch_csr_stream(*s.A, s.z[zc][0], e_a, st);

@@ -437,10 +437,12 @@ def test_native_partitioned_minres_single_rank(hip_engine, tmp_path, pre):
     lib = hip_engine.lib
     dist.init_process_group("gloo", init_method="file://" + str(tmp_path / "rdv"), rank=0, world_size=1)
     try:
-        assert lib.nss_minres_fold_mode(0) == 0 and lib.nss_minres_fuse_mode(0) == 0
-        ref = single_gpu_minres(s, pre, tol, maxsteps)
         comm = RcclComm(dist, hip_engine)
-        for native in (True, False):
+        # fuse mode 0: rows of B^T in their own launch half; 2: inside the launch of A's rows (round 3; the slab's
+        # fixed-width copy of B^T indexes z1's [owned | ghosts] layout) -- the block Jacobi apart in both
+        for fuse, native in ((0, True), (0, False), (2, True)):
+            assert lib.nss_minres_fold_mode(0) == 0 and lib.nss_minres_fuse_mode(fuse) == 0
+            ref = single_gpu_minres(s, pre, tol, maxsteps)
             run = DistributedMinres(s, f, g, s.line_blocks(3) if pre == "bjac" else None, dist, hip_engine, comm=comm,
                                     native=native)
             assert (run.native is not None) == native
