@@ -809,6 +809,18 @@ void bpcg2_spmv_phase(const nss_bpcg2_t& s, int which, int it, hipStream_t st, i
 
 // t1 = k * preA_unscaled t0 for everything that is not fused into K1's epilogue:
 // [AMG V-cycle] + [block Jacobi / block Gauss-Seidel | point Jacobi]  (additive MypreA, :383)
+// t1 = 0; J.Smooth(t1, k src)  (:377-378).  Colour-major layout: t1 is not zeroed and gathered -- the sweep starts from
+// zeros of its own and its first colour needs no pass over A (precond.h: kGsFromZero)
+static void gs_forward_from_zero(const nss_bpcg2_t& s, const double* src, hipStream_t st) {
+  if (s.pre_bjac->gs_permuted) {
+    bjac_smooth(*s.pre_bjac, s.k, src, s.t1, false, s.ctrl, st, kGsFromZero);
+    return;
+  }
+  hipLaunchKernelGGL(bpcg2_zero_kernel, dim3((s.n_u + kBlock - 1) / kBlock), dim3(kBlock), 0, st, s.ctrl, s.n_u, s.t1);
+  NSS_CHECK_LAUNCH();
+  bjac_smooth(*s.pre_bjac, s.k, src, s.t1, false, s.ctrl, st);
+}
+
 void bpcg2_k1_finish(const nss_bpcg2_t& s, hipStream_t st) {
   const double* src = s.t0;
   if (s.cond_HT) {                                   // harmonic_extension(): lift the residual first
@@ -820,13 +832,11 @@ void bpcg2_k1_finish(const nss_bpcg2_t& s, hipStream_t st) {
     // multiplicative MypreA on slabs (GS=True, :376-381): the sweeps run inside the slab (additive across slabs), the
     // residual between them with the partitioned A (halo exchange of the iterate), the auxiliary-space term on slabs
     const nss_dist_aux_s& aux = *s.pre_dist_aux;
-    hipLaunchKernelGGL(bpcg2_zero_kernel, dim3((s.n_u + kBlock - 1) / kBlock), dim3(kBlock), 0, st, s.ctrl, s.n_u, s.t1);
-    NSS_CHECK_LAUNCH();
-    bjac_smooth(*s.pre_bjac, s.k, src, s.t1, false, s.ctrl, st);
+    gs_forward_from_zero(s, src, st);
     exchange(*aux.d, aux.halo_y, st);
     launch_csr_stream(*s.A, s.t1, EpiScaledResidual{s.ctrl, s.k, src, s.t2}, st);
     dist_aux_apply(aux, 1.0, s.t2, s.t1, true, st, s.ctrl);
-    bjac_smooth(*s.pre_bjac, s.k, src, s.t1, true, s.ctrl, st);
+    bjac_smooth(*s.pre_bjac, s.k, src, s.t1, true, s.ctrl, st, s.pre_bjac->gs_permuted ? kGsKeepX : 0);   // (src again)
   } else if (s.pre_dist_aux) {                        // additive MypreA on slabs (:383)
     dist_aux_apply(*s.pre_dist_aux, s.k, src, s.t1, false, st, s.ctrl);
     if (s.pre_bjac) bjac_apply(*s.pre_bjac, s.k, src, 1.0, s.t1, s.ctrl, st);
@@ -839,12 +849,10 @@ void bpcg2_k1_finish(const nss_bpcg2_t& s, hipStream_t st) {
     // multiplicative MypreA (GS=True, :376-381) applied to k * t0:
     //   y = 0; J.Smooth(y, x); r = x - A y; y += M r; J.SmoothBack(y, x)        (t2 is free here: the
     //   previous iteration's t2 was consumed by K1 / C1 and the A-SpMV has not written the new one yet)
-    hipLaunchKernelGGL(bpcg2_zero_kernel, dim3((s.n_u + kBlock - 1) / kBlock), dim3(kBlock), 0, st, s.ctrl, s.n_u, s.t1);
-    NSS_CHECK_LAUNCH();
-    bjac_smooth(*s.pre_bjac, s.k, src, s.t1, false, s.ctrl, st);
+    gs_forward_from_zero(s, src, st);
     launch_csr_stream(*s.A, s.t1, EpiScaledResidual{s.ctrl, s.k, src, s.t2}, st);
     amg_apply(*s.pre_amg, 1.0, s.t2, s.t1, st, s.ctrl, true);
-    bjac_smooth(*s.pre_bjac, s.k, src, s.t1, true, s.ctrl, st);
+    bjac_smooth(*s.pre_bjac, s.k, src, s.t1, true, s.ctrl, st, s.pre_bjac->gs_permuted ? kGsKeepX : 0);   // (src again)
   } else if (s.pre_amg) {
     amg_apply(*s.pre_amg, s.k, src, s.t1, st, s.ctrl);
     if (s.pre_bjac) bjac_apply(*s.pre_bjac, s.k, src, 1.0, s.t1, s.ctrl, st);

@@ -349,11 +349,15 @@ static int lz_precondition(const nss_lanczos_t& s, const double* x, double* z, d
     return bjac_apply_dot(*s.pre_bjac, s.pre_scale, x, z, s.partials_b, done, st);
   if (multiplicative) {
     // MypreA with GS=True (templates/NavierStokesSIMPLE_iterative.py:376-381): y = 0; Smooth; r = x - A y; y += M r; SmoothBack
-    NSS_HIP(hipMemsetAsync(z, 0, sizeof(double) * size_t(s.n), st));
-    bjac_smooth(*s.pre_bjac, 1.0, x, z, false, done, st);
+    if (s.pre_bjac->gs_permuted) {
+      bjac_smooth(*s.pre_bjac, 1.0, x, z, false, done, st, kGsFromZero);
+    } else {
+      NSS_HIP(hipMemsetAsync(z, 0, sizeof(double) * size_t(s.n), st));
+      bjac_smooth(*s.pre_bjac, 1.0, x, z, false, done, st);
+    }
     launch_csr_stream(*s.A, z, EpiLzResidual{done, x, scratch}, st);
     amg_apply(*s.pre_amg, 1.0, scratch, z, st, done, true);
-    bjac_smooth(*s.pre_bjac, 1.0, x, z, true, done, st);
+    bjac_smooth(*s.pre_bjac, 1.0, x, z, true, done, st, s.pre_bjac->gs_permuted ? kGsKeepX : 0);
     if (s.pre_scale != 1.0) {
       hipLaunchKernelGGL(lanczos_scale_kernel, dim3(lz_grid(s)), dim3(kBlock), 0, st, done, s.n, s.pre_scale, z);
       NSS_CHECK_LAUNCH();

@@ -21,6 +21,7 @@ struct nss_bjac_s {
   const nss_csr_s* gs_mat = nullptr;      // rows of A permuted block by block, colour-major
   std::vector<int32_t> color_ptr;         // ncolors + 1 block offsets (host)
   std::vector<int32_t> color_rowblk;      // ncolors + 1 row-block offsets into gs_mat's launch plan (host)
+  std::vector<int32_t> color_row;         // ncolors + 1 row offsets of the colours in the permuted numbering (host)
   int32_t* rowdof = nullptr;              // device: original dof of permuted row r
   int32_t* ridx = nullptr;                // device [bs][nblocks]: permuted row of a block entry, -1 = padding
   double* res = nullptr;                  // device: residual of the colour being swept (permuted rows)
@@ -56,8 +57,13 @@ int bjac_apply_dot(const nss_bjac_s& j, double alpha, const double* x, double* y
 
 
 // one multicolour block Gauss-Seidel sweep / the symmetric pair as an operator (y = 0 first)
+// flags (colour-major layout; ignored by the row-permuted one):
+//   kGsFromZero  y is taken to be 0 on entry and need not hold zeros: it is not gathered, and the first colour of the
+//                sweep -- whose rows see A y = 0 -- is y_c = D_c^-1 (xscale x_c) without a pass over its rows of A
+//   kGsKeepX     x is the vector of the previous call on this handle (its permuted copy is still there): not gathered again
+enum { kGsFromZero = 1, kGsKeepX = 2 };
 void bjac_smooth(const nss_bjac_s& j, double xscale, const double* x, double* y, bool backward, const int32_t* done,
-                 hipStream_t st);
+                 hipStream_t st, int flags = 0);
 void bjac_symgs_apply(const nss_bjac_s& j, double xscale, const double* x, double* y, const int32_t* done,
                       hipStream_t st);
 

@@ -288,7 +288,7 @@ __global__ __launch_bounds__(kBlock) void gs_enter_kernel(int32_t n_perm, const 
   for (int r = blockIdx.x * kBlock + threadIdx.x; r <= n_perm; r += stride) {
     const bool live = r < n_perm;
     const int d = live ? rowdof[r] : 0;
-    xt[r] = live ? x[d] : 0.0;
+    if (x) xt[r] = live ? x[d] : 0.0;                    // (x == NULL: the permuted copy of the previous call stays)
     yt[r] = (live && y) ? y[d] : 0.0;
   }
 }
@@ -322,11 +322,38 @@ __global__ __launch_bounds__(kBlock) void gs_pack_inverse_kernel(int32_t bs, int
   }
 }
 
-static void gs_sweep_permuted(const nss_bjac_s& j, double xscale, bool backward, const int32_t* done, hipStream_t st) {
+// first colour of a sweep that starts from y = 0: its rows see A y = 0, so the residual is xscale x and
+// y_c = D_c^-1 (xscale x_c) -- the numbers the colour launch would produce (fma(xscale, x, -0) = xscale x; 0 + s = s)
+// without its pass over half of P A P^T
+__global__ __launch_bounds__(kBlock) void gs_first_color_kernel(int32_t r0, int32_t r1, const double* __restrict__ xt,
+                                                                 double* __restrict__ yt, const double* __restrict__ ginv,
+                                                                 const uint8_t* __restrict__ gpos,
+                                                                 const uint8_t* __restrict__ glen, int32_t n_perm,
+                                                                 double xscale, const int32_t* __restrict__ done) {
+  if (done && done[0] != 0) return;
+  const int r = r0 + blockIdx.x * kBlock + threadIdx.x;
+  if (r >= r1) return;
+  const int first = r - int(gpos[r]), len = int(glen[r]);
+  double s = 0.0;
+  for (int k = 0; k < len; ++k) s = fma(ginv[size_t(k) * n_perm + r], xscale * xt[first + k], s);
+  yt[r] = s;
+}
+
+static void gs_sweep_permuted(const nss_bjac_s& j, double xscale, bool backward, const int32_t* done, hipStream_t st,
+                              bool from_zero = false) {
   const int nc = int(j.color_ptr.size()) - 1;
   const EpiGsFused epi{done, j.gs_mat->rowblk, j.xt, j.yt, j.ginv, j.gpos, j.glen, j.n_perm, xscale};
   for (int k = 0; k < nc; ++k) {
     const int c = backward ? nc - 1 - k : k;
+    if (k == 0 && from_zero && !j.color_row.empty()) {
+      const int r0 = j.color_row[c], r1 = j.color_row[c + 1];
+      if (r1 > r0) {
+        hipLaunchKernelGGL(gs_first_color_kernel, dim3((r1 - r0 + kBlock - 1) / kBlock), dim3(kBlock), 0, st, r0, r1, j.xt,
+                           j.yt, j.ginv, j.gpos, j.glen, j.n_perm, xscale, done);
+        NSS_CHECK_LAUNCH();
+      }
+      continue;
+    }
     launch_csr_stream(*j.gs_mat, j.yt, epi, st, j.color_rowblk[c], j.color_rowblk[c + 1], sizeof(double) * kGsRows);
   }
 }
@@ -352,14 +379,21 @@ static void launch_bgs_solve(const nss_bjac_s& j, int c, double* y, const int32_
 }
 
 void bjac_smooth(const nss_bjac_s& j, double xscale, const double* x, double* y, bool backward, const int32_t* done,
-                 hipStream_t st) {
+                 hipStream_t st, int flags) {
   if (!j.gs_mat) throw Error("bjac_smooth: colours not set (nss_bjac_set_colors)");
   if (j.gs_permuted) {             // gather x and y into the colour-major numbering, sweep, scatter y back
-    gs_enter(j, x, y, done, st);
-    gs_sweep_permuted(j, xscale, backward, done, st);
+    const bool from_zero = (flags & kGsFromZero) != 0;
+    if (from_zero && j.n_uncovered > 0) {      // dofs in no block: 0 (guarded: a frozen solver keeps its y)
+      hipLaunchKernelGGL(bjac_uncovered_kernel, dim3((j.n_uncovered + kBlock - 1) / kBlock), dim3(kBlock), 0, st,
+                         j.n_uncovered, j.covered, 0.0, y, done);
+      NSS_CHECK_LAUNCH();
+    }
+    gs_enter(j, (flags & kGsKeepX) ? nullptr : x, from_zero ? nullptr : y, done, st);
+    gs_sweep_permuted(j, xscale, backward, done, st, from_zero);
     gs_leave(j, y, done, st);
     return;
   }
+  if (flags & kGsFromZero) throw Error("bjac_smooth: the from-zero form exists for the colour-major layout only");
   const int nc = int(j.color_ptr.size()) - 1;
   for (int k = 0; k < nc; ++k) {
     const int c = backward ? nc - 1 - k : k;
@@ -385,7 +419,7 @@ void bjac_symgs_apply(const nss_bjac_s& j, double xscale, const double* x, doubl
       NSS_CHECK_LAUNCH();
     }
     gs_enter(j, x, nullptr, done, st);                               // y[:] = 0 (:377)
-    gs_sweep_permuted(j, xscale, false, done, st);                   // jacobi.Smooth(y, x)      (:378)
+    gs_sweep_permuted(j, xscale, false, done, st, true);             // jacobi.Smooth(y, x)      (:378)
     gs_sweep_permuted(j, xscale, true, done, st);                    // jacobi.SmoothBack(y, x)  (:381)
     gs_leave(j, y, done, st);
     return;
@@ -616,6 +650,7 @@ static void set_colors_common(nss_bjac_t j, nss_csr_t a_perm, int32_t ncolors, c
     j->gs_permuted = false;
     j->color_ptr.assign(h_color_ptr, h_color_ptr + ncolors + 1);
     j->color_rowblk = crb;
+    j->color_row.assign(h_color_rowptr, h_color_rowptr + ncolors + 1);
   }
 }
 
