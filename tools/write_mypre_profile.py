@@ -54,7 +54,9 @@ Reading the tables below for this path (per BPCG iteration: 2 sweep calls, 1 aux
   inverse blocks 0.09, x 0.03, y in / out 0.06, the other colour's y through the operand copy ~0.045): **drawn /
   algorithmic = 1.04** (round 1's form: ~2.4 GB per pass for a 0.63-GB matrix).  The entry gather draws 395 MB for 240
   algorithmic: with two colours every 64-byte line of x and y holds dofs of both, so each half of the gather touches
-  every line (1.6 x); per sweep call 1.61 GB drawn for 1.27 GB algorithmic = 1.27 x.
+  every line (1.6 x); per sweep call 1.61 GB drawn for 1.27 GB algorithmic = 1.27 x.  Inside the loop the FORWARD sweep starts
+  from zero: its entry gathers x only, its first colour is `gs_first_color_kernel` (a block solve, no pass over A) and the
+  backward sweep's entry gathers y only -- the averages above mix those launches with the stand-alone calls.
 * **Auxiliary-space term**: T^T and T SpMVs (`csr_stream_kernel<EpiAxpby>`, %.1f us each) around ONE joint cycle over the
   shared hierarchy (levels 2 460 375 / 253 314 / 12 487 / 1 487) for the three components: %.3f ms per apply for %.2f GB
   algorithmic (%.2f of peak) against 0.97 ms / 4.1 GB for three cycles one after the other
