@@ -711,6 +711,13 @@ typedef struct nss_bpcg1_s {
 NSS_API int nss_bpcg1_workspace(const nss_bpcg1_t* s, int64_t* partials_a, int64_t* partials_b,
                                 int64_t* partials_c);
 NSS_API int nss_bpcg1_iterate(const nss_bpcg1_t* s, int32_t it_begin, int32_t it_end, nss_stream_t stream);
+/* One GPU, B^T with at most two entries per row: the rows of B^T ride in the epilogue of A's rows (V1a + V1b in one
+ * pass, up to 2^21 velocity rows); small systems (every sum of an iteration <= 1024 partials) also evaluate the
+ * loop-top bookkeeping (:115-119), alpha (:129) and rho_new / beta (:137-138) inside the consuming kernels by every
+ * workgroup -- 6 dependent launches per iteration instead of 10.  Identical bits in every form.  Process-wide override
+ * for tests and A/B runs: -1 by size (default), 0 neither, 1 both whenever B^T allows.  (rho of iteration it is kept in
+ * scal[0] for even it and scal[7] for odd it.) */
+NSS_API int nss_bpcg1_fold_mode(int32_t mode);
 NSS_API int nss_bpcg1_poll(const nss_bpcg1_t* s, int32_t* stop, int32_t* it_stop, int32_t* last_it,
                            nss_stream_t stream);
 /* The device phases first .. last of iteration `it` (row-partitioned schedules with a host-side

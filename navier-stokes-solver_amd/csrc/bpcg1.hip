@@ -20,10 +20,30 @@
 
 namespace nss {
 
-enum { P_RHO = 0, P_DSUM = 1, P_RHON = 2, P_ALPHA = 3, P_BETA = 4, P_ERR0 = 5, P_TOL = 6,
+// rho of iteration `it` lives in P_RHO (even it) or P_RHO_ODD (odd it): the kernel that forms rho_new writes the
+// OTHER slot, so that -- when every workgroup of V6 evaluates beta itself (small systems) -- nobody reads a slot
+// that workgroup 0 is rewriting
+enum { P_RHO = 0, P_DSUM = 1, P_RHON = 2, P_ALPHA = 3, P_BETA = 4, P_ERR0 = 5, P_TOL = 6, P_RHO_ODD = 7,
        // row-partitioned runs: local totals; the all-reduce writes P_DSUM / P_RHON out of place (frozen after the stop)
        P_DSUM_LOC = 8, P_RHON_LOC = 9 };
 enum { PC_STOP = 0, PC_ITSTOP = 1, PC_LAST = 2 };
+__host__ __device__ __forceinline__ int rho_slot(int it) { return (it & 1) ? P_RHO_ODD : P_RHO; }
+
+// loop-top bookkeeping (:115-119) evaluated by EVERY workgroup of the first launch of an iteration (small systems):
+// hist[it] = err / err0 and the stop test from the same scalars; one thread of the grid records them.  false: stop.
+__device__ __forceinline__ bool v1_loop_top(int32_t* ctrl, const double* s, double* hist, int it) {
+  const double err = sqrt(fabs(s[rho_slot(it)]));
+  const bool stop = err < s[P_TOL] * s[P_ERR0];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    hist[it] = err / s[P_ERR0];
+    ctrl[PC_LAST] = it;
+    if (stop) {
+      ctrl[PC_ITSTOP] = it;
+      ctrl[PC_STOP] = 1;
+    }
+  }
+  return !stop;
+}
 
 struct EpiStore1 {
   const int32_t* __restrict__ ctrl;
@@ -54,10 +74,52 @@ struct EpiV1c {
   const int32_t* __restrict__ ctrl;
   double* __restrict__ t1p;
   double* __restrict__ t2p;
+  // small systems: this launch opens the iteration (see v1_loop_top)
+  int32_t* top_ctrl = nullptr;
+  const double* top_scal = nullptr;
+  double* top_hist = nullptr;
+  int it = 0;
   __device__ bool skip() const { return ctrl[PC_STOP] != 0; }
+  __device__ bool prologue(double*) const { return top_ctrl ? v1_loop_top(top_ctrl, top_scal, top_hist, it) : true; }
   __device__ void row(int r, double kp) const {
     t1p[r] = -kp;
     t2p[r] = kp;
+  }
+  __device__ void finish(int, double*) const {}
+};
+
+// Small systems, B^T with at most two entries per row: the rows of A add their row of B^T dp from B^T's fixed-width
+// copy (V1a + V1b in one pass; the row of B^T summed as csr_direct_kernel sums it, then adu + btp as V1b did:
+// identical bits) and open the iteration.
+struct EpiV1Rows {
+  const int32_t* __restrict__ ctrl;
+  double* __restrict__ t1u;
+  double* __restrict__ t2u;
+  const double* __restrict__ dinv;
+  double k;
+  const int32_t* __restrict__ ecol;
+  const double* __restrict__ eval;
+  const double* __restrict__ dp;
+  int32_t* top_ctrl;
+  const double* top_scal;
+  double* top_hist;
+  int it;
+  __device__ bool skip() const { return ctrl[PC_STOP] != 0; }
+  __device__ bool prologue(double*) const { return top_ctrl ? v1_loop_top(top_ctrl, top_scal, top_hist, it) : true; }
+  struct Pre { double dinv = 0.0, v0 = 0.0, v1 = 0.0, x0 = 0.0, x1 = 0.0; bool h0 = false, h1 = false; };
+  __device__ Pre fetch(int r) const {
+    typedef int32_t int2v __attribute__((ext_vector_type(2)));
+    const int2v c = reinterpret_cast<const int2v*>(ecol)[r];
+    const dbl2v v = reinterpret_cast<const dbl2v*>(eval)[r];
+    return Pre{dinv ? dinv[r] : 0.0, v.x, v.y, c.x >= 0 ? dp[c.x] : 0.0, c.y >= 0 ? dp[c.y] : 0.0, c.x >= 0, c.y >= 0};
+  }
+  __device__ void row(int r, double adu, const Pre& p) const {
+    double btp = 0.0;
+    if (p.h0) btp += mul_unfused(p.v0, p.x0);
+    if (p.h1) btp += mul_unfused(p.v1, p.x1);
+    const double ku = adu + btp;
+    t1u[r] = -ku;
+    if (dinv) t2u[r] = k * (p.dinv * ku);
   }
   __device__ void finish(int, double*) const {}
 };
@@ -118,18 +180,18 @@ __global__ __launch_bounds__(kPSum) void bpcg1_scalar_kernel(int32_t* __restrict
   if (which == 3 || which == 4) {
     if (tid == 0) {
       if (which == 3) {
-        s[P_ALPHA] = s[P_RHO] / s[P_DSUM];
+        s[P_ALPHA] = s[rho_slot(it)] / s[P_DSUM];
       } else {
         const double total = s[P_RHON];
-        s[P_BETA] = total / s[P_RHO];
-        s[P_RHO] = total;
+        s[P_BETA] = total / s[rho_slot(it)];
+        s[rho_slot(it + 1)] = total;
       }
     }
     return;
   }
   if (which == 0) {
     if (tid == 0) {
-      const double err = sqrt(fabs(s[P_RHO]));
+      const double err = sqrt(fabs(s[rho_slot(it)]));
       hist[it] = err / s[P_ERR0];
       ctrl[PC_LAST] = it;
       if (err < s[P_TOL] * s[P_ERR0]) {
@@ -160,29 +222,43 @@ __global__ __launch_bounds__(kPSum) void bpcg1_scalar_kernel(int32_t* __restrict
       s[which == 1 ? P_DSUM_LOC : P_RHON_LOC] = total;
     } else if (which == 1) {
       s[P_DSUM] = total;
-      s[P_ALPHA] = s[P_RHO] / total;
+      s[P_ALPHA] = s[rho_slot(it)] / total;
     } else {
       s[P_RHON] = total;
-      s[P_BETA] = total / s[P_RHO];
-      s[P_RHO] = total;
+      s[P_BETA] = total / s[rho_slot(it)];
+      s[rho_slot(it + 1)] = total;
     }
   }
 }
 
 struct V4Args {
   const int32_t* ctrl;
-  const double* scal;
+  double* scal;
   int32_t n_u, n_p;
   double *xu, *xp, *ru, *rp, *au, *ap;
   const double *du, *dp, *t1u, *t1p, *t2u, *t2p;
   double* partials;
+  // small systems: alpha = rho / (sum(pa) + sum(pb)) evaluated by every workgroup (the tree of bpcg1_scalar_kernel:
+  // identical bits), workgroup 0 records it
+  int32_t fold, it, na, nb;
+  const double *pa, *pb;
 };
 
 template <bool NT>      // streaming loads of the operands that are not read again (stream_vector_loads, nss_common.h)
 __global__ __launch_bounds__(kBlock) void bpcg1_v4_kernel(V4Args a) {
-  __shared__ double lds[kBlock / kWave];
+  __shared__ double lds[kRedDoubles];
   if (a.ctrl[PC_STOP] != 0) return;
-  const double alpha = a.scal[P_ALPHA];
+  double alpha;
+  if (a.fold) {
+    const double total = fixed_sum_1024(a.pa, a.na, a.pb, a.nb, lds);
+    alpha = a.scal[rho_slot(a.it)] / total;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      a.scal[P_DSUM] = total;
+      a.scal[P_ALPHA] = alpha;
+    }
+  } else {
+    alpha = a.scal[P_ALPHA];
+  }
   const int stride = gridDim.x * kBlock;
   double acc = 0.0;
   // streaming loads for what is not read again before it is rewritten or an iteration has passed (x, r, t1, t2,
@@ -204,14 +280,30 @@ __global__ __launch_bounds__(kBlock) void bpcg1_v4_kernel(V4Args a) {
   if (threadIdx.x == 0) a.partials[blockIdx.x] = s;
 }
 
+// fold: rho_new = sum(pc) + sum(pb), beta = rho_new / rho evaluated by every workgroup; workgroup 0 records them and
+// rho_new in the slot of iteration it + 1
 template <bool NT>
 __global__ __launch_bounds__(kBlock) void bpcg1_v6_kernel(const int32_t* __restrict__ ctrl,
-                                                           const double* __restrict__ scal, int32_t n_u, int32_t n_p,
+                                                           double* __restrict__ scal, int32_t n_u, int32_t n_p,
                                                            double* __restrict__ du, double* __restrict__ dp,
                                                            const double* __restrict__ au,
-                                                           const double* __restrict__ t1p) {
+                                                           const double* __restrict__ t1p, int fold, int it, int nc,
+                                                           const double* __restrict__ pc, int nb,
+                                                           const double* __restrict__ pb) {
+  __shared__ double lds[kRedDoubles];
   if (ctrl[PC_STOP] != 0) return;
-  const double beta = scal[P_BETA];
+  double beta;
+  if (fold) {
+    const double total = fixed_sum_1024(pc, nc, pb, nb, lds);
+    beta = total / scal[rho_slot(it)];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      scal[P_RHON] = total;
+      scal[P_BETA] = beta;
+      scal[rho_slot(it + 1)] = total;
+    }
+  } else {
+    beta = scal[P_BETA];
+  }
   const int stride = gridDim.x * kBlock;
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < n_u; i += stride) du[i] = fma(beta, ld1s<NT>(&du[i]), ld1s<NT>(&au[i]));
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < n_p; i += stride) dp[i] = fma(beta, ld1s<NT>(&dp[i]), ld1s<NT>(&t1p[i]));
@@ -252,6 +344,24 @@ static void scalar_step(const nss_bpcg1_t& s, int which, int it, int lanes, int 
   NSS_CHECK_LAUNCH();
 }
 
+// One GPU, B^T with a fixed-width copy: the rows of B^T ride in the epilogue of A's rows (`merge`: up to 2^22 velocity
+// rows -- measured -10 ... -26 % per iteration up to 1.2e6 DoF, +5 % at 4e6); small systems (every sum of the iteration
+// <= 1024 partials) also evaluate the loop-top bookkeeping, alpha and rho_new / beta inside the consuming kernels by
+// every workgroup (`fold`) -- 6 dependent launches per iteration instead of 10.  Identical bits in every form
+// (nss_bpcg1_fold_mode: -1 by size, 0 neither, 1 both whenever B^T allows).
+constexpr int kV1FoldMax = 1024;
+constexpr int kV1MergeMaxRows = 1 << 21;
+static int g_bpcg1_fold_mode = -1;
+static bool v1_merge(const nss_bpcg1_t& s, bool dist) {
+  if (dist || s.local_sums || g_bpcg1_fold_mode == 0) return false;
+  if (g_bpcg1_fold_mode < 0 && s.A->m > kV1MergeMaxRows) return false;
+  return s.BT->m == s.A->m && fixed_width_copy(*s.BT);
+}
+static bool v1_fold(const nss_bpcg1_t& s) {      // (only together with the merged rows: their launch opens the iteration)
+  if (g_bpcg1_fold_mode == 1) return true;
+  return s.A->nblk <= kV1FoldMax && s.B->nblk <= kV1FoldMax && p_grid(s) <= kV1FoldMax;
+}
+
 // phases first .. last of one iteration (nss_bpcg1_phases); `dist`: exchanges and all-reduces issued from here
 static void bpcg1_iteration(const nss_bpcg1_t& s, int it, hipStream_t st, int first = 1, int last = 5,
                             const Bpcg1Dist* dist = nullptr) {
@@ -261,12 +371,25 @@ static void bpcg1_iteration(const nss_bpcg1_t& s, int it, hipStream_t st, int fi
     c.ext = ext;
     return c;
   };
+  const bool merge = v1_merge(s, dist != nullptr);           // rows of B^T inside the launch of A's rows
+  const bool fast = merge && v1_fold(s);                     // ... and the scalar steps inside their consumers
   if (on(1)) {
-    scalar_step(s, 0, it, kWave, 0, s.partials_a, 0, s.partials_b, st);
+    if (!fast) scalar_step(s, 0, it, kWave, 0, s.partials_a, 0, s.partials_b, st);
     if (dist) {
       const nss_halo_t h0 = halo_of(dist->hu, s.d[0]), h1 = halo_of(dist->hp, s.d[1]);
       exchange(*dist->d, h0, st, &h1);
     }
+    if (merge) {
+      // rows of A (+ their row of B^T dp, V1b's combination) and rows of B in one launch, which (fast) opens the iteration
+      int32_t* top = fast ? s.ctrl : nullptr;
+      const EpiV1Rows e1{s.ctrl, s.t1[0], s.t2[0], s.pre_amg ? nullptr : s.pre_diag, s.k, s.BT->fw_col, s.BT->fw_val,
+                         s.d[1], top, s.scal, s.hist, it};
+      const EpiV1c e1c{s.ctrl, s.t1[1], s.t2[1], top, s.scal, s.hist, it};
+      if (!launch_csr_stream_dual(*s.A, s.d[0], e1, *s.B, s.d[0], e1c, st)) {
+        launch_csr_stream(*s.A, s.d[0], e1, st);                // (opens the iteration; the second launch repeats the
+        launch_csr_stream(*s.B, s.d[0], e1c, st);               //  test from the same scalars: same outcome)
+      }
+    } else {
     // V1a and V1c multiply the same operand (du) and do not depend on each other: one launch
     const EpiStore1 e1a{s.ctrl, s.t1[0]};
     const EpiV1c e1c{s.ctrl, s.t1[1], s.t2[1]};
@@ -275,6 +398,7 @@ static void bpcg1_iteration(const nss_bpcg1_t& s, int it, hipStream_t st, int fi
       launch_csr_stream(*s.B, s.d[0], e1c, st);
     }
     launch_csr_stream(*s.BT, s.d[1], EpiV1b{s.ctrl, s.t1[0], s.t2[0], s.pre_amg ? nullptr : s.pre_diag, s.k}, st);
+    }
     if (s.pre_amg) {                                         // t2 = -k (AMG + J) t1 (t1 holds -K u here)
       amg_apply(*s.pre_amg, -s.k, s.t1[0], s.t2[0], st);
       if (s.pre_bjac) bjac_apply(*s.pre_bjac, -s.k, s.t1[0], 1.0, s.t2[0], s.ctrl, st);
@@ -294,13 +418,14 @@ static void bpcg1_iteration(const nss_bpcg1_t& s, int it, hipStream_t st, int fi
       launch_csr_stream(*s.A, s.t2[0], e3a, st);
       launch_csr_stream(*s.B, s.t2[0], e3b, st);
     }
-    scalar_step(s, 1, it, kPSum, s.A->nblk, s.partials_a, s.B->nblk, s.partials_b, st);
+    if (!fast) scalar_step(s, 1, it, kPSum, s.A->nblk, s.partials_a, s.B->nblk, s.partials_b, st);
     if (dist) allreduce_sum(*dist->d, s.scal + P_DSUM_LOC, s.scal + P_DSUM, 1, st);
   }
   if (on(3)) {
     if (s.local_sums) scalar_step(s, 3, it, kWave, 0, s.partials_a, 0, s.partials_b, st);
     V4Args a4{s.ctrl, s.scal, s.n_u, s.n_p, s.x[0], s.x[1], s.r[0], s.r[1], s.a[0], s.a[1],
-              s.d[0], s.d[1], s.t1[0], s.t1[1], s.t2[0], s.t2[1], s.partials_c};
+              s.d[0], s.d[1], s.t1[0], s.t1[1], s.t2[0], s.t2[1], s.partials_c,
+              fast ? 1 : 0, it, s.A->nblk, s.B->nblk, s.partials_a, s.partials_b};
     if (stream_vector_loads(s.n_u)) hipLaunchKernelGGL(bpcg1_v4_kernel<true>, dim3(p_grid(s)), dim3(kBlock), 0, st, a4);
     else hipLaunchKernelGGL(bpcg1_v4_kernel<false>, dim3(p_grid(s)), dim3(kBlock), 0, st, a4);
     NSS_CHECK_LAUNCH();
@@ -308,17 +433,17 @@ static void bpcg1_iteration(const nss_bpcg1_t& s, int it, hipStream_t st, int fi
   if (on(4)) {
     if (dist) exchange(*dist->d, halo_of(dist->hu, s.a[0]), st);
     launch_csr_stream(*s.B, s.a[0], EpiV5{s.ctrl, s.a[1], s.minv, s.r[1], s.t1[1], s.partials_b}, st);
-    scalar_step(s, 2, it, kPSum, p_grid(s), s.partials_c, s.B->nblk, s.partials_b, st);
+    if (!fast) scalar_step(s, 2, it, kPSum, p_grid(s), s.partials_c, s.B->nblk, s.partials_b, st);
     if (dist) allreduce_sum(*dist->d, s.scal + P_RHON_LOC, s.scal + P_RHON, 1, st);
   }
   if (on(5)) {
     if (s.local_sums) scalar_step(s, 4, it, kWave, 0, s.partials_a, 0, s.partials_b, st);
     if (stream_vector_loads(s.n_u))
       hipLaunchKernelGGL(bpcg1_v6_kernel<true>, dim3(p_grid(s)), dim3(kBlock), 0, st, s.ctrl, s.scal, s.n_u, s.n_p, s.d[0],
-                         s.d[1], s.a[0], s.t1[1]);
+                         s.d[1], s.a[0], s.t1[1], fast ? 1 : 0, it, p_grid(s), s.partials_c, s.B->nblk, s.partials_b);
     else
       hipLaunchKernelGGL(bpcg1_v6_kernel<false>, dim3(p_grid(s)), dim3(kBlock), 0, st, s.ctrl, s.scal, s.n_u, s.n_p, s.d[0],
-                         s.d[1], s.a[0], s.t1[1]);
+                         s.d[1], s.a[0], s.t1[1], fast ? 1 : 0, it, p_grid(s), s.partials_c, s.B->nblk, s.partials_b);
     NSS_CHECK_LAUNCH();
   }
 }
@@ -367,6 +492,13 @@ int nss_bpcg1_iterate_dist(const nss_bpcg1_t* s, nss_dist_t d, const nss_halo_t*
     check_halo(&h1, *s->BT, "halo_p");
     Bpcg1Dist bd{d, halo_u, halo_p};
     for (int it = it_begin; it < it_end; ++it) bpcg1_iteration(*s, it, as_stream(stream), 1, 5, &bd);
+  });
+}
+
+int nss_bpcg1_fold_mode(int32_t mode) {
+  return guarded([&] {
+    NSS_REQUIRE(mode >= -1 && mode <= 1, "bpcg1_fold_mode: -1 (by size), 0 (never) or 1 (whenever B^T has a fixed-width copy)");
+    g_bpcg1_fold_mode = mode;
   });
 }
 

@@ -130,6 +130,7 @@ def _signatures():
         "nss_minres_iterate_dist": (C.c_int, [vp, vp, vp, vp, i32, i32, vp]),
         "nss_minres_fold_mode": (C.c_int, [i32]),
         "nss_lanczos_fold_mode": (C.c_int, [i32]),
+        "nss_bpcg1_fold_mode": (C.c_int, [i32]),
         "nss_amg_batch_components": (C.c_int, [i32]),
         "nss_bpcg2_fuse_block_jacobi": (C.c_int, [i32]),
         "nss_bpcg2_c1_applies_preA": (C.c_int, [vp, c_i32_p]),
@@ -166,7 +167,7 @@ def load_library(path=None):
         lib.nss_csr_dispatch_mode(int(os.environ["NSS_DISPATCH_PLANES"]), int(os.environ.get("NSS_DISPATCH_MIN_PERIOD", "0")),
                                   int(os.environ.get("NSS_DISPATCH_RUN", "0")))
     if os.environ.get("NSS_FOLD_SUMS"):                                                   # measurements: -1 / 0 / 1
-        for name in ("nss_bpcg2_fold_mode", "nss_minres_fold_mode"):
+        for name in ("nss_bpcg2_fold_mode", "nss_minres_fold_mode", "nss_bpcg1_fold_mode"):
             if hasattr(lib, name):
                 getattr(lib, name)(int(os.environ["NSS_FOLD_SUMS"]))
     if os.environ.get("NSS_FUSE_BJAC") and hasattr(lib, "nss_bpcg2_fuse_block_jacobi"):   # measurements: 0 / 1

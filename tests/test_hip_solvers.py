@@ -878,6 +878,37 @@ def test_minres_sum_placement_gives_identical_bits(hip_engine, case):
     check_iterations(len(outs[0][0]) - 1, d["iterations"], d)
 
 
+@pytest.mark.parametrize("case", ["stokes3d_n10_bjac_bpcg1", "stokes2d_n48_jacobi_bpcg1", "stokes2d_n24_bjac_bpcg1",
+                                  "stokes3d_n5_facet_x12_bpcg1"])
+def test_bpcg1_small_system_form_gives_identical_bits(hip_engine, case):
+    """Small systems run the fused textbook BPCG (bramble_pasciak_cg.py:110-143) in 6 dependent launches instead of 10:
+    the loop-top bookkeeping (:115-119), alpha (:129) and rho_new / beta (:137-138) are evaluated by every workgroup of
+    the consuming kernels (the summation tree of the stand-alone scalar kernel), and the rows of A add their row of
+    B^T dp from B^T's fixed-width copy (nss_bpcg1_fold_mode).  Errors and solution agree BIT FOR BIT with the
+    10-launch form; both match the golden."""
+    import hipla
+    from bramble_pasciak_cg import bramble_pasciak_cg
+    d = np.load(golden_path(case))
+    c, _, A, B, preA, preS = case_operands(d)
+    fv, gv = hipla.Vector.from_numpy(c.f), hipla.Vector.from_numpy(c.g)
+    lib = hip_engine.lib
+    outs = {}
+    try:
+        for mode in (0, 1):
+            assert lib.nss_bpcg1_fold_mode(mode) == 0
+            with contextlib.redirect_stdout(io.StringIO()), fused_loops_counted() as counts:
+                sol, errors = bramble_pasciak_cg(A, B, None, preA, preS, fv, gv, tolerance=float(d["tol"]),
+                                                 max_steps=int(d["maxsteps"]), print_rates=False)
+            assert counts["bpcg1"] == 1
+            outs[mode] = (np.array(errors), sol.numpy())
+    finally:
+        lib.nss_bpcg1_fold_mode(-1)
+    np.testing.assert_array_equal(outs[1][0], outs[0][0])
+    np.testing.assert_array_equal(outs[1][1], outs[0][1])
+    check_history(outs[1][0], d["errors"], d["window"])
+    check_iterations(len(outs[1][0]) - 1, d["iterations"], d)
+
+
 @pytest.mark.parametrize("case", ["stokes3d_n10_bjac_minres", "stokes2d_n24_jacobi_minres",
                                   "stokes3d_n5_facet_x12_minres"])
 def test_minres_merged_launches_give_identical_bits(hip_engine, case):
