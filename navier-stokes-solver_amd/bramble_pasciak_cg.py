@@ -13,6 +13,7 @@ statement for statement -- 6 SpMV, 1 pre_a, 1 pre_s, 2 inner products per iterat
 from math import sqrt
 
 from hipla import BaseMatrix, BlockMatrix, BlockVector, IdentityMatrix, InnerProduct, Vector
+from hipla import fused
 from hipla.fused import Bpcg1Loop
 from hipla.la import EigenValues_Preconditioner
 from hipla.ngstd import Timer
@@ -88,6 +89,7 @@ def bramble_pasciak_cg(a_matrix, b_matrix, c_matrix, pre_a, pre_schur_complement
     the stop test, so ``errors[0] == 1.0`` and ``len(errors) == iterations + 1``
     (bramble_pasciak_cg.py:115-121).  ``solution`` (a 2-component BlockVector) is the
     start vector and is updated in place; ``None`` starts from zero (:88-90)."""
+    fused.plan_for_textbook_bpcg(a_matrix, pre_a)        # (launch plans before the first product: see there)
     ev_timer = Timer("eigenvalues")
     ev_timer.Start()
     ritz = EigenValues_Preconditioner(mat=a_matrix, pre=pre_a)

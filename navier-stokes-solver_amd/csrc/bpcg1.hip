@@ -14,6 +14,7 @@
 //   V5   rows of B   : t1p = minv (B a_res_u - a_res_p), partial <t1p, r_p>           (:135,137)
 //   R2   rho_new, beta = rho_new / rho                                                (:137-138)
 //   V6   element-wise: du = b du + a_res_u, dp = b dp + t1p                           (:140-141)
+#include "bpcg2.h"
 #include "dist.h"
 
 #include <algorithm>
@@ -104,6 +105,13 @@ struct EpiV1Rows {
   const double* top_scal;
   double* top_hist;
   int it;
+  // block Jacobi applied here (A planned around its blocks, nss_csr_plan_for_blocks): t2u = -k J t1u from the LDS copy
+  // of this row block's t1u, one lane per Jacobi block, the arithmetic of bjac_apply_sym_kernel (identical bits)
+  const int32_t* __restrict__ jb_first = nullptr;    // nullptr: not fused
+  const int32_t* __restrict__ jb_order = nullptr;
+  const int32_t* __restrict__ jb_run = nullptr;
+  const double* __restrict__ jb_packed = nullptr;
+  int32_t jb_count = 0, jb_bs = 0;
   __device__ bool skip() const { return ctrl[PC_STOP] != 0; }
   __device__ bool prologue(double*) const { return top_ctrl ? v1_loop_top(top_ctrl, top_scal, top_hist, it) : true; }
   struct Pre { double dinv = 0.0, v0 = 0.0, v1 = 0.0, x0 = 0.0, x1 = 0.0; bool h0 = false, h1 = false; };
@@ -120,8 +128,30 @@ struct EpiV1Rows {
     const double ku = adu + btp;
     t1u[r] = -ku;
     if (dinv) t2u[r] = k * (p.dinv * ku);
+    if (jb_first) {
+      extern __shared__ double v1_t1u[];
+      v1_t1u[r & (kBlockRows - 1)] = -ku;                // (a row block holds at most kBlockRows consecutive rows)
+    }
   }
-  __device__ void finish(int, double*) const {}
+  __device__ void finish(int b, double*) const {
+    if (!jb_first || b < 0) return;                      // (uniform over the workgroup)
+    extern __shared__ double v1_t1u[];
+    __syncthreads();
+    const int j1 = jb_first[b + 1];
+    for (int pos = jb_first[b] + int(threadIdx.x); pos < j1; pos += kBlock) {
+      const int jb = jb_order[pos];
+      const int32_t w = jb_run[jb], first = w >> 5, len = w & 31;
+      for (int i = 0; i < len; ++i) {
+        double s = 0.0;
+        for (int j = 0; j < len; ++j) {
+          const int lo = i < j ? i : j, hi = i < j ? j : i;
+          const int tri = lo * jb_bs - (lo * (lo - 1)) / 2 + (hi - lo);        // upper triangle, row-major
+          s = fma(jb_packed[size_t(tri) * jb_count + jb], v1_t1u[(first + j) & (kBlockRows - 1)], s);
+        }
+        t2u[first + i] = -k * s;
+      }
+    }
+  }
 };
 
 struct EpiV3 {  // y += A x ; partial <d, y>
@@ -372,6 +402,7 @@ static void bpcg1_iteration(const nss_bpcg1_t& s, int it, hipStream_t st, int fi
     return c;
   };
   const bool merge = v1_merge(s, dist != nullptr);           // rows of B^T inside the launch of A's rows
+  bool fused_j = false;                                      // ... and the block Jacobi in the epilogue of that launch
   const bool fast = merge && v1_fold(s);                     // ... and the scalar steps inside their consumers
   if (on(1)) {
     if (!fast) scalar_step(s, 0, it, kWave, 0, s.partials_a, 0, s.partials_b, st);
@@ -382,11 +413,17 @@ static void bpcg1_iteration(const nss_bpcg1_t& s, int it, hipStream_t st, int fi
     if (merge) {
       // rows of A (+ their row of B^T dp, V1b's combination) and rows of B in one launch, which (fast) opens the iteration
       int32_t* top = fast ? s.ctrl : nullptr;
+      const nss_bjac_s* J = s.pre_bjac;
+      fused_j = J && !s.pre_amg && !J->gs_mat && J->run && J->inv_sym && s.A->jb_first && s.A->jb_serial == J->serial &&
+                !s.A->ell_col && fuse_block_jacobi_wanted(s.A->m);
+      const size_t lds = fused_j ? sizeof(double) * kBlockRows : 0;
       const EpiV1Rows e1{s.ctrl, s.t1[0], s.t2[0], s.pre_amg ? nullptr : s.pre_diag, s.k, s.BT->fw_col, s.BT->fw_val,
-                         s.d[1], top, s.scal, s.hist, it};
+                         s.d[1], top, s.scal, s.hist, it, fused_j ? s.A->jb_first : nullptr,
+                         fused_j ? s.A->jb_order : nullptr, fused_j ? J->run : nullptr, fused_j ? J->inv_sym : nullptr,
+                         fused_j ? J->nblocks : 0, fused_j ? J->bs : 0};
       const EpiV1c e1c{s.ctrl, s.t1[1], s.t2[1], top, s.scal, s.hist, it};
-      if (!launch_csr_stream_dual(*s.A, s.d[0], e1, *s.B, s.d[0], e1c, st)) {
-        launch_csr_stream(*s.A, s.d[0], e1, st);                // (opens the iteration; the second launch repeats the
+      if (!launch_csr_stream_dual(*s.A, s.d[0], e1, *s.B, s.d[0], e1c, st, lds)) {
+        launch_csr_stream(*s.A, s.d[0], e1, st, 0, -1, lds);    // (opens the iteration; the second launch repeats the
         launch_csr_stream(*s.B, s.d[0], e1c, st);               //  test from the same scalars: same outcome)
       }
     } else {
@@ -406,7 +443,7 @@ static void bpcg1_iteration(const nss_bpcg1_t& s, int it, hipStream_t st, int fi
         const int rc = nss_diag_apply_f64(s.n_u, s.pre_diag, -s.k, s.t1[0], 1.0, s.t2[0], st);
         if (rc != 0) throw Error(nss_last_error());
       }
-    } else if (s.pre_bjac) {
+    } else if (s.pre_bjac && !fused_j) {
       bjac_apply(*s.pre_bjac, -s.k, s.t1[0], 0.0, s.t2[0], s.ctrl, st);
     }
   }

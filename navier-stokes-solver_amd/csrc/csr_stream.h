@@ -732,7 +732,7 @@ inline void launch_csr_stream(const nss_csr_s& A, const double* x, const Epi& ep
 // one of the instantiated ones; returns false (nothing launched) otherwise -- the caller then issues two launches.
 template <class EpiA, class EpiB>
 inline bool launch_csr_stream_dual(const nss_csr_s& A, const double* xa, const EpiA& ea, const nss_csr_s& B,
-                                   const double* xb, const EpiB& eb, hipStream_t st) {
+                                   const double* xb, const EpiB& eb, hipStream_t st, size_t dyn_lds = 0) {
 #ifdef NSS_NO_DUAL        // measurements: the two halves as launches of their own
   return false;
 #endif
@@ -750,7 +750,7 @@ inline bool launch_csr_stream_dual(const nss_csr_s& A, const double* xa, const E
   const int ga = nss_csr_s::grid(A.nblk), gb = nss_csr_s::grid(B.nblk);
   const dim3 grid(ga + gb), block(kBlock);
 #define NSS_DUAL_GO(N, CHK, IA, IB, G) \
-  hipLaunchKernelGGL((csr_stream_dual_kernel<N, EpiA, EpiB, IA, IB, CHK, G>), grid, block, 0, st, va, vb, ga, gb, xa, xb, ea, eb)
+  hipLaunchKernelGGL((csr_stream_dual_kernel<N, EpiA, EpiB, IA, IB, CHK, G>), grid, block, dyn_lds, st, va, vb, ga, gb, xa, xb, ea, eb)
 #define NSS_DUAL_PAIR(N, CHK, IA, IB) \
   if (grp) NSS_DUAL_GO(N, CHK, IA, IB, true); else NSS_DUAL_GO(N, CHK, IA, IB, false);
 #define NSS_LAUNCH_DUAL_ONE(N, CHK)                                                        \

@@ -116,6 +116,19 @@ def native_velocity_pre(op):
     return out
 
 
+def plan_for_textbook_bpcg(a_matrix, pre_a):
+    """Launch plans the fused textbook BPCG loop wants, made BEFORE anything multiplies with the matrices (the scale
+    factor's Lanczos runs over A: with the plan changed afterwards the first solve on fresh matrices would differ from
+    later ones in the last bits of k).  Block Jacobi alone: A's row blocks around the Jacobi blocks (small systems), so
+    that the launch of A's rows applies it in its epilogue.  No-op for anything that is not native."""
+    if not ENABLED or not isinstance(a_matrix, SparseMatrix) or not hasattr(a_matrix.handle, "plan_for_blocks"):
+        return
+    parts = native_velocity_pre(pre_a)
+    if parts is None or parts["amg"] is not None or parts["multiplicative"] or not isinstance(parts["bjac"], BlockJacobi):
+        return
+    a_matrix.handle.plan_for_blocks(parts["bjac"].handle)
+
+
 def _amg_plus_jacobi(op):
     """(amg, (1.0, diag) | None, (1.0, bjac) | None) when `op` is an unscaled AMG V-cycle, optionally
     plus a point / block Jacobi (the additive MypreA); (None, None, None) otherwise."""
@@ -491,6 +504,10 @@ class Bpcg1Loop:
         elif pa_b is not None:
             scale, op = pa_b
             st.pre_diag, st.pre_bjac = None, op.handle.ptr
+            # block Jacobi alone: A's row blocks are planned around its blocks (small systems) and the launch of A's rows
+            # applies it in its epilogue (csrc/bpcg1.hip: EpiV1Rows)
+            if pa_amg is None and hasattr(A.handle, "plan_for_blocks"):
+                A.handle.plan_for_blocks(op.handle)
         else:
             st.pre_diag, st.pre_bjac = None, None
         st.k = float(k) * scale
