@@ -382,8 +382,10 @@ static void scalar_step(const nss_bpcg1_t& s, int which, int it, int lanes, int 
 constexpr int kV1FoldMax = 1024;
 constexpr int kV1MergeMaxRows = 1 << 21;
 static int g_bpcg1_fold_mode = -1;
-static bool v1_merge(const nss_bpcg1_t& s, bool dist) {
-  if (dist || s.local_sums || g_bpcg1_fold_mode == 0) return false;
+static bool v1_merge(const nss_bpcg1_t& s) {
+  // (row-partitioned runs too: both operands' ghosts arrive in the grouped exchange in front of the launch, and the
+  // slab's copy of B^T indexes dp's [owned | ghosts] layout)
+  if (g_bpcg1_fold_mode == 0) return false;
   if (g_bpcg1_fold_mode < 0 && s.A->m > kV1MergeMaxRows) return false;
   return s.BT->m == s.A->m && fixed_width_copy(*s.BT);
 }
@@ -401,9 +403,9 @@ static void bpcg1_iteration(const nss_bpcg1_t& s, int it, hipStream_t st, int fi
     c.ext = ext;
     return c;
   };
-  const bool merge = v1_merge(s, dist != nullptr);           // rows of B^T inside the launch of A's rows
+  const bool merge = v1_merge(s);                            // rows of B^T inside the launch of A's rows
   bool fused_j = false;                                      // ... and the block Jacobi in the epilogue of that launch
-  const bool fast = merge && v1_fold(s);                     // ... and the scalar steps inside their consumers
+  const bool fast = merge && !dist && !s.local_sums && v1_fold(s);   // ... and the scalar steps inside their consumers
   if (on(1)) {
     if (!fast) scalar_step(s, 0, it, kWave, 0, s.partials_a, 0, s.partials_b, st);
     if (dist) {

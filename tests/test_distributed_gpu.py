@@ -489,6 +489,10 @@ def test_native_partitioned_bpcg1_single_rank(hip_engine, tmp_path, pre):
 
     try:
         distributed.Bpcg1DistLoop.try_create = classmethod(spy)
+        # (the single-GPU loop would plan A's row blocks around the Jacobi blocks and apply them in the epilogue of A's
+        # rows: another partition of the partial sums of <d, t1>.  Held to the slab's launch plan for the bit comparison;
+        # the merged rows of B^T stay on in both.)
+        assert hip_engine.lib.nss_bpcg2_fuse_block_jacobi(0) == 0
         ref = single_gpu_bpcg1(s, pre, tol, maxsteps)
         comm = RcclComm(dist, hip_engine)
         ops = DistributedStokes(s, s.line_blocks(3) if pre == "bjac" else None, comm, hip_engine)
@@ -511,6 +515,7 @@ def test_native_partitioned_bpcg1_single_rank(hip_engine, tmp_path, pre):
             run.close()
         comm.close()
     finally:
+        hip_engine.lib.nss_bpcg2_fuse_block_jacobi(-1)
         distributed.Bpcg1DistLoop.NATIVE = True
         distributed.Bpcg1DistLoop.try_create = classmethod(orig)
         dist.destroy_process_group()
