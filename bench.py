@@ -310,7 +310,7 @@ def secondary_configs(torch, hipla, headline=None):
         sysm, A, B, preA = headline
         out["cfg4_other_solvers"] = {"workload": "headline matrices (%d DoF)" % sysm.ndof,
                                      **entry_point_rates(torch, hipla, sysm, A, B, preA, ("minres", "bpcg_v1"), 50, 350)}
-    for name, dim, n, solvers, ref in (("cfg2", 2, 183, ("minres", "bpcg_v2"), "stokes_hcurldiv.py 2D, MINRES, ~1e5 DoF"),
+    for name, dim, n, solvers, ref in (("cfg2", 2, 183, ("minres", "bpcg_v2", "bpcg_v1"), "stokes_hcurldiv.py 2D, MINRES, ~1e5 DoF"),
                                        ("cfg3", 2, 577, ("bpcg_v2", "minres"), "templates/NavierStokesSIMPLE_test.py 2D, BPCG, ~1e6 DoF")):
         sysm = mac_stokes(dim, n, 0.01)
         A, B = hipla.SparseMatrix.from_scipy(sysm.A), hipla.SparseMatrix.from_scipy(sysm.B)
