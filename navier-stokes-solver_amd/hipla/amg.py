@@ -50,7 +50,14 @@ def _coarsest(A, omega, dense_limit):
     stalled on a large level) one damped-Jacobi step -- both symmetric positive definite."""
     host = A.to_scipy()
     if A.height <= dense_limit:
-        inv = sp.csr_matrix(np.linalg.inv(host.toarray()))
+        dense = np.linalg.inv(host.toarray())
+        n = dense.shape[0]
+        if np.count_nonzero(dense) == dense.size:     # (the usual case: the CSR arrays written directly -- scipy's
+            # dense -> CSR conversion goes through nonzero() and a COO sort: 0.15 s for the 1487-row coarse level of cfg4)
+            inv = sp.csr_matrix((dense.ravel(), np.tile(np.arange(n, dtype=np.int32), n),
+                                 np.arange(0, n * n + 1, n, dtype=np.int32)), shape=(n, n))
+        else:
+            inv = sp.csr_matrix(dense)
     else:
         inv = sp.diags(omega / host.diagonal()).tocsr()
     return SparseMatrix.from_scipy(inv, engine=A.engine)

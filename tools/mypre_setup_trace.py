@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Where the set-up of the reference's default preconditioner goes at cfg4 (bench: setup_s.amg_hierarchies_colouring_
+permutation): cProfile of auxiliary_space_preconditioner(...) + MypreA(GS=True, ...).  python tools/mypre_setup_trace.py [grid]"""
+import cProfile, os, pstats, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "navier-stokes-solver_amd")):
+    sys.path.insert(0, p)
+import torch
+import hipla
+from staggered_grid import mac_stokes
+from templates.NavierStokesSIMPLE_iterative import MypreA, auxiliary_space_preconditioner
+
+
+class Form:
+    def __init__(self, mat):
+        self.mat, self.condense = mat, False
+
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 136
+s = mac_stokes(3, n, 0.01)
+A = hipla.SparseMatrix.from_scipy(s.A)
+torch.cuda.synchronize()
+for label in ("cold", "warm"):
+    pr = cProfile.Profile()
+    t0 = time.perf_counter()
+    pr.enable()
+    _, _, aux = auxiliary_space_preconditioner(s)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    preA = MypreA(None, Form(A), s.line_blocks(3), GS=True, aux=aux)
+    torch.cuda.synchronize()
+    pr.disable()
+    t2 = time.perf_counter()
+    print("%s: auxiliary space + hierarchies %.3f s, sweep (colouring, permutation, inverse blocks) %.3f s" % (label, t1 - t0, t2 - t1))
+    pstats.Stats(pr).sort_stats("cumtime").print_stats(28)
+    del aux, preA
