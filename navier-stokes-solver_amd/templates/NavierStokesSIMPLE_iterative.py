@@ -72,12 +72,13 @@ class ConvectionOperator(hipla.BaseMatrix):
         y.data = -self.div * flux
 
 
-def auxiliary_space_preconditioner(system):
+def auxiliary_space_preconditioner(system, space=None):
     """``transform`` and ``preAh1`` of the reference (:208-357) on the grid restatement of the auxiliary
     space: returns (transform, preAh1, aux) with ``preAh1 = sum_c emb_c @ Preconditioner(aH1_c, 'h1amg') @
     emb_c.T`` as the protocol composition the reference writes (:336-337,357) and ``aux`` = the same
     operator ``transform @ preAh1 @ transform.T`` as one native handle (`hipla.AuxiliarySpaceAMG`)."""
-    space = system.auxiliary_space()
+    if space is None:                  # (`space`: an assembled `system.auxiliary_space()`, so that callers can time the
+        space = system.auxiliary_space()   #  host assembly of the auxiliary operators apart from the preconditioner set-up)
     transform = hipla.SparseMatrix.from_scipy(space["transform"])
     ndof = transform.width
     comps, preAh1 = [], None
