@@ -33,4 +33,7 @@ for label in ("cold", "warm"):
     t2 = time.perf_counter()
     print("%s: auxiliary space + hierarchies %.3f s, sweep (colouring, permutation, inverse blocks) %.3f s" % (label, t1 - t0, t2 - t1))
     pstats.Stats(pr).sort_stats("cumtime").print_stats(28)
+    if label == "warm":
+        print("---- by own time ----")
+        pstats.Stats(pr).strip_dirs().sort_stats("tottime").print_stats(22)
     del aux, preA
