@@ -39,6 +39,15 @@ struct nss_amg_s {
     double *x = nullptr, *r = nullptr, *b = nullptr, *y = nullptr;
   };
   std::vector<MultiLevel> multi;     // empty: components are cycled one after the other
+  // one 16-byte descriptor {first row, end row, first entry, entries} per row block of every matrix the joint cycle
+  // multiplies with: a workgroup of csr_multi_kernel then starts its matrix stream after ONE (scalar) load instead of
+  // the rowblk -> rowptr chain
+  struct MultiDesc {
+    const nss_csr_s* mat;
+    const int32_t* rowblk;           // the launch plan the descriptors were made from (checked at every launch)
+    int32_t* desc;
+  };
+  std::vector<MultiDesc> multi_desc;
 };
 
 namespace nss {

@@ -68,8 +68,22 @@ struct VecK {
 // the matrix stream so that their latency hides behind it.
 // L lanes share a pair when rows are long (the Galerkin operators of the coarser levels: ~30 entries per row, where one
 // lane per pair would leave most of the workgroup idle while it adds up its products).
+typedef const int32_t __attribute__((address_space(4)))* MultiDesc;   // (constant address space: scalar loads)
+
+__global__ __launch_bounds__(kBlock) void multi_desc_kernel(int32_t nblk, const int32_t* __restrict__ rowblk,
+                                                             const int32_t* __restrict__ rowptr, int32_t* __restrict__ desc) {
+  const int b = blockIdx.x * kBlock + threadIdx.x;
+  if (b >= nblk) return;
+  const int r0 = rowblk[b], r1 = rowblk[b + 1], p0 = rowptr[r0];
+  desc[4 * b] = r0;
+  desc[4 * b + 1] = r1;
+  desc[4 * b + 2] = p0;
+  desc[4 * b + 3] = rowptr[r1] - p0;
+}
+
 template <int K, int L, class Epi>
-__global__ __launch_bounds__(kBlock) void csr_multi_kernel(CsrView a, const double* __restrict__ x, Epi epi) {
+__global__ __launch_bounds__(kBlock) void csr_multi_kernel(CsrView a, const int32_t* __restrict__ desc,
+                                                            const double* __restrict__ x, Epi epi) {
   __shared__ double prod[K * kMultiPlane];
   __shared__ double red[kRedDoubles];
   if (epi.skip()) return;
@@ -77,8 +91,8 @@ __global__ __launch_bounds__(kBlock) void csr_multi_kernel(CsrView a, const doub
   const int lb = (wg & (kXcds - 1)) * a.per_xcd + (wg >> 3);          // the XCD-aware map of the other kernels
   if (lb >= a.nblk) return;
   const int b = a.blk0 + lb;
-  const int r0 = a.rowblk[b], r1 = a.rowblk[b + 1];
-  const int p0 = a.rowptr[r0], cnt = a.rowptr[r1] - p0;
+  const MultiDesc d = (MultiDesc)(desc + size_t(b) * 4);
+  const int r0 = d[0], r1 = d[1], p0 = d[2], cnt = d[3];
   if (cnt <= kMultiChunk) {
     constexpr int kPF = 2;                                             // pairs per lane whose operands are prefetched
     constexpr int kLanePairs = kBlock / L;                             // pairs per pass of the workgroup
@@ -224,15 +238,25 @@ __global__ __launch_bounds__(kBlock) void amg_diag_multi_kernel(int32_t n, doubl
   }
 }
 
+static const int32_t* multi_desc_of(const nss_amg_s& aux, const nss_csr_s& A) {
+  for (const auto& e : aux.multi_desc)
+    if (e.mat == &A) {
+      if (e.rowblk != A.rowblk) throw Error("amg: a level matrix of the joint cycle was re-planned after the handle was created");
+      return e.desc;
+    }
+  throw Error("amg: a matrix of the joint cycle has no row-block descriptors");
+}
+
 template <int K, class Epi>
-static void launch_multi(const nss_csr_s& A, const double* x, const Epi& epi, hipStream_t st) {
+static void launch_multi(const nss_amg_s& aux, const nss_csr_s& A, const double* x, const Epi& epi, hipStream_t st) {
   if (A.m == 0 || A.nblk == 0) return;
   const dim3 grid(nss_csr_s::grid(A.nblk)), block(kBlock);
   const CsrView v = A.view(0, A.nblk, 0);
+  const int32_t* desc = multi_desc_of(aux, A);
   const double mean = double(A.nnz) / double(A.m);                     // lanes per (row, k) pair by the mean row length
-  if (mean >= 48.0) hipLaunchKernelGGL((csr_multi_kernel<K, 4, Epi>), grid, block, 0, st, v, x, epi);
-  else if (mean >= 20.0) hipLaunchKernelGGL((csr_multi_kernel<K, 2, Epi>), grid, block, 0, st, v, x, epi);
-  else hipLaunchKernelGGL((csr_multi_kernel<K, 1, Epi>), grid, block, 0, st, v, x, epi);
+  if (mean >= 48.0) hipLaunchKernelGGL((csr_multi_kernel<K, 4, Epi>), grid, block, 0, st, v, desc, x, epi);
+  else if (mean >= 20.0) hipLaunchKernelGGL((csr_multi_kernel<K, 2, Epi>), grid, block, 0, st, v, desc, x, epi);
+  else hipLaunchKernelGGL((csr_multi_kernel<K, 1, Epi>), grid, block, 0, st, v, desc, x, epi);
   NSS_CHECK_LAUNCH();
 }
 
@@ -244,19 +268,19 @@ static void cycle_multi(const nss_amg_s& aux, const nss_amg_s& h, int l, VecK b,
   const nss_amg_s::MultiLevel& w = aux.multi[size_t(l)];
   if (l == int(h.levels.size()) - 1) {
     // (b is interleaved here unless the hierarchy has one level only)
-    launch_multi<K>(*h.coarse_inverse, b.p, MAxpby<K>{scale, accumulate ? 1.0 : 0.0, out, done}, st);
+    launch_multi<K>(aux, *h.coarse_inverse, b.p, MAxpby<K>{scale, accumulate ? 1.0 : 0.0, out, done}, st);
     return;
   }
   const int n = lv.n;
   hipLaunchKernelGGL((amg_diag_multi_kernel<K>), dim3(stream_grid(n, kBlock * 2)), dim3(kBlock), 0, st, n, h.omega, lv.dinv,
                      b, w.x, done);
   NSS_CHECK_LAUNCH();
-  launch_multi<K>(*lv.A, w.x, MResidual<K>{b, w.r, done}, st);
+  launch_multi<K>(aux, *lv.A, w.x, MResidual<K>{b, w.r, done}, st);
   const nss_amg_s::MultiLevel& nx = aux.multi[size_t(l) + 1];
-  launch_multi<K>(*lv.R, w.r, MAxpby<K>{1.0, 0.0, VecK{nx.b, K, 1}, done}, st);
+  launch_multi<K>(aux, *lv.R, w.r, MAxpby<K>{1.0, 0.0, VecK{nx.b, K, 1}, done}, st);
   cycle_multi<K>(aux, h, l + 1, VecK{nx.b, K, 1}, VecK{nx.y, K, 1}, st, done, 1.0, false);
-  launch_multi<K>(*lv.P, nx.y, MAxpby<K>{1.0, 1.0, VecK{w.x, K, 1}, done}, st);
-  launch_multi<K>(*lv.A, w.x, MJacobi<K>{b, w.x, lv.dinv, out, h.omega, scale, done, accumulate}, st);
+  launch_multi<K>(aux, *lv.P, nx.y, MAxpby<K>{1.0, 1.0, VecK{w.x, K, 1}, done}, st);
+  launch_multi<K>(aux, *lv.A, w.x, MJacobi<K>{b, w.x, lv.dinv, out, h.omega, scale, done, accumulate}, st);
 }
 
 static int g_amg_batch = 1;
@@ -367,6 +391,22 @@ int nss_amg_create_auxiliary(nss_csr_t T, nss_csr_t TT, int32_t ncomp, const nss
           if (lv.R) replan_row_blocks(*const_cast<nss_csr_s*>(lv.R), kMultiChunk);
         }
         replan_row_blocks(*const_cast<nss_csr_s*>(h.coarse_inverse), kMultiChunk);
+        auto describe = [&](const nss_csr_s* M) {
+          if (!M || M->nblk == 0) return;
+          int32_t* desc = nullptr;
+          NSS_HIP(hipMalloc(&desc, sizeof(int32_t) * 4 * size_t(M->nblk)));
+          a->multi_desc.push_back({M, M->rowblk, desc});
+          hipLaunchKernelGGL(multi_desc_kernel, dim3((M->nblk + kBlock - 1) / kBlock), dim3(kBlock), 0, nullptr, M->nblk,
+                             M->rowblk, M->rowptr, desc);
+          NSS_CHECK_LAUNCH();
+        };
+        for (const AmgLevel& lv : h.levels) {
+          describe(lv.A);
+          describe(lv.P);
+          describe(lv.R);
+        }
+        describe(h.coarse_inverse);
+        NSS_HIP(hipDeviceSynchronize());
         a->multi.resize(h.levels.size());
         for (size_t l = 0; l < h.levels.size(); ++l) {
           const size_t lb = sizeof(double) * size_t(ncomp) * size_t(std::max(1, h.levels[l].n));
@@ -389,6 +429,7 @@ int nss_amg_destroy(nss_amg_t a) {
     if (!a) return;
     (void)hipFree(a->aux_r);
     (void)hipFree(a->aux_z);
+    for (auto& e : a->multi_desc) (void)hipFree(e.desc);
     for (auto& m : a->multi) {
       (void)hipFree(m.x);
       (void)hipFree(m.r);
